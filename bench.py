@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py — grasps/s of the PointNetGPD grasp-evaluation hot path on MI355X.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` (for N>1 launched under
+torch.distributed.run, one rank per GPU).  Prints ONE JSON line on rank 0.
+
+Workload = BASELINE.json configs[1]: 2-class PointNetCls, N=1024 points, batch 1024 clouds per
+GPU, fp32, synthetic in-gripper clouds already resident in HBM.  One "step" = one eval-mode
+``PointNetCls.forward`` over the batch (STN trunk + STN FC + feat trunk + head, log-probs left on
+the device).  Inference shards by batch with no data-path collective -> weak scaling.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+FLOP_PER_POINT_TRUNK = 2 * (3 * 64 + 64 * 128 + 128 * 1024)   # 278,912
+FLOP_FC_K2 = 2_627_072
+PEAK_FP32_MFMA_TFLOPS = 157.3                                   # MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def flops_per_grasp(n, k=2):
+    return n * (2 * FLOP_PER_POINT_TRUNK + 18) + FLOP_FC_K2 + (512 if k == 3 else 0)
+
+
+def build_model(num_points, k, device):
+    from pointnetgpd_amd.model.pointnet import PointNetCls
+    torch.manual_seed(0)
+    m = PointNetCls(num_points=num_points, input_chann=3, k=k)
+    # non-trivial eval-mode BN: the same recipe the parity tests use
+    g = torch.Generator().manual_seed(4321)
+    with torch.no_grad():
+        for name, buf in m.named_buffers():
+            if name.endswith("running_mean"):
+                buf.copy_(torch.randn(buf.shape, generator=g) * 0.1)
+            elif name.endswith("running_var"):
+                buf.copy_(torch.rand(buf.shape, generator=g) + 0.5)
+        for name, p in m.named_parameters():
+            if "bn" in name.split(".")[-2]:
+                if name.endswith("weight"):
+                    p.copy_(torch.rand(p.shape, generator=g) + 0.5)
+                else:
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+    return m.eval().to(device)
+
+
+def synth_clouds(b, n, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    w = 0.085
+    u = torch.rand(b, 3, n, generator=g) - 0.5
+    return (u * torch.tensor([w / 2, w, w / 2]).view(1, 3, 1)).float().contiguous().to(device)
+
+
+def cpu_baseline(num_points, k, budget_s=20.0):
+    """The oracle's torch-functional restatement (the reference's own ATen op sequence) timed on
+    this box's host cores, on a bounded sample of the same workload."""
+    from oracle import pointnet_oracle as po
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    m = build_model(num_points, k, torch.device("cpu"))
+    sd = {kk: v.detach().clone() for kk, v in m.state_dict().items()}
+    b = 64
+    x = synth_clouds(b, num_points, 99, torch.device("cpu"))
+    with torch.no_grad():
+        t0 = time.perf_counter(); po.forward_torch(sd, x); warm = time.perf_counter() - t0
+        iters = max(2, min(20, int(budget_s / max(warm, 1e-3))))
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            po.forward_torch(sd, x)
+        dt = (time.perf_counter() - t0) / iters
+    return {"value": round(b / dt, 2), "unit": "grasps/s", "cores": cores, "kind": "port",
+            "sample": f"oracle.forward_torch (reference ATen op sequence, eval, fp32), B={b} N={num_points}, "
+                      f"{iters} iters, {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--num-points", type=int, default=1024)
+    ap.add_argument("--classes", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    B, N, k = args.batch, args.num_points, args.classes
+    model = build_model(N, k, dev)
+    x = synth_clouds(B, N, 1234 + rank, dev)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            model(x)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out, _ = model(x)
+        sync_all()
+        dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    assert torch.isfinite(out).all()
+
+    # ---- dominant kernel (fused trunk) timed live with events on the launch stream
+    from pointnetgpd_amd import ops
+    from pointnetgpd_amd.model import pointnet as pn
+    wts = pn._trunk_infer_weights(model.feat.stn, dev)
+    reps = max(10, args.steps)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.no_grad():
+        ops.trunk_fwd_infer(x, None, *wts, relu_last=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            ops.trunk_fwd_infer(x, None, *wts, relu_last=True)
+        e1.record()
+        torch.cuda.synchronize()
+    trunk_ms = e0.elapsed_time(e1) / reps
+    trunk_flops = B * N * FLOP_PER_POINT_TRUNK
+    achieved = trunk_flops / (trunk_ms * 1e-3) / 1e12
+
+    if rank == 0:
+        value = world * B * args.steps / dt
+        alg_bytes = B * (4 * 3 * N + 4 * (k + 9))
+        res = {
+            "metric": "grasps/sec (inference) at B=1024,N=1024",
+            "value": round(value, 1), "unit": "grasps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: 2-class PointNetCls eval forward, fp32, "
+                                   "synthetic in-gripper clouds resident in HBM",
+                       "batch_per_gpu": B, "num_points": N, "classes": k, "mode": "infer",
+                       "sharding": f"batch x{world}, no collective"},
+            "tflops_effective": round(value * flops_per_grasp(N, k) / 1e12, 2),
+            "hbm_algorithmic_gbs": round(value / world * alg_bytes / B / 1e9, 3),
+            "roofline": {"bound": "mfma", "kernel": "trunk_infer_kernel", "achieved": round(achieved, 2),
+                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "avg_launch_ms": round(trunk_ms, 4),
+                         "flops_per_launch": trunk_flops},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(N, k)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,102 @@
+/*
+ * pngpd.h — C ABI of libpngpd.so, the MI355X (gfx950) implementation of the
+ * PointNetGPD grasp-evaluation hot path.
+ *
+ * The reference (lianghongzhuo/PointNetGPD) has no FFI for this path: it is pure
+ * Python dispatching ATen ops.  Each entry point below therefore cites the reference
+ * *call site* it replaces (paths relative to the reference root).  The boundary is
+ * plain C: raw device pointers, sizes, and a HIP stream passed as `void*`
+ * (a `hipStream_t`; NULL = the default stream).  No torch types, no allocation,
+ * no host/device synchronisation, no retained pointers.  Every function returns
+ * PNGPD_OK (0) or a PNGPD_ERR_* code; `pngpd_strerror` names it.
+ *
+ * Layout conventions (all row-major, contiguous, device memory unless stated):
+ *   clouds      x      (B,3,N)  fp32   channel-major, as Dataset.__getitem__ +
+ *                                       default_collate produce (dataset.py:440-444)
+ *   pooled      g      (B,1024) fp32   output of MaxPool1d+view (pointnet.py:32-33,148-149)
+ *   transforms  trans  (B,3,3)  fp32   STN3d output (pointnet.py:44)
+ *   weights     W      (Cout,Cin) fp32 Conv1d(k=1).weight[:,:,0] / Linear.weight
+ */
+#ifndef PNGPD_H
+#define PNGPD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PNGPD_ABI_VERSION 1
+
+enum {
+    PNGPD_OK = 0,
+    PNGPD_ERR_INVALID_ARG = 1,   /* NULL pointer, non-positive size, unsupported shape */
+    PNGPD_ERR_WORKSPACE = 2,     /* workspace smaller than pngpd_*_workspace_bytes()  */
+    PNGPD_ERR_UNSUPPORTED = 3,
+    PNGPD_ERR_HIP = 100          /* PNGPD_ERR_HIP + hipError_t of the failed launch   */
+};
+
+/* Weight layouts produced by pngpd_fold_conv_bn. */
+enum {
+    PNGPD_LAYOUT_ROWMAJOR = 0,   /* (C,K) as given                                     */
+    PNGPD_LAYOUT_MFMA_B = 1      /* v_mfma_f32_32x32x2_f32 B-fragment order, see DESIGN */
+};
+
+/* Epilogues of pngpd_fc_fwd. */
+enum {
+    PNGPD_EPI_NONE = 0,
+    PNGPD_EPI_RELU = 1,          /* F.relu(bn(fc(x))) with BN folded   pointnet.py:35-36,191-192 */
+    PNGPD_EPI_ADD_IDEN3 = 2,     /* fc3(x) + eye(3).view(1,9)          pointnet.py:37-43         */
+    PNGPD_EPI_LOG_SOFTMAX = 3    /* F.log_softmax(fc3(x), dim=-1)      pointnet.py:193-194       */
+};
+
+int pngpd_abi_version(void);
+const char *pngpd_strerror(int code);
+/* Tuning knobs for experiments ("trunk_target_blocks": workgroups the trunk launch aims for). */
+int pngpd_set_option(const char *name, int value);
+
+/*
+ * Fold an eval-mode BatchNorm1d into the preceding 1x1 Conv1d / Linear and lay the
+ * weight out for the kernels.  Replaces the eval-mode `self.bnX(self.convX(x))`
+ * pairs of pointnet.py:29-31,35-36,144-147,191-192:
+ *     s = gamma / sqrt(var + eps);  Wf = W * s[:,None];  bf = (b - mean) * s + beta
+ * gamma == NULL means "no BatchNorm" (fc3 layers): Wf = W, bf = b.
+ * layout PNGPD_LAYOUT_MFMA_B requires C % 32 == 0 and K % 8 == 0.
+ */
+int pngpd_fold_conv_bn(const float *W, const float *b, const float *gamma, const float *beta,
+                       const float *mean, const float *var, float eps, int C, int K, int layout,
+                       float *Wf, float *bf, void *stream);
+
+/*
+ * Fused per-point MLP 3->64->128->1024 (BN folded, ReLU after layers 1,2 and — iff
+ * relu_last — after layer 3) + global max over the N points of each cloud.  The
+ * (B,1024,N) activation never leaves the chip.  Replaces, in eval mode,
+ *   STN3d trunk        pointnet.py:29-33   (relu_last = 1, trans = NULL)
+ *   PointNetfeat trunk pointnet.py:140-149 (relu_last = 0, trans = STN output; the
+ *                      transpose/bmm/transpose of :140-143 is applied per point)
+ *   x      (B,3,N) fp32;  trans (B,3,3) fp32 or NULL
+ *   w1 (64,3) rowmajor folded, b1 (64);  w2p (128,64) MFMA_B folded, b2 (128);
+ *   w3p (1024,128) MFMA_B folded, b3 (1024)
+ *   out_pool (B,1024) fp32
+ *   workspace: pngpd_trunk_workspace_bytes(B,N) bytes of device scratch.
+ */
+size_t pngpd_trunk_workspace_bytes(int B, int N);
+int pngpd_trunk_fwd_infer(const float *x, int B, int N, const float *trans,
+                          const float *w1, const float *b1, const float *w2p, const float *b2,
+                          const float *w3p, const float *b3, int relu_last,
+                          float *out_pool, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * out = epilogue(in @ W^T + bias)   in (B,K), W (Nout,K) rowmajor (BN pre-folded), out (B,Nout).
+ * Replaces the Linear(+BatchNorm1d eval)(+ReLU) stacks pointnet.py:35-37,191-193 and the
+ * `+ iden` (:39-43) / `F.log_softmax` (:194) tails.  K % 8 == 0.  ADD_IDEN3 needs Nout == 9,
+ * LOG_SOFTMAX needs Nout <= 32.
+ */
+int pngpd_fc_fwd(const float *in, int B, int K, const float *W, const float *bias, int Nout,
+                 int epilogue, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PNGPD_H */

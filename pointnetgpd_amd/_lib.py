@@ -1,0 +1,70 @@
+"""ctypes binding of libpngpd.so (the C ABI declared in include/pngpd.h).
+
+The library is built in-tree (``pointnetgpd_amd/libpngpd.so``) by ``__graft_entry__.build()``
+or ``make -C pointnetgpd_amd/csrc``.  There is NO fallback: any CUDA-tensor op raises
+``RuntimeError`` if the library is missing or fails to load.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpngpd.so")
+ABI_VERSION = 1
+
+_lib = None
+_load_error = None
+
+c_f32p = ctypes.c_void_p
+c_void = ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/pngpd.h one-to-one (checked by tests).
+SIGNATURES = {
+    "pngpd_abi_version": (ctypes.c_int, []),
+    "pngpd_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "pngpd_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
+    "pngpd_fold_conv_bn": (ctypes.c_int, [c_f32p] * 6 + [ctypes.c_float, ctypes.c_int, ctypes.c_int,
+                                                       ctypes.c_int, c_f32p, c_f32p, c_void]),
+    "pngpd_trunk_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "pngpd_trunk_fwd_infer": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, c_f32p] + [c_f32p] * 6 +
+                              [ctypes.c_int, c_f32p, c_void, ctypes.c_size_t, c_void]),
+    "pngpd_fc_fwd": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, ctypes.c_int,
+                                    ctypes.c_int, c_f32p, c_void]),
+}
+
+
+def load():
+    """Return the loaded library (cached).  Raises RuntimeError — never falls back."""
+    global _lib, _load_error
+    if _lib is not None:
+        return _lib
+    if _load_error is not None:
+        raise RuntimeError(_load_error)
+    # torch must be imported first so that libamdhip64.so.7 resolves to the HIP runtime
+    # torch already loaded (one runtime per process; device pointers are shared with torch).
+    import torch  # noqa: F401
+    if not os.path.exists(LIB_PATH):
+        _load_error = (f"libpngpd.so not found at {LIB_PATH}: build it with "
+                       f"`python -c 'import __graft_entry__ as g; g.build()'` "
+                       f"(hipcc --offload-arch=gfx950).  There is no CPU/PyTorch fallback for CUDA tensors.")
+        raise RuntimeError(_load_error)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        _load_error = f"failed to load {LIB_PATH}: {e}"
+        raise RuntimeError(_load_error)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.pngpd_abi_version()
+    if got != ABI_VERSION:
+        _load_error = f"libpngpd ABI version {got} != expected {ABI_VERSION}; rebuild the library"
+        raise RuntimeError(_load_error)
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().pngpd_strerror(code).decode()
+        raise RuntimeError(f"libpngpd: {what} failed: {msg} (code {code})")

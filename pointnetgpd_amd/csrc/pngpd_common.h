@@ -1,0 +1,27 @@
+// Shared device helpers for libpngpd (gfx950 / CDNA4 only — no portability layer).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/pngpd.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define PNGPD_WAVE 64
+
+// v_mfma_f32_32x32x2_f32: D(32x32) += A(32x2) * B(2x32), exact fp32 (fmaf chain).
+//   lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];
+//   D register r of lane l is D[i = (r&3) + 8*(r>>2) + 4*(l>>5)][j = l&31].
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+static inline int pngpd_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PNGPD_OK : (PNGPD_ERR_HIP + (int)e);
+}

@@ -1,0 +1,343 @@
+"""Drop-in mirror of the reference's ``PointNetGPD/model/pointnet.py`` module surface.
+
+Same class names, constructor signatures, sub-module attribute names and construction
+order (hence identical ``state_dict`` keys, identical seeded initialisation, and whole-module
+pickles that load across implementations):
+
+    PointNetCls(num_points=2500, input_chann=3, k=2).forward(x: (B,3,N) fp32)
+        -> (log_probs (B,k), trans (B,3,3))                      reference pointnet.py:177-194
+    PointNetfeat(...).forward(x) -> (global_feat (B,1024), trans)           pointnet.py:123-154
+    STN3d(...).forward(x) -> trans (B,3,3)                                  pointnet.py:8-45
+
+Dispatch is by the input's device and is explicit, never silent:
+
+* CUDA tensor  -> libpngpd HIP kernels (``include/pngpd.h``).  A missing / unloadable library
+  raises ``RuntimeError``; nothing falls back to ATen.
+* CPU tensor   -> the plain ATen composite the reference itself runs on CPU
+  (BASELINE config 1 "CPU PyTorch (plumbing, no GPU)").
+
+``DualPointNetCls`` / ``DualPointNetfeat`` / ``SimpleSTN3d`` / ``PointNetDenseCls`` are never
+instantiated by any reference script; they are kept as plain-ATen modules only
+so that ``from model.pointnet import PointNetCls, DualPointNetCls`` (main_1v.py:16) works.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+_TRUNK_WIDTHS = (64, 128, 1024)
+
+
+def _check_points(x, num_points, input_chann):
+    if x.dim() != 3 or x.shape[1] != input_chann:
+        raise RuntimeError(f"expected input of shape (B,{input_chann},N), got {tuple(x.shape)}")
+    if x.shape[2] != num_points:
+        # The reference's MaxPool1d(num_points)+view(-1,1024) silently corrupts the batch
+        # dimension when N != num_points; fail instead.
+        raise RuntimeError(f"N={x.shape[2]} points per cloud but the model was built with "
+                           f"num_points={num_points}")
+
+
+class _FoldCache:
+    """Per-device cache of BN-folded / MFMA-packed inference weights, invalidated by the
+    version counters of the tensors it was built from (optimizer steps, load_state_dict)."""
+
+    def __init__(self):
+        self.store = {}
+
+    def get(self, key, tensors, build):
+        sig = tuple((t.data_ptr(), t._version) for t in tensors)
+        hit = self.store.get(key)
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        val = build()
+        self.store[key] = (sig, val)
+        return val
+
+
+class _HipModule(nn.Module):
+    """nn.Module with a non-persistent fold cache (never pickled, never in state_dict)."""
+
+    def _cache(self):
+        c = self.__dict__.get("_fold_cache")
+        if c is None:
+            c = _FoldCache()
+            self.__dict__["_fold_cache"] = c
+        return c
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d.pop("_fold_cache", None)
+        return d
+
+
+def _bn_tensors(bn):
+    return [bn.weight, bn.bias, bn.running_mean, bn.running_var]
+
+
+def _fold(layer, bn, layout, device):
+    if bn is None:
+        return ops.fold_conv_bn(layer.weight, layer.bias, layout=layout)
+    return ops.fold_conv_bn(layer.weight, layer.bias, bn.weight, bn.bias, bn.running_mean,
+                            bn.running_var, eps=bn.eps, layout=layout)
+
+
+def _trunk_infer_weights(mod, device):
+    """Folded weights of a conv1..3 / bn1..3 trunk, in the layouts pngpd_trunk_fwd_infer wants."""
+    srcs = []
+    for i in (1, 2, 3):
+        conv, bn = getattr(mod, f"conv{i}"), getattr(mod, f"bn{i}")
+        srcs += [conv.weight, conv.bias] + _bn_tensors(bn)
+
+    def build():
+        w1, b1 = _fold(mod.conv1, mod.bn1, ops.LAYOUT_ROWMAJOR, device)
+        w2, b2 = _fold(mod.conv2, mod.bn2, ops.LAYOUT_MFMA_B, device)
+        w3, b3 = _fold(mod.conv3, mod.bn3, ops.LAYOUT_MFMA_B, device)
+        return (w1, b1, w2, b2, w3, b3)
+
+    return mod._cache().get(("trunk", device), srcs, build)
+
+
+def _fc_infer_weights(mod, names, device):
+    """names: [(linear_attr, bn_attr or None), ...] -> [(Wf, bf), ...]."""
+    srcs = []
+    for lin, bn in names:
+        l = getattr(mod, lin)
+        srcs += [l.weight, l.bias] + (_bn_tensors(getattr(mod, bn)) if bn else [])
+
+    def build():
+        return [_fold(getattr(mod, lin), getattr(mod, bn) if bn else None, ops.LAYOUT_ROWMAJOR, device)
+                for lin, bn in names]
+
+    return mod._cache().get(("fc",) + tuple(n for n, _ in names) + (device,), srcs, build)
+
+
+def _trunk_aten(mod, x, relu_last):
+    """The ATen composite of a trunk (CPU plumbing path)."""
+    x = F.relu(mod.bn1(mod.conv1(x)))
+    x = F.relu(mod.bn2(mod.conv2(x)))
+    x = mod.bn3(mod.conv3(x))
+    if relu_last:
+        x = F.relu(x)
+    return torch.max(x, dim=2)[0]
+
+
+def _train_on_cuda():
+    raise NotImplementedError(
+        "train-mode (batch-statistics BatchNorm, backward) HIP kernels are not available in this "
+        "build; call .eval() for the HIP inference path or run training on CPU tensors")
+
+
+# ---------------------------------------------------------------------------------------
+# hot-path classes
+# ---------------------------------------------------------------------------------------
+class STN3d(_HipModule):
+    """Input transform net (reference pointnet.py:8-45)."""
+
+    def __init__(self, num_points=2500, input_chann=3):
+        super().__init__()
+        self.num_points = num_points
+        widths = (input_chann,) + _TRUNK_WIDTHS
+        for i in range(3):
+            setattr(self, f"conv{i + 1}", nn.Conv1d(widths[i], widths[i + 1], 1))
+        self.mp1 = nn.MaxPool1d(num_points)
+        self.fc1 = nn.Linear(1024, 512)
+        self.fc2 = nn.Linear(512, 256)
+        self.fc3 = nn.Linear(256, 9)
+        self.relu = nn.ReLU()
+        for i, c in enumerate(_TRUNK_WIDTHS + (512, 256)):
+            setattr(self, f"bn{i + 1}", nn.BatchNorm1d(c))
+
+    def forward(self, x):
+        _check_points(x, self.num_points, self.conv1.in_channels)
+        if x.is_cuda:
+            if self.training:
+                _train_on_cuda()
+            return self._forward_hip_infer(x)
+        g = _trunk_aten(self, x, relu_last=True)
+        g = F.relu(self.bn4(self.fc1(g)))
+        g = F.relu(self.bn5(self.fc2(g)))
+        g = self.fc3(g)
+        return (g + torch.eye(3, dtype=g.dtype, device=g.device).reshape(1, 9)).view(-1, 3, 3)
+
+    def _forward_hip_infer(self, x):
+        dev = x.device
+        x = x.contiguous()
+        pooled = ops.trunk_fwd_infer(x, None, *_trunk_infer_weights(self, dev), relu_last=True)
+        (w1, b1), (w2, b2), (w3, b3) = _fc_infer_weights(self, [("fc1", "bn4"), ("fc2", "bn5"), ("fc3", None)], dev)
+        g = ops.fc_fwd(pooled, w1, b1, ops.EPI_RELU)
+        g = ops.fc_fwd(g, w2, b2, ops.EPI_RELU)
+        return ops.fc_fwd(g, w3, b3, ops.EPI_ADD_IDEN3).view(-1, 3, 3)
+
+
+class PointNetfeat(_HipModule):
+    """Transform + per-point MLP + global max feature (reference pointnet.py:123-154)."""
+
+    def __init__(self, num_points=2500, input_chann=3, global_feat=True):
+        super().__init__()
+        self.stn = STN3d(num_points=num_points, input_chann=input_chann)
+        widths = (input_chann,) + _TRUNK_WIDTHS
+        for i in range(3):
+            setattr(self, f"conv{i + 1}", nn.Conv1d(widths[i], widths[i + 1], 1))
+        for i, c in enumerate(_TRUNK_WIDTHS):
+            setattr(self, f"bn{i + 1}", nn.BatchNorm1d(c))
+        self.mp1 = nn.MaxPool1d(num_points)
+        self.num_points = num_points
+        self.global_feat = global_feat
+
+    def forward(self, x):
+        _check_points(x, self.num_points, self.conv1.in_channels)
+        if x.is_cuda and self.global_feat:
+            if self.training:
+                _train_on_cuda()
+            x = x.contiguous()
+            trans = self.stn(x)
+            pooled = ops.trunk_fwd_infer(x, trans.contiguous(), *_trunk_infer_weights(self, x.device),
+                                         relu_last=False)
+            return pooled, trans
+        # ATen composite: CPU plumbing path, and the (never used) global_feat=False branch.
+        trans = self.stn(x)
+        x = torch.bmm(x.transpose(2, 1), trans).transpose(2, 1)
+        x = F.relu(self.bn1(self.conv1(x)))
+        pointfeat = x
+        x = F.relu(self.bn2(self.conv2(x)))
+        x = self.bn3(self.conv3(x))
+        g = torch.max(x, dim=2)[0]
+        if self.global_feat:
+            return g, trans
+        g = g.view(-1, 1024, 1).repeat(1, 1, self.num_points)
+        return torch.cat([g, pointfeat], 1), trans
+
+
+class PointNetCls(_HipModule):
+    """Grasp classifier (reference pointnet.py:177-194): log-probabilities + the 3x3 transform."""
+
+    def __init__(self, num_points=2500, input_chann=3, k=2):
+        super().__init__()
+        self.num_points = num_points
+        self.feat = PointNetfeat(num_points, input_chann=input_chann, global_feat=True)
+        self.fc1 = nn.Linear(1024, 512)
+        self.fc2 = nn.Linear(512, 256)
+        self.fc3 = nn.Linear(256, k)
+        self.bn1 = nn.BatchNorm1d(512)
+        self.bn2 = nn.BatchNorm1d(256)
+        self.relu = nn.ReLU()
+
+    def forward(self, x):
+        g, trans = self.feat(x)
+        if g.is_cuda:
+            if self.training:
+                _train_on_cuda()
+            (w1, b1), (w2, b2), (w3, b3) = _fc_infer_weights(self, [("fc1", "bn1"), ("fc2", "bn2"), ("fc3", None)],
+                                                             g.device)
+            g = ops.fc_fwd(g, w1, b1, ops.EPI_RELU)
+            g = ops.fc_fwd(g, w2, b2, ops.EPI_RELU)
+            return ops.fc_fwd(g, w3, b3, ops.EPI_LOG_SOFTMAX), trans
+        g = F.relu(self.bn1(self.fc1(g)))
+        g = F.relu(self.bn2(self.fc2(g)))
+        return F.log_softmax(self.fc3(g), dim=-1), trans
+
+
+# ---------------------------------------------------------------------------------------
+# import-compatibility classes (plain ATen; out of the hot path, see module docstring)
+# ---------------------------------------------------------------------------------------
+class SimpleSTN3d(nn.Module):
+    """Small T-Net (reference pointnet.py:48-85); never instantiated by the reference scripts
+    except through DualPointNetfeat."""
+
+    def __init__(self, num_points=2500, input_chann=3):
+        super().__init__()
+        self.num_points = num_points
+        widths = (input_chann, 64, 128, 256)
+        for i in range(3):
+            setattr(self, f"conv{i + 1}", nn.Conv1d(widths[i], widths[i + 1], 1))
+        self.mp1 = nn.MaxPool1d(num_points)
+        self.fc1 = nn.Linear(256, 128)
+        self.fc2 = nn.Linear(128, 64)
+        self.fc3 = nn.Linear(64, 9)
+        self.relu = nn.ReLU()
+        for i, c in enumerate((64, 128, 256, 128, 64)):
+            setattr(self, f"bn{i + 1}", nn.BatchNorm1d(c))
+
+    def forward(self, x):
+        g = _trunk_aten(self, x, relu_last=True)
+        g = F.relu(self.bn4(self.fc1(g)))
+        g = F.relu(self.bn5(self.fc2(g)))
+        g = self.fc3(g)
+        return (g + torch.eye(3, dtype=g.dtype, device=g.device).reshape(1, 9)).view(-1, 3, 3)
+
+
+class DualPointNetfeat(nn.Module):
+    """Two-cloud feature extractor (reference pointnet.py:88-120)."""
+
+    def __init__(self, num_points=2500, input_chann=6, global_feat=True):
+        super().__init__()
+        self.stn1 = SimpleSTN3d(num_points=num_points, input_chann=input_chann // 2)
+        self.stn2 = SimpleSTN3d(num_points=num_points, input_chann=input_chann // 2)
+        widths = (input_chann,) + _TRUNK_WIDTHS
+        for i in range(3):
+            setattr(self, f"conv{i + 1}", nn.Conv1d(widths[i], widths[i + 1], 1))
+        for i, c in enumerate(_TRUNK_WIDTHS):
+            setattr(self, f"bn{i + 1}", nn.BatchNorm1d(c))
+        self.mp1 = nn.MaxPool1d(num_points)
+        self.num_points = num_points
+        self.global_feat = global_feat
+
+    def forward(self, x):
+        t1, t2 = self.stn1(x[:, 0:3, :]), self.stn2(x[:, 3:6, :])
+        xt = x.transpose(2, 1)
+        x = torch.cat([torch.bmm(xt[..., 0:3], t1), torch.bmm(xt[..., 3:6], t2)], dim=-1).transpose(2, 1)
+        x = F.relu(self.bn1(self.conv1(x)))
+        pointfeat = x
+        x = F.relu(self.bn2(self.conv2(x)))
+        g = torch.max(self.bn3(self.conv3(x)), dim=2)[0]
+        if self.global_feat:
+            return g, t1 + t2
+        g = g.view(-1, 1024, 1).repeat(1, 1, self.num_points)
+        return torch.cat([g, pointfeat], 1), t1 + t2
+
+
+class DualPointNetCls(nn.Module):
+    """Two-cloud classifier (reference pointnet.py:157-174)."""
+
+    def __init__(self, num_points=2500, input_chann=3, k=2):
+        super().__init__()
+        self.num_points = num_points
+        self.feat = DualPointNetfeat(num_points, input_chann=input_chann, global_feat=True)
+        self.fc1 = nn.Linear(1024, 512)
+        self.fc2 = nn.Linear(512, 256)
+        self.fc3 = nn.Linear(256, k)
+        self.bn1 = nn.BatchNorm1d(512)
+        self.bn2 = nn.BatchNorm1d(256)
+        self.relu = nn.ReLU()
+
+    def forward(self, x):
+        g, trans = self.feat(x)
+        g = F.relu(self.bn1(self.fc1(g)))
+        g = F.relu(self.bn2(self.fc2(g)))
+        return F.log_softmax(self.fc3(g), dim=-1), trans
+
+
+class PointNetDenseCls(nn.Module):
+    """Per-point segmentation head (reference pointnet.py:197-221)."""
+
+    def __init__(self, num_points=2500, input_chann=3, k=2):
+        super().__init__()
+        self.num_points = num_points
+        self.k = k
+        self.feat = PointNetfeat(num_points, input_chann=input_chann, global_feat=False)
+        widths = (1088, 512, 256, 128, k)
+        for i in range(4):
+            setattr(self, f"conv{i + 1}", nn.Conv1d(widths[i], widths[i + 1], 1))
+        for i, c in enumerate((512, 256, 128)):
+            setattr(self, f"bn{i + 1}", nn.BatchNorm1d(c))
+
+    def forward(self, x):
+        b = x.size(0)
+        x, trans = self.feat(x)
+        for i in (1, 2, 3):
+            x = F.relu(getattr(self, f"bn{i}")(getattr(self, f"conv{i}")(x)))
+        x = self.conv4(x).transpose(2, 1).contiguous()
+        x = F.log_softmax(x.view(-1, self.k), dim=-1)
+        return x.view(b, self.num_points, self.k), trans

@@ -1,0 +1,49 @@
+"""Shared test helpers (weights recipe of the golden fixtures, comparisons)."""
+import glob
+import os
+
+import numpy as np
+import torch
+
+from oracle.pointnet_oracle import randomize_bn_
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_files(prefix):
+    return sorted(glob.glob(os.path.join(GOLDEN, prefix + "*.npz")))
+
+
+def build_model(num_points, k, seed_w, seed_bn, cls=None):
+    """The recipe recorded by oracle/make_golden.py, applied to OUR mirror module."""
+    if cls is None:
+        from pointnetgpd_amd.model.pointnet import PointNetCls as cls
+    torch.manual_seed(int(seed_w))
+    m = cls(num_points=int(num_points), input_chann=3, k=int(k))
+    if int(seed_bn) >= 0:
+        randomize_bn_(m.state_dict(), int(seed_bn))
+    return m
+
+
+def assert_checksums(model, fx):
+    """The rebuilt weights must be bit-identical to the reference's (sum / abs-sum in fp64)."""
+    sd = model.state_dict()
+    names = [str(n) for n in fx["names"]]
+    assert sorted(k for k in sd if not k.endswith("num_batches_tracked")) == names
+    cs = np.array([[sd[k].double().sum().item(), sd[k].double().abs().sum().item()] for k in names])
+    np.testing.assert_array_equal(cs, fx["checksums"])
+
+
+def synth_cloud(b, n, seed, kind="box"):
+    g = torch.Generator().manual_seed(seed)
+    if kind == "box":
+        w = 0.085
+        u = torch.rand(b, 3, n, generator=g) - 0.5
+        return (u * torch.tensor([w / 2, w, w / 2]).view(1, 3, 1)).float().contiguous()
+    if kind == "gauss":
+        return (torch.randn(b, 3, n, generator=g) * 0.02).float().contiguous()
+    return torch.randn(b, 3, n, generator=g).float().contiguous()
+
+
+def state_dict_cpu(model):
+    return {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}

@@ -1,0 +1,64 @@
+"""CPU: libpngpd.so loads, exports every symbol include/pngpd.h declares, and the ctypes
+binding table mirrors the header.  No compute calls (no GPU here)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "pngpd.h")
+
+
+def header_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pngpd_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_functions():
+    fns = header_functions()
+    assert "pngpd_trunk_fwd_infer" in fns and "pngpd_fc_fwd" in fns and len(fns) >= 6
+
+
+def test_library_exports_header_symbols():
+    from pointnetgpd_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "build libpngpd.so first (__graft_entry__.build())"
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\bT (pngpd_[a-z0-9_]+)", out))
+    missing = [f for f in header_functions() if f not in exported]
+    assert not missing, f"header declares but library lacks: {missing}"
+
+
+def test_ctypes_table_matches_header():
+    from pointnetgpd_amd import _lib
+    assert sorted(_lib.SIGNATURES) == header_functions()
+
+
+def test_library_loads_and_reports_abi():
+    from pointnetgpd_amd import _lib
+    lib = _lib.load()
+    assert lib.pngpd_abi_version() == _lib.ABI_VERSION
+    assert lib.pngpd_strerror(0) == b"ok"
+    assert lib.pngpd_strerror(1) == b"invalid argument"
+    # argument validation happens before any launch, so it is testable without a GPU
+    assert lib.pngpd_trunk_fwd_infer(None, 1, 1, None, None, None, None, None, None, None, 0, None, None, 0, None) == 1
+    assert lib.pngpd_fc_fwd(None, 1, 8, None, None, 1, 0, None, None) == 1
+    assert lib.pngpd_trunk_workspace_bytes(4, 100) == 4 * 2 * 1024 * 4
+
+
+def test_cuda_ops_refuse_cpu_tensors():
+    """The product path has no CPU fallback behind the HIP ops."""
+    import torch
+    from pointnetgpd_amd import ops
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        ops.fc_fwd(torch.zeros(2, 8), torch.zeros(3, 8), torch.zeros(3), ops.EPI_NONE)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from pointnetgpd_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_load_error", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libpngpd.so")
+    with pytest.raises(RuntimeError, match="libpngpd.so not found"):
+        _lib.load()
