@@ -63,7 +63,9 @@ def cpu_baseline(num_points, k, budget_s=20.0):
     """The oracle's torch-functional restatement (the reference's own ATen op sequence) timed on
     this box's host cores, on a bounded sample of the same workload."""
     from oracle import pointnet_oracle as po
-    cores = os.cpu_count() or 1
+    # measured on the GPU box (2x EPYC 9575F, 256 hw threads): 8/16/32/64/128 threads give
+    # 119/135/127/104/63 grasps/s -> 16 threads is the best this op sequence reaches.
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     m = build_model(num_points, k, torch.device("cpu"))
     sd = {kk: v.detach().clone() for kk, v in m.state_dict().items()}
@@ -147,6 +149,14 @@ def main():
     trunk_flops = B * N * FLOP_PER_POINT_TRUNK
     achieved = trunk_flops / (trunk_ms * 1e-3) / 1e12
 
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_trunk.json")) as f:
+            pmc = json.load(f)
+        if B == 1024 and N == 1024:
+            traffic = pmc["traffic_bytes_per_launch"]
+    except Exception:
+        pass
     if rank == 0:
         value = world * B * args.steps / dt
         alg_bytes = B * (4 * 3 * N + 4 * (k + 9))
@@ -164,7 +174,8 @@ def main():
             "hbm_algorithmic_gbs": round(value / world * alg_bytes / B / 1e9, 3),
             "roofline": {"bound": "mfma", "kernel": "trunk_infer_kernel", "achieved": round(achieved, 2),
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "HBM bytes/launch (rocprofv3 PMC, profiles/r01_pmc_trunk.json)",
                          "avg_launch_ms": round(trunk_ms, 4),
                          "flops_per_launch": trunk_flops},
         }

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 rocpd (.db) outputs into a small text file for profiles/.
+
+usage: tools/rocprof_summary.py OUT.md LABEL=path/to/results.db [LABEL=...]
+Kernel-trace dbs yield the --stats style table (calls, total, average); PMC dbs yield the
+per-kernel average of every collected counter.  Only kernels of this repo (pngpd) are listed
+in full; everything else is folded into one 'other' line.
+"""
+import sqlite3
+import sys
+
+OURS = ("trunk_", "fc_", "pool_reduce", "fold_conv_bn", "crop_", "resample", "bn_", "pngpd")
+
+
+def short(name):
+    return name.split("(")[0]
+
+
+def main():
+    out, items = sys.argv[1], sys.argv[2:]
+    lines = []
+    for it in items:
+        label, path = it.split("=", 1)
+        cur = sqlite3.connect(path).cursor()
+        lines.append(f"## {label}  ({path.split('gpurun_out/')[-1]})\n")
+        rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
+        if rows:
+            lines.append("| kernel | calls | total_us | avg_us | % |\n|---|---|---|---|---|")
+            other = [0, 0.0, 0.0]
+            for n, c, t, a, p in rows:
+                if short(n).startswith(OURS):
+                    lines.append(f"| {short(n)} | {c} | {t:.1f} | {a:.3f} | {p:.2f} |")
+                else:
+                    other[0] += c; other[1] += t; other[2] += p
+            lines.append(f"| (other: torch/rocclr) | {other[0]} | {other[1]:.1f} | - | {other[2]:.2f} |\n")
+        try:
+            q = ("select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection "
+                 "group by kernel_name, counter_name")
+            rows = list(cur.execute(q))
+        except sqlite3.Error:
+            rows = []
+        rows = [r for r in rows if short(r[0]).startswith(OURS)]
+        if rows:
+            lines.append("| kernel | counter | dispatches | avg value per dispatch | avg dispatch ns |\n|---|---|---|---|---|")
+            for n, c, k, v, d in rows:
+                lines.append(f"| {short(n)} | {c} | {k} | {v:.6g} | {d:.0f} |")
+            lines.append("")
+    open(out, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
