@@ -62,6 +62,8 @@ int pngpd_set_option(const char *name, int value);
  * pairs of pointnet.py:29-31,35-36,144-147,191-192:
  *     s = gamma / sqrt(var + eps);  Wf = W * s[:,None];  bf = (b - mean) * s + beta
  * gamma == NULL means "no BatchNorm" (fc3 layers): Wf = W, bf = b.
+ * var == NULL (gamma != NULL) means "scale only": s = gamma, bf = b (used to sign-fold W3 and to
+ * re-layout raw weights for the training passes).  b == NULL is read as zeros.
  * layout PNGPD_LAYOUT_MFMA_B requires C % 32 == 0 and K % 8 == 0.
  */
 int pngpd_fold_conv_bn(const float *W, const float *b, const float *gamma, const float *beta,
@@ -95,6 +97,78 @@ int pngpd_trunk_fwd_infer(const float *x, int B, int N, const float *trans,
  */
 int pngpd_fc_fwd(const float *in, int B, int K, const float *W, const float *bias, int Nout,
                  int epilogue, float *out, void *stream);
+
+/* =======================================================================================
+ * Training path (batch-statistics BatchNorm, backward).  The trunk's forward/backward is a
+ * sequence of recompute passes (DESIGN.md "Training passes"); the host composes them
+ * (pointnetgpd_amd/train.py).  Together they replace the autograd graph that
+ * PointNetGPD/main_1v.py:72-76 builds over pointnet.py:29-33 / :140-149.
+ * Common arguments: x (B,3,N); trans (B,3,3) or NULL; layer-1/2 per-channel forms
+ *   h1 = relu((W1 x' + b1)*s1c + t1c),  h2 = relu((W2 h1)*s2c + t2c)
+ * w1 (64,3) raw rowmajor, b1/s1c/t1c (64); w2p (128,64) raw MFMA_B packed, s2c/t2c (128).
+ * "blk" below = B * pngpd_trunk_train_splits(B,N) workgroups; partial buffers are reduced
+ * by the caller (deterministic, no atomics).
+ * ======================================================================================= */
+int pngpd_train_set_target_blocks(int blocks);
+int pngpd_trunk_train_splits(int B, int N);
+
+/* pass A: per-cloud fp64 moments  mom (B,9) = {sx,sy,sz,sxx,sxy,sxz,syy,syz,szz}  (BN1 stats in closed form) */
+int pngpd_cloud_moments(const float *x, int B, int N, double *mom, void *stream);
+
+/* pass B: BN2 statistics.  part (blk,128,2) = per-workgroup sum / sum-of-squares of z2 = W2 h1 */
+int pngpd_trunk_bn2_stats(const float *x, int B, int N, const float *trans,
+                          const float *w1, const float *b1, const float *s1c, const float *t1c,
+                          const float *w2p, float *part, void *stream);
+
+/* pass C: layer 3 with sign-folded weights w3sp = MFMA_B(sign(gamma3) * W3):
+ *   pmax/parg (blk,1024): max / argmax over the workgroup's points of z3s = w3s . h2
+ *   psum (blk,2,1024):    sum / sum of squares of z3s over valid points                     */
+int pngpd_trunk_fwd_train(const float *x, int B, int N, const float *trans,
+                          const float *w1, const float *b1, const float *s1c, const float *t1c,
+                          const float *w2p, const float *s2c, const float *t2c, const float *w3sp,
+                          float *pmax, int *parg, float *psum, void *stream);
+
+/* second moments of the hidden activations (needed by the closed-form dW3 / dW2):
+ *   ps2 (B,128,128) = sum_n h2 h2^T, ps1 (B,64,64) = sum_n h1 h1^T, psh (B,192) = [sum h2 | sum h1] */
+int pngpd_trunk_h_moments(const float *x, int B, int N, const float *trans,
+                          const float *w1, const float *b1, const float *s1c, const float *t1c,
+                          const float *w2p, const float *s2c, const float *t2c,
+                          float *ps2, float *ps1, float *psh, void *stream);
+
+/* sparse (arg-extremum) term of dW3:  Gp (ceil(B/clouds_per_range),1024,128),
+ *   Gp[r][c][:] = sum_{b in range r} coef[b][c] * h2[b][:, idx[b][c]]                         */
+int pngpd_trunk_bwd_gather(const float *x, int B, int N, const float *trans,
+                           const float *w1, const float *b1, const float *s1c, const float *t1c,
+                           const float *w2p, const float *s2c, const float *t2c,
+                           const int *idx, const float *coef, int clouds_per_range, float *Gp, void *stream);
+
+/* backward pass D: g2buf (B,N,128) = dL/d(bn2 out);  pa (blk,128,2) = sum g2, sum g2*zhat2;
+ *   pP (blk,128,64) = sum_points g2 h1^T.   zhat2 = z2*is2 + nm2;  Ap = MFMA_B(A), A (128,128)
+ *   symmetric; dh2 = cvec - h2 A + sum_{c: idx[b][c]==n} coef[b][c] W3[c]; w3 (1024,128) raw.  */
+int pngpd_trunk_bwd_d(const float *x, int B, int N, const float *trans,
+                      const float *w1, const float *b1, const float *s1c, const float *t1c,
+                      const float *w2p, const float *s2c, const float *t2c,
+                      const float *is2, const float *nm2, const float *Ap, const float *cvec,
+                      const float *w3, const int *idx, const float *coef,
+                      float *g2buf, float *pa, float *pP, void *stream);
+
+/* backward pass E: dz2 = dsc2*(g2 - a1m - zhat2*a2m); dh1 = W2^T dz2 (w2tp = MFMA_B(W2^T as (64,128)));
+ *   g1 = dh1*(h1>0); pc (blk,64,2) = sum g1, sum g1*zhat1; pR (blk,64,3) = sum_points g1 x^T (original x) */
+int pngpd_trunk_bwd_e(const float *x, int B, int N, const float *trans,
+                      const float *w1, const float *b1, const float *s1c, const float *t1c,
+                      const float *w2p, const float *is1, const float *nm1, const float *is2, const float *nm2,
+                      const float *a1m, const float *a2m, const float *dsc2, const float *w2tp,
+                      const float *g2buf, float *pc, float *pR, void *stream);
+
+/* BatchNorm1d over the batch dimension for the FC stacks (pointnet.py:35-36,191-192, train mode),
+ * optional fused ReLU; biased variance returned (the caller updates running stats). */
+int pngpd_bn1d_fwd_train(const float *z, int B, int C, const float *gamma, const float *beta, float eps,
+                         int relu, float *y, float *mean, float *var, void *stream);
+int pngpd_bn1d_bwd(const float *dy, const float *z, const float *y, int B, int C, const float *gamma,
+                   const float *mean, const float *var, float eps, int relu,
+                   float *dz, float *dgamma, float *dbeta, void *stream);
+/* backward of F.log_softmax (pointnet.py:194): dlogits = g - exp(logp) * rowsum(g) */
+int pngpd_log_softmax_bwd(const float *g, const float *logp, int B, int K, float *dlogits, void *stream);
 
 #ifdef __cplusplus
 }

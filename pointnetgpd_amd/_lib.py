@@ -29,6 +29,22 @@ SIGNATURES = {
                               [ctypes.c_int, c_f32p, c_void, ctypes.c_size_t, c_void]),
     "pngpd_fc_fwd": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, ctypes.c_int,
                                     ctypes.c_int, c_f32p, c_void]),
+    # ---- training passes
+    "pngpd_train_set_target_blocks": (ctypes.c_int, [ctypes.c_int]),
+    "pngpd_trunk_train_splits": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    "pngpd_cloud_moments": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, c_f32p, c_void]),
+    "pngpd_trunk_bn2_stats": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 7 + [c_void]),
+    "pngpd_trunk_fwd_train": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 12 + [c_void]),
+    "pngpd_trunk_h_moments": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 11 + [c_void]),
+    "pngpd_trunk_bwd_gather": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 10 +
+                               [ctypes.c_int, c_f32p, c_void]),
+    "pngpd_trunk_bwd_d": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 18 + [c_void]),
+    "pngpd_trunk_bwd_e": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 17 + [c_void]),
+    "pngpd_bn1d_fwd_train": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, ctypes.c_float,
+                                            ctypes.c_int, c_f32p, c_f32p, c_f32p, c_void]),
+    "pngpd_bn1d_bwd": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, c_f32p,
+                                      ctypes.c_float, ctypes.c_int, c_f32p, c_f32p, c_f32p, c_void]),
+    "pngpd_log_softmax_bwd": (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, c_f32p, c_void]),
 }
 
 

@@ -26,7 +26,7 @@ __global__ void fold_conv_bn_kernel(const float *__restrict__ W, const float *__
     if (idx >= C * K) return;
     int c = idx / K, k = idx - c * K;
     double s = 1.0;
-    if (gamma) s = (double)gamma[c] / sqrt((double)var[c] + (double)eps);
+    if (gamma) s = var ? (double)gamma[c] / sqrt((double)var[c] + (double)eps) : (double)gamma[c];
     float wv = (float)((double)W[idx] * s);
     int o = idx;
     if (layout == PNGPD_LAYOUT_MFMA_B) {
@@ -36,7 +36,7 @@ __global__ void fold_conv_bn_kernel(const float *__restrict__ W, const float *__
     Wf[o] = wv;
     if (k == 0) {
         double bb = b ? (double)b[c] : 0.0;
-        if (gamma) bb = (bb - (double)mean[c]) * s + (double)beta[c];
+        if (gamma && var) bb = (bb - (double)mean[c]) * s + (double)beta[c];
         bf[c] = (float)bb;
     }
 }
@@ -286,7 +286,7 @@ int pngpd_fold_conv_bn(const float *W, const float *b, const float *gamma, const
                        const float *mean, const float *var, float eps, int C, int K, int layout,
                        float *Wf, float *bf, void *stream) {
     if (!W || !Wf || !bf || C <= 0 || K <= 0) return PNGPD_ERR_INVALID_ARG;
-    if (gamma && (!beta || !mean || !var)) return PNGPD_ERR_INVALID_ARG;
+    if (gamma && var && (!beta || !mean)) return PNGPD_ERR_INVALID_ARG;
     if (layout == PNGPD_LAYOUT_MFMA_B) {
         if ((C & 31) || (K & 7)) return PNGPD_ERR_INVALID_ARG;
     } else if (layout != PNGPD_LAYOUT_ROWMAJOR) {

@@ -1,0 +1,119 @@
+// Tile-level building blocks shared by the inference and training trunk kernels.
+// A workgroup = 256 threads = 4 waves; a tile = 64 points of one cloud.
+//   xs  [3][64]   staged (optionally T^T-transformed) coordinates
+//   h1  [64][68]  layer-1 activations  (row = point, 64 channels + 4 pad floats)
+//   h2  [64][132] layer-2 activations  (row = point, 128 channels + 4 pad floats)
+// The +4-float row pad makes the per-lane float4 A-fragment reads (ds_read_b128: lane i reads
+// row i at a common column offset) conflict-free: row stride 68 / 132 dwords == 4 (mod 64).
+#pragma once
+#include "pngpd_common.h"
+
+#define TP 64
+#define H1S 68
+#define H2S 132
+
+struct Lane {
+    int tid, lane, wave, j, h;
+    __device__ __forceinline__ Lane() {
+        tid = threadIdx.x;
+        lane = tid & 63;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        j = lane & 31;
+        h = lane >> 5;
+    }
+};
+
+// Load the tile's 64 points (tail: replicate point N-1), optionally apply x' = x^T @ T
+// (reference pointnet.py:140-143), write xs (and the untransformed copy xo if non-null).
+__device__ __forceinline__ void stage_points(const float *__restrict__ xb, int N, int tile, bool has_t,
+                                             const float (&tm)[9], float *xs, float *xo, int tid) {
+    if (tid < TP) {
+        int n = tile * TP + tid;
+        n = n < N ? n : N - 1;
+        float x0 = xb[n], x1 = xb[N + n], x2 = xb[2 * N + n];
+        if (xo) { xo[tid] = x0; xo[TP + tid] = x1; xo[2 * TP + tid] = x2; }
+        if (has_t) {
+            float y0 = fmaf(x2, tm[6], fmaf(x1, tm[3], x0 * tm[0]));
+            float y1 = fmaf(x2, tm[7], fmaf(x1, tm[4], x0 * tm[1]));
+            float y2 = fmaf(x2, tm[8], fmaf(x1, tm[5], x0 * tm[2]));
+            x0 = y0; x1 = y1; x2 = y2;
+        }
+        xs[tid] = x0; xs[TP + tid] = x1; xs[2 * TP + tid] = x2;
+    }
+}
+
+// Layer 1 (3 -> 64) on the VALU.  thread = (point p = lane, 16-channel group = wave).
+//   z = w1[c]·x + b1[c];  h1 = relu(z * sc[c] + sh[c])      (sc == nullptr: h1 = relu(z))
+// w1/b1 (and sc/sh) are indexed with wave-uniform c -> scalar loads.
+__device__ __forceinline__ void layer1_tile(const float *xs, const float *__restrict__ w1,
+                                            const float *__restrict__ b1, const float *__restrict__ sc,
+                                            const float *__restrict__ sh, float *h1, const Lane &L) {
+    const int p = L.lane;
+    const float x0 = xs[p], x1 = xs[TP + p], x2 = xs[2 * TP + p];
+    float *dst = h1 + p * H1S + L.wave * 16;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = L.wave * 16 + g * 4 + e;
+            float z = fmaf(w1[c * 3 + 2], x2, fmaf(w1[c * 3 + 1], x1, fmaf(w1[c * 3], x0, b1[c])));
+            if (sc) z = fmaf(z, sc[c], sh[c]);
+            v[e] = fmaxf(z, 0.f);
+        }
+        *(f32x4 *)(dst + g * 4) = v;
+    }
+}
+
+// Layer 2 (64 -> 128) raw product for channel block cb (32 channels), both 32-point blocks:
+//   acc{0,1}[r] = sum_k h1[point][k] * W2[cb*32 + j][k],  point = pb*32 + mfma_row(r, lane)
+// w2p is the MFMA_B-packed (128,64) weight.
+__device__ __forceinline__ void layer2_mfma(const float *h1, const float *__restrict__ w2p, int cb,
+                                            const Lane &L, f32x16 &acc0, f32x16 &acc1) {
+    const f32x4 *wp = (const f32x4 *)w2p + (size_t)(cb * 8) * 64 + L.lane;
+    const float *a0p = h1 + L.j * H1S + L.h * 4;
+    const float *a1p = h1 + (32 + L.j) * H1S + L.h * 4;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+        f32x4 wv = wp[kb * 64];
+        f32x4 a0 = *(const f32x4 *)(a0p + kb * 8);
+        f32x4 a1 = *(const f32x4 *)(a1p + kb * 8);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            acc0 = mfma32(a0[t], wv[t], acc0);
+            acc1 = mfma32(a1[t], wv[t], acc1);
+        }
+    }
+}
+
+// K = 128 product against an MFMA_B-packed (C,128) matrix, channel block cb, A rows from an
+// h2-shaped LDS tile ([64][H2S]):  acc{0,1}[r] = sum_k tile[point][k] * Wp[cb*32 + j][k].
+__device__ __forceinline__ void k128_mfma(const float *tile, const float *__restrict__ wp128, int cb,
+                                          const Lane &L, f32x16 &acc0, f32x16 &acc1) {
+    const f32x4 *wp = (const f32x4 *)wp128 + (size_t)(cb * 16) * 64 + L.lane;
+    f32x4 wf[16];
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) wf[kb] = wp[kb * 64];
+    const float *a0p = tile + L.j * H2S + L.h * 4;
+    const float *a1p = tile + (32 + L.j) * H2S + L.h * 4;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) {
+        f32x4 a0 = *(const f32x4 *)(a0p + kb * 8);
+        f32x4 a1 = *(const f32x4 *)(a1p + kb * 8);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            acc0 = mfma32(a0[t], wf[kb][t], acc0);
+            acc1 = mfma32(a1[t], wf[kb][t], acc1);
+        }
+    }
+}
+
+// Split of a cloud's T tiles over S workgroups.
+__device__ __forceinline__ void tile_range(int s, int S, int T, int &t0, int &t1) {
+    t0 = (int)(((long)s * T) / S);
+    t1 = (int)(((long)(s + 1) * T) / S);
+}

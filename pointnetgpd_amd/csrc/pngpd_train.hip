@@ -1,0 +1,849 @@
+// libpngpd — training path of the per-point MLP trunk (batch-statistics BatchNorm + max-pool)
+// as a sequence of recompute passes; no (B,C,N) activation is ever stored except the
+// (B,N,128) layer-2 gradient handed from backward pass D to pass E.
+//
+// Replaces, in train mode, the autograd graph of
+//   PointNetGPD/model/pointnet.py:29-33 (STN3d trunk) and :140-149 (PointNetfeat trunk)
+// driven by PointNetGPD/main_1v.py:72-76 (forward, nll_loss, backward).
+// The algebra (closed-form backward through conv1x1 -> BN(batch) -> [ReLU] -> max) is
+// documented in DESIGN.md §"Training passes" and verified against autograd in fp64 by
+// tests/train_algo_prototype.py.
+//
+// Per-channel affine forms used by every pass (so recomputed activations are bit-identical
+// across passes):   h1 = relu(z1*s1c + t1c),  zhat1 = z1*is1 + nm1,   z1 = W1 x' + b1
+//                   h2 = relu(z2*s2c + t2c),  zhat2 = z2*is2 + nm2,   z2 = W2 h1   (no bias)
+#include "pngpd_tile.h"
+
+struct TrainChan {
+    const float *w1, *b1, *s1c, *t1c;   // layer 1: (64,3) raw, bias, scale, shift
+    const float *w2p, *s2c, *t2c;       // layer 2: raw MFMA_B packed (128,64), scale, shift
+};
+
+static int g_train_target_blocks = 2048;
+
+static int train_splits(int B, int T) {
+    int S = (g_train_target_blocks + B - 1) / B;
+    if (S < 1) S = 1;
+    if (S > T) S = T;
+    return S;
+}
+
+// ---------------------------------------------------------------------------------------
+// pass A: per-cloud input moments in fp64:  mom[b] = {sx,sy,sz, sxx,sxy,sxz, syy,syz,szz}
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cloud_moments_kernel(const float *__restrict__ x, int N,
+                                                            double *__restrict__ mom) {
+    __shared__ double red[4][9];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float *xb = x + (size_t)b * 3 * N;
+    double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int n = tid; n < N; n += 256) {
+        double x0 = xb[n], x1 = xb[N + n], x2 = xb[2 * N + n];
+        a[0] += x0; a[1] += x1; a[2] += x2;
+        a[3] += x0 * x0; a[4] += x0 * x1; a[5] += x0 * x2;
+        a[6] += x1 * x1; a[7] += x1 * x2; a[8] += x2 * x2;
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) a[i] += __shfl_xor(a[i], m);
+    }
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) red[tid >> 6][i] = a[i];
+    }
+    __syncthreads();
+    if (tid < 9) mom[(size_t)b * 9 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+// ---------------------------------------------------------------------------------------
+// pass B: BN2 statistics.  part[blk][c][0..1] = sum, sum of squares of z2 = W2 h1 over the
+// workgroup's valid points.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void trunk_bn2_stats_kernel(
+    const float *__restrict__ x, int N, const float *__restrict__ trans, TrainChan P,
+    int T, int S, float *__restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *h1 = smem;             // [TP][H1S]
+    float *xs = h1 + TP * H1S;    // [3][TP]
+    const Lane L;
+    const int b = blockIdx.x / S, s = blockIdx.x - b * S;
+    int t0, t1; tile_range(s, S, T, t0, t1);
+    const float *xb = x + (size_t)b * 3 * N;
+    float tm[9] = {0};
+    const bool has_t = trans != nullptr;
+    if (has_t) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) tm[i] = trans[(size_t)b * 9 + i];
+    }
+    float sum = 0.f, sq = 0.f;
+    for (int tile = t0; tile < t1; ++tile) {
+        stage_points(xb, N, tile, has_t, tm, xs, nullptr, L.tid);
+        __syncthreads();
+        layer1_tile(xs, P.w1, P.b1, P.s1c, P.t1c, h1, L);
+        __syncthreads();
+        f32x16 a0, a1;
+        layer2_mfma(h1, P.w2p, L.wave, L, a0, a1);
+        const int nbase = tile * TP;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = mfma_row(r, L.lane);
+            const float v0 = (nbase + row < N) ? a0[r] : 0.f;
+            const float v1 = (nbase + 32 + row < N) ? a1[r] : 0.f;
+            sum += v0 + v1;
+            sq = fmaf(v0, v0, fmaf(v1, v1, sq));
+        }
+        __syncthreads();   // h1/xs are rewritten by the next tile
+    }
+    sum += __shfl_xor(sum, 32);
+    sq += __shfl_xor(sq, 32);
+    if (L.h == 0) {
+        float *o = part + ((size_t)blockIdx.x * 128 + L.wave * 32 + L.j) * 2;
+        o[0] = sum; o[1] = sq;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// pass C (main forward): z3s = (sgn*W3) h2 per point; per (cloud, channel) running max and
+// argmax over the workgroup's tiles; per channel sum / sum of squares over valid points.
+//   pmax/parg : [blk][1024]      psum : [blk][2][1024]
+// ---------------------------------------------------------------------------------------
+#define TRAIN_MAIN_LDS_FLOATS (TP * H1S + TP * H2S + 3 * TP + 4 * 1024)
+
+__global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
+    const float *__restrict__ x, int N, const float *__restrict__ trans, TrainChan P,
+    const float *__restrict__ w3sp, int T, int S,
+    float *__restrict__ pmax, int *__restrict__ parg, float *__restrict__ psum) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *h1 = smem;
+    float *h2 = h1 + TP * H1S;
+    float *xs = h2 + TP * H2S;
+    float *rm = xs + 3 * TP;          // [1024] running max
+    int *ri = (int *)(rm + 1024);     // [1024] running argmax (point index)
+    float *ss = (float *)(ri + 1024); // [1024] sum
+    float *sq = ss + 1024;            // [1024] sum of squares
+    const Lane L;
+    const int b = blockIdx.x / S, s = blockIdx.x - b * S;
+    int t0, t1; tile_range(s, S, T, t0, t1);
+    const float *xb = x + (size_t)b * 3 * N;
+    for (int i = L.tid; i < 1024; i += 256) { rm[i] = -INFINITY; ri[i] = 0; ss[i] = 0.f; sq[i] = 0.f; }
+    float tm[9] = {0};
+    const bool has_t = trans != nullptr;
+    if (has_t) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) tm[i] = trans[(size_t)b * 9 + i];
+    }
+    for (int tile = t0; tile < t1; ++tile) {
+        stage_points(xb, N, tile, has_t, tm, xs, nullptr, L.tid);
+        __syncthreads();
+        layer1_tile(xs, P.w1, P.b1, P.s1c, P.t1c, h1, L);
+        __syncthreads();
+        {
+            f32x16 a0, a1;
+            const int cb = L.wave;
+            layer2_mfma(h1, P.w2p, cb, L, a0, a1);
+            const float sc = P.s2c[cb * 32 + L.j], sh = P.t2c[cb * 32 + L.j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mfma_row(r, L.lane);
+                h2[row * H2S + cb * 32 + L.j] = fmaxf(fmaf(a0[r], sc, sh), 0.f);
+                h2[(32 + row) * H2S + cb * 32 + L.j] = fmaxf(fmaf(a1[r], sc, sh), 0.f);
+            }
+        }
+        __syncthreads();
+        const int nbase = tile * TP;
+        const bool full = nbase + TP <= N;
+#pragma unroll 1
+        for (int ci = 0; ci < 8; ++ci) {
+            const int cb = L.wave + 4 * ci;
+            f32x16 a0, a1;
+            k128_mfma(h2, w3sp, cb, L, a0, a1);
+            // max / argmax over this lane's 32 rows (ascending row order, strict >: first wins)
+            float m = a0[0]; int am = mfma_row(0, L.lane);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) { if (a0[r] > m) { m = a0[r]; am = mfma_row(r, L.lane); } }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { if (a1[r] > m) { m = a1[r]; am = 32 + mfma_row(r, L.lane); } }
+            float su = 0.f, qu = 0.f;
+            if (full) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { su += a0[r] + a1[r]; qu = fmaf(a0[r], a0[r], fmaf(a1[r], a1[r], qu)); }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = mfma_row(r, L.lane);
+                    const float v0 = (nbase + row < N) ? a0[r] : 0.f;
+                    const float v1 = (nbase + 32 + row < N) ? a1[r] : 0.f;
+                    su += v0 + v1; qu = fmaf(v0, v0, fmaf(v1, v1, qu));
+                }
+            }
+            const float om = __shfl_xor(m, 32); const int oa = __shfl_xor(am, 32);
+            if (om > m || (om == m && oa < am)) { m = om; am = oa; }
+            su += __shfl_xor(su, 32); qu += __shfl_xor(qu, 32);
+            if (L.h == 0) {
+                const int c = cb * 32 + L.j;
+                if (m > rm[c]) { rm[c] = m; int n = nbase + am; ri[c] = n < N ? n : N - 1; }
+                ss[c] += su; sq[c] += qu;
+            }
+        }
+    }
+    if (L.h == 0) {
+#pragma unroll
+        for (int ci = 0; ci < 8; ++ci) {
+            const int c = (L.wave + 4 * ci) * 32 + L.j;
+            pmax[(size_t)blockIdx.x * 1024 + c] = rm[c];
+            parg[(size_t)blockIdx.x * 1024 + c] = ri[c];
+            psum[((size_t)blockIdx.x * 2) * 1024 + c] = ss[c];
+            psum[((size_t)blockIdx.x * 2 + 1) * 1024 + c] = sq[c];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// h-moments pass: S2 = sum h2 h2^T (128x128), S1 = sum h1 h1^T (64x64), column sums.
+// One workgroup per cloud (all its tiles).  Contraction over points on the MFMA:
+//   D[i][j] += A[i][k=point] * B[k=point][j]  with A = B = the LDS tile read column-wise.
+//   ps2 [blk][128][128]  ps1 [blk][64][64]  psh [blk][128+64]
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void trunk_h_moments_kernel(
+    const float *__restrict__ x, int N, const float *__restrict__ trans, TrainChan P, int T,
+    float *__restrict__ ps2, float *__restrict__ ps1, float *__restrict__ psh) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *h1 = smem;
+    float *h2 = h1 + TP * H1S;
+    float *xs = h2 + TP * H2S;
+    const Lane L;
+    const int b = blockIdx.x;
+    const float *xb = x + (size_t)b * 3 * N;
+    float tm[9] = {0};
+    const bool has_t = trans != nullptr;
+    if (has_t) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) tm[i] = trans[(size_t)b * 9 + i];
+    }
+    f32x16 s2a[4];
+    f32x16 s1a;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s2a[q][r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s1a[r] = 0.f;
+    float colsum = 0.f;
+    for (int tile = 0; tile < T; ++tile) {
+        stage_points(xb, N, tile, has_t, tm, xs, nullptr, L.tid);
+        __syncthreads();
+        layer1_tile(xs, P.w1, P.b1, P.s1c, P.t1c, h1, L);
+        __syncthreads();
+        const int nbase = tile * TP;
+        {
+            f32x16 a0, a1;
+            const int cb = L.wave;
+            layer2_mfma(h1, P.w2p, cb, L, a0, a1);
+            const float sc = P.s2c[cb * 32 + L.j], sh = P.t2c[cb * 32 + L.j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mfma_row(r, L.lane);
+                h2[row * H2S + cb * 32 + L.j] = (nbase + row < N) ? fmaxf(fmaf(a0[r], sc, sh), 0.f) : 0.f;
+                h2[(32 + row) * H2S + cb * 32 + L.j] = (nbase + 32 + row < N) ? fmaxf(fmaf(a1[r], sc, sh), 0.f) : 0.f;
+            }
+        }
+        __syncthreads();
+        if (nbase + TP > N) {   // tail tile: zero the replicated rows of h1 (block-uniform branch)
+            for (int i = L.tid; i < TP * 64; i += 256) {
+                const int row = i >> 6, c = i & 63;
+                if (nbase + row >= N) h1[row * H1S + c] = 0.f;
+            }
+            __syncthreads();
+        }
+        // S2: wave owns row block ib = wave, all four column blocks
+        {
+            const int ib = L.wave;
+#pragma unroll 4
+            for (int st = 0; st < 32; ++st) {
+                const float *rowp = h2 + (2 * st + L.h) * H2S + L.j;
+                const float av = rowp[ib * 32];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s2a[q] = mfma32(av, rowp[q * 32], s2a[q]);
+            }
+            const int i1 = L.wave >> 1, j1 = L.wave & 1;
+#pragma unroll 4
+            for (int st = 0; st < 32; ++st) {
+                const float *rowp = h1 + (2 * st + L.h) * H1S + L.j;
+                s1a = mfma32(rowp[i1 * 32], rowp[j1 * 32], s1a);
+            }
+        }
+        // column sums: threads 0..127 -> h2 column, 128..191 -> h1 column
+        if (L.tid < 128) {
+            for (int r = 0; r < TP; ++r) colsum += h2[r * H2S + L.tid];
+        } else if (L.tid < 192) {
+            for (int r = 0; r < TP; ++r) colsum += h1[r * H1S + (L.tid - 128)];
+        }
+        __syncthreads();
+    }
+    {
+        float *o2 = ps2 + (size_t)b * 128 * 128;
+        const int ib = L.wave;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                o2[(ib * 32 + mfma_row(r, L.lane)) * 128 + q * 32 + L.j] = s2a[q][r];
+        float *o1 = ps1 + (size_t)b * 64 * 64;
+        const int i1 = L.wave >> 1, j1 = L.wave & 1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o1[(i1 * 32 + mfma_row(r, L.lane)) * 64 + j1 * 32 + L.j] = s1a[r];
+        if (L.tid < 192) psh[(size_t)b * 192 + L.tid] = colsum;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// gather pass: Gp[rng][c][k] = sum_{b in range} coef[b][c] * h2[b][k] evaluated at point idx[b][c]
+// workgroup = (64-channel chunk cc, cloud range rng).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void trunk_bwd_gather_kernel(
+    const float *__restrict__ x, int B, int N, const float *__restrict__ trans, TrainChan P,
+    const int *__restrict__ idx, const float *__restrict__ coef, int clouds_per_range,
+    float *__restrict__ Gp) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *h1 = smem;
+    float *h2 = h1 + TP * H1S;
+    float *xs = h2 + TP * H2S;
+    float *cf = xs + 3 * TP;   // [64]
+    const Lane L;
+    const int cc = blockIdx.x & 15, rng = blockIdx.x >> 4;
+    const int b0 = rng * clouds_per_range;
+    const int b1 = (b0 + clouds_per_range < B) ? b0 + clouds_per_range : B;
+    const bool has_t = trans != nullptr;
+    float g[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) g[i] = 0.f;
+    const int k = L.tid & 127, rh = L.tid >> 7;
+    for (int b = b0; b < b1; ++b) {
+        if (L.tid < TP) {
+            const int c = cc * 64 + L.tid;
+            const int n = idx[(size_t)b * 1024 + c];
+            const float *xb = x + (size_t)b * 3 * N;
+            float x0 = xb[n], x1 = xb[N + n], x2 = xb[2 * N + n];
+            if (has_t) {
+                const float *tm = trans + (size_t)b * 9;
+                float y0 = fmaf(x2, tm[6], fmaf(x1, tm[3], x0 * tm[0]));
+                float y1 = fmaf(x2, tm[7], fmaf(x1, tm[4], x0 * tm[1]));
+                float y2 = fmaf(x2, tm[8], fmaf(x1, tm[5], x0 * tm[2]));
+                x0 = y0; x1 = y1; x2 = y2;
+            }
+            xs[L.tid] = x0; xs[TP + L.tid] = x1; xs[2 * TP + L.tid] = x2;
+            cf[L.tid] = coef[(size_t)b * 1024 + c];
+        }
+        __syncthreads();
+        layer1_tile(xs, P.w1, P.b1, P.s1c, P.t1c, h1, L);
+        __syncthreads();
+        {
+            f32x16 a0, a1;
+            const int cb = L.wave;
+            layer2_mfma(h1, P.w2p, cb, L, a0, a1);
+            const float sc = P.s2c[cb * 32 + L.j], sh = P.t2c[cb * 32 + L.j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mfma_row(r, L.lane);
+                h2[row * H2S + cb * 32 + L.j] = fmaxf(fmaf(a0[r], sc, sh), 0.f);
+                h2[(32 + row) * H2S + cb * 32 + L.j] = fmaxf(fmaf(a1[r], sc, sh), 0.f);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int r = rh * 32 + i;
+            g[i] = fmaf(cf[r], h2[r * H2S + k], g[i]);
+        }
+        __syncthreads();
+    }
+    float *o = Gp + ((size_t)rng * 1024 + cc * 64 + rh * 32) * 128 + k;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) o[(size_t)i * 128] = g[i];
+}
+
+// ---------------------------------------------------------------------------------------
+// backward pass D: g2 = dL/d(bn2 output) per point, written to HBM (B,N,128); accumulates
+//   pa [blk][128][2] = sum g2, sum g2*zhat2 ;  pP [blk][128][64] = sum_points g2 h1^T
+//   dh2[point][k] = cvec[k] - (h2 Asym)[point][k] + sum_{c: idx[b][c]==point} coef[b][c] W3[c][k]
+// ---------------------------------------------------------------------------------------
+struct BwdDParams {
+    const float *is2, *nm2;     // zhat2 = z2*is2 + nm2
+    const float *Ap;            // (128,128) symmetric, MFMA_B packed
+    const float *cvec;          // (128)
+    const float *w3;            // (1024,128) raw row-major
+    const int *idx;             // (B,1024)
+    const float *coef;          // (B,1024)
+};
+#define BWD_D_LDS_FLOATS (TP * H1S + 2 * TP * H2S + 3 * TP + 4 * 256 + 4)
+
+__global__ __launch_bounds__(256, 1) void trunk_bwd_d_kernel(
+    const float *__restrict__ x, int N, const float *__restrict__ trans, TrainChan P, BwdDParams D,
+    int T, int S, float *__restrict__ g2buf, float *__restrict__ pa, float *__restrict__ pP) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *h1 = smem;
+    float *h2 = h1 + TP * H1S;
+    float *sp = h2 + TP * H2S;            // sparse term, later the g2 tile
+    float *xs = sp + TP * H2S;
+    int *hits = (int *)(xs + 3 * TP);     // [4][256]  (c << 8) | local point
+    int *hcnt = hits + 4 * 256;           // [4]
+    const Lane L;
+    const int b = blockIdx.x / S, s = blockIdx.x - b * S;
+    int t0, t1; tile_range(s, S, T, t0, t1);
+    const float *xb = x + (size_t)b * 3 * N;
+    float tm[9] = {0};
+    const bool has_t = trans != nullptr;
+    if (has_t) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) tm[i] = trans[(size_t)b * 9 + i];
+    }
+    const int *idxb = D.idx + (size_t)b * 1024;
+    const float *coefb = D.coef + (size_t)b * 1024;
+    f32x16 pp0, pp1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { pp0[r] = 0.f; pp1[r] = 0.f; }
+    float a1s = 0.f, a2s = 0.f;
+    const int cb = L.wave;
+    const int c2 = cb * 32 + L.j;
+    const float sc2 = P.s2c[c2], sh2 = P.t2c[c2], is2 = D.is2[c2], nm2 = D.nm2[c2], cv = D.cvec[c2];
+    for (int tile = t0; tile < t1; ++tile) {
+        const int nbase = tile * TP;
+        stage_points(xb, N, tile, has_t, tm, xs, nullptr, L.tid);
+        for (int i = L.tid; i < TP * H2S; i += 256) sp[i] = 0.f;
+        __syncthreads();
+        layer1_tile(xs, P.w1, P.b1, P.s1c, P.t1c, h1, L);
+        // ordered compaction of this tile's arg-extremum hits: wave w scans channels [256w, 256w+256)
+        {
+            int cnt = 0;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int c = L.wave * 256 + it * 64 + L.lane;
+                const int n = idxb[c];
+                const bool hit = (n >= nbase) && (n < nbase + TP);
+                const unsigned long long mask = __ballot(hit);
+                if (hit) {
+                    const int pos = cnt + __popcll(mask & ((1ull << L.lane) - 1ull));
+                    hits[L.wave * 256 + pos] = (c << 8) | (n - nbase);
+                }
+                cnt += __popcll(mask);
+            }
+            if (L.lane == 0) hcnt[L.wave] = cnt;
+        }
+        __syncthreads();
+        f32x16 zh0, zh1;   // zhat2 for (points of this lane, channel c2)
+        {
+            f32x16 a0, a1;
+            layer2_mfma(h1, P.w2p, cb, L, a0, a1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mfma_row(r, L.lane);
+                h2[row * H2S + c2] = fmaxf(fmaf(a0[r], sc2, sh2), 0.f);
+                h2[(32 + row) * H2S + c2] = fmaxf(fmaf(a1[r], sc2, sh2), 0.f);
+                zh0[r] = fmaf(a0[r], is2, nm2);
+                zh1[r] = fmaf(a1[r], is2, nm2);
+                a0[r] = fmaf(a0[r], sc2, sh2);   // keep the pre-activation sign for the ReLU mask
+                a1[r] = fmaf(a1[r], sc2, sh2);
+            }
+            // sparse term (deterministic order: waves' lists in order, ascending channel)
+            {
+                const int k = L.tid & 127, half = L.tid >> 7;
+                for (int w = 0; w < 4; ++w) {
+                    const int n = hcnt[w];
+                    for (int e = 0; e < n; ++e) {
+                        const int hv = hits[w * 256 + e];
+                        const int p = hv & 255, c = hv >> 8;
+                        if ((p & 1) == half) sp[p * H2S + k] = fmaf(coefb[c], D.w3[(size_t)c * 128 + k], sp[p * H2S + k]);
+                    }
+                }
+            }
+            __syncthreads();
+            f32x16 d0, d1;
+            k128_mfma(h2, D.Ap, cb, L, d0, d1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mfma_row(r, L.lane);
+                const bool v0 = nbase + row < N, v1 = nbase + 32 + row < N;
+                float g0 = cv - d0[r] + sp[row * H2S + c2];
+                float g1 = cv - d1[r] + sp[(32 + row) * H2S + c2];
+                g0 = (v0 && a0[r] > 0.f) ? g0 : 0.f;
+                g1 = (v1 && a1[r] > 0.f) ? g1 : 0.f;
+                a1s += g0 + g1;
+                a2s = fmaf(g0, zh0[r], fmaf(g1, zh1[r], a2s));
+                sp[row * H2S + c2] = g0;            // same element this lane just read
+                sp[(32 + row) * H2S + c2] = g1;
+                if (v0) g2buf[((size_t)b * N + nbase + row) * 128 + c2] = g0;
+                if (v1) g2buf[((size_t)b * N + nbase + 32 + row) * 128 + c2] = g1;
+            }
+        }
+        __syncthreads();
+        // P += g2^T h1 : rows o = cb*32 + i, columns c = {0,1}*32 + j, contraction over the 64 points
+#pragma unroll 4
+        for (int st = 0; st < 32; ++st) {
+            const int pt = 2 * st + L.h;
+            const float av = sp[pt * H2S + cb * 32 + L.j];
+            const float *hr = h1 + pt * H1S + L.j;
+            pp0 = mfma32(av, hr[0], pp0);
+            pp1 = mfma32(av, hr[32], pp1);
+        }
+        __syncthreads();
+    }
+    a1s += __shfl_xor(a1s, 32);
+    a2s += __shfl_xor(a2s, 32);
+    if (L.h == 0) {
+        float *o = pa + ((size_t)blockIdx.x * 128 + c2) * 2;
+        o[0] = a1s; o[1] = a2s;
+    }
+    float *oP = pP + (size_t)blockIdx.x * 128 * 64;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int o = cb * 32 + mfma_row(r, L.lane);
+        oP[o * 64 + L.j] = pp0[r];
+        oP[o * 64 + 32 + L.j] = pp1[r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// backward pass E: dz2 -> dh1 = W2^T dz2 -> g1 = dL/d(bn1 output); accumulates
+//   pc [blk][64][2] = sum g1, sum g1*zhat1 ;  pR [blk][64][3] = sum_points g1 x^T (original x)
+// ---------------------------------------------------------------------------------------
+struct BwdEParams {
+    const float *is1, *nm1;       // zhat1 = z1*is1 + nm1
+    const float *is2, *nm2;
+    const float *a1m, *a2m;       // (128) a1/M, a2/M
+    const float *dsc2;            // (128) gamma2/sigma2
+    const float *w2tp;            // W2^T as a (64,128) matrix, MFMA_B packed
+};
+#define BWD_E_LDS_FLOATS (TP * H1S + TP * H2S + 6 * TP)
+
+__global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
+    const float *__restrict__ x, int N, const float *__restrict__ trans, TrainChan P, BwdEParams E,
+    int T, int S, const float *__restrict__ g2buf, float *__restrict__ pc, float *__restrict__ pR) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *h1 = smem;
+    float *dz = h1 + TP * H1S;    // [TP][H2S]
+    float *xs = dz + TP * H2S;    // [3][TP] transformed
+    float *xo = xs + 3 * TP;      // [3][TP] original
+    const Lane L;
+    const int b = blockIdx.x / S, s = blockIdx.x - b * S;
+    int t0, t1; tile_range(s, S, T, t0, t1);
+    const float *xb = x + (size_t)b * 3 * N;
+    float tm[9] = {0};
+    const bool has_t = trans != nullptr;
+    if (has_t) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) tm[i] = trans[(size_t)b * 9 + i];
+    }
+    const int cb = L.wave, c2 = cb * 32 + L.j;
+    const float is2 = E.is2[c2], nm2 = E.nm2[c2], a1m = E.a1m[c2], a2m = E.a2m[c2], dsc = E.dsc2[c2];
+    // dh1 tile owned by this wave: point block pb1, channel block cb1
+    const int pb1 = L.wave >> 1, cb1 = L.wave & 1, c1 = cb1 * 32 + L.j;
+    const float w10 = P.w1[c1 * 3], w11 = P.w1[c1 * 3 + 1], w12 = P.w1[c1 * 3 + 2], bb1 = P.b1[c1];
+    const float is1 = E.is1[c1], nm1 = E.nm1[c1];
+    float c1s = 0.f, c2s = 0.f, r0 = 0.f, r1 = 0.f, r2 = 0.f;
+    for (int tile = t0; tile < t1; ++tile) {
+        const int nbase = tile * TP;
+        stage_points(xb, N, tile, has_t, tm, xs, xo, L.tid);
+        __syncthreads();
+        layer1_tile(xs, P.w1, P.b1, P.s1c, P.t1c, h1, L);
+        __syncthreads();
+        {
+            f32x16 a0, a1;
+            layer2_mfma(h1, P.w2p, cb, L, a0, a1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mfma_row(r, L.lane);
+                const bool v0 = nbase + row < N, v1 = nbase + 32 + row < N;
+                const float g0 = v0 ? g2buf[((size_t)b * N + nbase + row) * 128 + c2] : 0.f;
+                const float g1 = v1 ? g2buf[((size_t)b * N + nbase + 32 + row) * 128 + c2] : 0.f;
+                const float z0 = fmaf(a0[r], is2, nm2), z1 = fmaf(a1[r], is2, nm2);
+                dz[row * H2S + c2] = v0 ? dsc * (g0 - a1m - z0 * a2m) : 0.f;
+                dz[(32 + row) * H2S + c2] = v1 ? dsc * (g1 - a1m - z1 * a2m) : 0.f;
+            }
+        }
+        __syncthreads();
+        {
+            // dh1[point][c1] = sum_o dz[point][o] * W2[o][c1]   (K = 128), one 32x32 tile per wave
+            const f32x4 *wp = (const f32x4 *)E.w2tp + (size_t)(cb1 * 16) * 64 + L.lane;
+            const float *ap = dz + (pb1 * 32 + L.j) * H2S + L.h * 4;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 16; ++kb) {
+                f32x4 wv = wp[kb * 64];
+                f32x4 av = *(const f32x4 *)(ap + kb * 8);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc = mfma32(av[t], wv[t], acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pt = pb1 * 32 + mfma_row(r, L.lane);
+                const float g1v = (h1[pt * H1S + c1] > 0.f) ? acc[r] : 0.f;   // rows past N: dz == 0 -> 0
+                const float xp0 = xs[pt], xp1 = xs[TP + pt], xp2 = xs[2 * TP + pt];
+                const float z1 = fmaf(w12, xp2, fmaf(w11, xp1, fmaf(w10, xp0, bb1)));
+                c1s += g1v;
+                c2s = fmaf(g1v, fmaf(z1, is1, nm1), c2s);
+                r0 = fmaf(g1v, xo[pt], r0);
+                r1 = fmaf(g1v, xo[TP + pt], r1);
+                r2 = fmaf(g1v, xo[2 * TP + pt], r2);
+            }
+        }
+        __syncthreads();
+    }
+    c1s += __shfl_xor(c1s, 32); c2s += __shfl_xor(c2s, 32);
+    r0 += __shfl_xor(r0, 32); r1 += __shfl_xor(r1, 32); r2 += __shfl_xor(r2, 32);
+    // two waves (pb1 = 0,1) own the same channel block: combine through LDS
+    float *red = dz;   // safe: every wave passed the loop's final barrier
+    if (L.h == 0) {
+        float *o = red + (L.wave * 32 + L.j) * 5;
+        o[0] = c1s; o[1] = c2s; o[2] = r0; o[3] = r1; o[4] = r2;
+    }
+    __syncthreads();
+    if (L.tid < 64) {
+        const int cb_ = L.tid >> 5, jj = L.tid & 31;
+        const float *p0 = red + ((0 * 2 + cb_) * 32 + jj) * 5;   // wave = pb1*2 + cb1
+        const float *p1 = red + ((1 * 2 + cb_) * 32 + jj) * 5;
+        float *oc = pc + ((size_t)blockIdx.x * 64 + L.tid) * 2;
+        oc[0] = p0[0] + p1[0]; oc[1] = p0[1] + p1[1];
+        float *oR = pR + ((size_t)blockIdx.x * 64 + L.tid) * 3;
+        oR[0] = p0[2] + p1[2]; oR[1] = p0[3] + p1[3]; oR[2] = p0[4] + p1[4];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// BatchNorm1d over the batch (FC stacks) — train forward / backward, optional fused ReLU.
+// block = 32 channels x 8 row lanes.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn1d_fwd_train_kernel(
+    const float *__restrict__ z, int B, int C, const float *__restrict__ gamma,
+    const float *__restrict__ beta, float eps, int relu, float *__restrict__ y,
+    float *__restrict__ mean_out, float *__restrict__ var_out) {
+    __shared__ float red[8][33];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
+    const bool ok = c < C;
+    float s = 0.f;
+    if (ok) for (int b = ry; b < B; b += 8) s += z[(size_t)b * C + c];
+    red[ry][cx] = s;
+    __syncthreads();
+    float mean = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mean += red[i][cx];
+    mean /= (float)B;
+    __syncthreads();
+    float q = 0.f;
+    if (ok) for (int b = ry; b < B; b += 8) { float d = z[(size_t)b * C + c] - mean; q = fmaf(d, d, q); }
+    red[ry][cx] = q;
+    __syncthreads();
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) var += red[i][cx];
+    var /= (float)B;
+    if (!ok) return;
+    const float inv = 1.0f / sqrtf(var + eps);
+    const float g = gamma[c], be = beta[c];
+    for (int b = ry; b < B; b += 8) {
+        float v = (z[(size_t)b * C + c] - mean) * inv * g + be;
+        if (relu) v = fmaxf(v, 0.f);
+        y[(size_t)b * C + c] = v;
+    }
+    if (ry == 0) { mean_out[c] = mean; var_out[c] = var; }
+}
+
+// dy: gradient wrt the (post-ReLU if relu) output y.  dz, dgamma, dbeta out.
+__global__ __launch_bounds__(256) void bn1d_bwd_kernel(
+    const float *__restrict__ dy, const float *__restrict__ z, const float *__restrict__ y, int B, int C,
+    const float *__restrict__ gamma, const float *__restrict__ mean, const float *__restrict__ var,
+    float eps, int relu, float *__restrict__ dz, float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    __shared__ float red[2][8][33];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
+    const bool ok = c < C;
+    float mu = 0.f, inv = 0.f;
+    if (ok) { mu = mean[c]; inv = 1.0f / sqrtf(var[c] + eps); }
+    float s1 = 0.f, s2 = 0.f;
+    if (ok) for (int b = ry; b < B; b += 8) {
+        const size_t i = (size_t)b * C + c;
+        float g = dy[i];
+        if (relu && !(y[i] > 0.f)) g = 0.f;
+        s1 += g;
+        s2 = fmaf(g, (z[i] - mu) * inv, s2);
+    }
+    red[0][ry][cx] = s1; red[1][ry][cx] = s2;
+    __syncthreads();
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { t1 += red[0][i][cx]; t2 += red[1][i][cx]; }
+    if (!ok) return;
+    const float gi = gamma[c] * inv, m1 = t1 / (float)B, m2 = t2 / (float)B;
+    for (int b = ry; b < B; b += 8) {
+        const size_t i = (size_t)b * C + c;
+        float g = dy[i];
+        if (relu && !(y[i] > 0.f)) g = 0.f;
+        dz[i] = gi * (g - m1 - (z[i] - mu) * inv * m2);
+    }
+    if (ry == 0) { dgamma[c] = t2; dbeta[c] = t1; }
+}
+
+// dlogits = g - exp(logp) * rowsum(g)      (backward of F.log_softmax, pointnet.py:194)
+__global__ void log_softmax_bwd_kernel(const float *__restrict__ g, const float *__restrict__ logp,
+                                       int B, int K, float *__restrict__ dlogits) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += g[(size_t)b * K + k];
+    for (int k = 0; k < K; ++k) dlogits[(size_t)b * K + k] = g[(size_t)b * K + k] - expf(logp[(size_t)b * K + k]) * s;
+}
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+// LDS requests above 64 KB need an explicit opt-in per kernel.
+static void allow_lds(const void *fn, size_t bytes) {
+    if (bytes > 48 * 1024) hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+static TrainChan make_chan(const float *w1, const float *b1, const float *s1c, const float *t1c,
+                           const float *w2p, const float *s2c, const float *t2c) {
+    TrainChan P; P.w1 = w1; P.b1 = b1; P.s1c = s1c; P.t1c = t1c; P.w2p = w2p; P.s2c = s2c; P.t2c = t2c;
+    return P;
+}
+
+extern "C" {
+
+int pngpd_train_set_target_blocks(int v) { g_train_target_blocks = v > 0 ? v : 1; return PNGPD_OK; }
+
+int pngpd_trunk_train_splits(int B, int N) {
+    if (B <= 0 || N <= 0) return 0;
+    return train_splits(B, (N + TP - 1) / TP);
+}
+
+int pngpd_cloud_moments(const float *x, int B, int N, double *mom, void *stream) {
+    if (!x || !mom || B <= 0 || N <= 0) return PNGPD_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(cloud_moments_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, N, mom);
+    return pngpd_launch_status();
+}
+
+int pngpd_trunk_bn2_stats(const float *x, int B, int N, const float *trans,
+                          const float *w1, const float *b1, const float *s1c, const float *t1c,
+                          const float *w2p, float *part, void *stream) {
+    if (!x || !w1 || !b1 || !s1c || !t1c || !w2p || !part || B <= 0 || N <= 0) return PNGPD_ERR_INVALID_ARG;
+    const int T = (N + TP - 1) / TP, S = train_splits(B, T);
+    TrainChan P = make_chan(w1, b1, s1c, t1c, w2p, nullptr, nullptr);
+    const size_t lds = (TP * H1S + 3 * TP) * sizeof(float);
+    hipLaunchKernelGGL(trunk_bn2_stats_kernel, dim3((unsigned)B * S), dim3(256), lds, (hipStream_t)stream,
+                       x, N, trans, P, T, S, part);
+    return pngpd_launch_status();
+}
+
+int pngpd_trunk_fwd_train(const float *x, int B, int N, const float *trans,
+                          const float *w1, const float *b1, const float *s1c, const float *t1c,
+                          const float *w2p, const float *s2c, const float *t2c, const float *w3sp,
+                          float *pmax, int *parg, float *psum, void *stream) {
+    if (!x || !w1 || !b1 || !s1c || !t1c || !w2p || !s2c || !t2c || !w3sp || !pmax || !parg || !psum ||
+        B <= 0 || N <= 0)
+        return PNGPD_ERR_INVALID_ARG;
+    const int T = (N + TP - 1) / TP, S = train_splits(B, T);
+    TrainChan P = make_chan(w1, b1, s1c, t1c, w2p, s2c, t2c);
+    const size_t lds = TRAIN_MAIN_LDS_FLOATS * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) { allow_lds((const void *)trunk_fwd_train_kernel, lds); attr_set = true; }
+    hipLaunchKernelGGL(trunk_fwd_train_kernel, dim3((unsigned)B * S), dim3(256), lds, (hipStream_t)stream,
+                       x, N, trans, P, w3sp, T, S, pmax, parg, psum);
+    return pngpd_launch_status();
+}
+
+int pngpd_trunk_h_moments(const float *x, int B, int N, const float *trans,
+                          const float *w1, const float *b1, const float *s1c, const float *t1c,
+                          const float *w2p, const float *s2c, const float *t2c,
+                          float *ps2, float *ps1, float *psh, void *stream) {
+    if (!x || !w1 || !b1 || !s1c || !t1c || !w2p || !s2c || !t2c || !ps2 || !ps1 || !psh || B <= 0 || N <= 0)
+        return PNGPD_ERR_INVALID_ARG;
+    const int T = (N + TP - 1) / TP;
+    TrainChan P = make_chan(w1, b1, s1c, t1c, w2p, s2c, t2c);
+    const size_t lds = (TP * H1S + TP * H2S + 3 * TP) * sizeof(float);
+    hipLaunchKernelGGL(trunk_h_moments_kernel, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream,
+                       x, N, trans, P, T, ps2, ps1, psh);
+    return pngpd_launch_status();
+}
+
+int pngpd_trunk_bwd_gather(const float *x, int B, int N, const float *trans,
+                           const float *w1, const float *b1, const float *s1c, const float *t1c,
+                           const float *w2p, const float *s2c, const float *t2c,
+                           const int *idx, const float *coef, int clouds_per_range, float *Gp, void *stream) {
+    if (!x || !w1 || !b1 || !s1c || !t1c || !w2p || !s2c || !t2c || !idx || !coef || !Gp || B <= 0 || N <= 0 ||
+        clouds_per_range <= 0)
+        return PNGPD_ERR_INVALID_ARG;
+    const int R = (B + clouds_per_range - 1) / clouds_per_range;
+    TrainChan P = make_chan(w1, b1, s1c, t1c, w2p, s2c, t2c);
+    const size_t lds = (TP * H1S + TP * H2S + 3 * TP + 64) * sizeof(float);
+    hipLaunchKernelGGL(trunk_bwd_gather_kernel, dim3((unsigned)R * 16), dim3(256), lds, (hipStream_t)stream,
+                       x, B, N, trans, P, idx, coef, clouds_per_range, Gp);
+    return pngpd_launch_status();
+}
+
+int pngpd_trunk_bwd_d(const float *x, int B, int N, const float *trans,
+                      const float *w1, const float *b1, const float *s1c, const float *t1c,
+                      const float *w2p, const float *s2c, const float *t2c,
+                      const float *is2, const float *nm2, const float *Ap, const float *cvec,
+                      const float *w3, const int *idx, const float *coef,
+                      float *g2buf, float *pa, float *pP, void *stream) {
+    if (!x || !w1 || !b1 || !s1c || !t1c || !w2p || !s2c || !t2c || !is2 || !nm2 || !Ap || !cvec || !w3 ||
+        !idx || !coef || !g2buf || !pa || !pP || B <= 0 || N <= 0)
+        return PNGPD_ERR_INVALID_ARG;
+    const int T = (N + TP - 1) / TP, S = train_splits(B, T);
+    TrainChan P = make_chan(w1, b1, s1c, t1c, w2p, s2c, t2c);
+    BwdDParams D; D.is2 = is2; D.nm2 = nm2; D.Ap = Ap; D.cvec = cvec; D.w3 = w3; D.idx = idx; D.coef = coef;
+    const size_t lds = BWD_D_LDS_FLOATS * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) { allow_lds((const void *)trunk_bwd_d_kernel, lds); attr_set = true; }
+    hipLaunchKernelGGL(trunk_bwd_d_kernel, dim3((unsigned)B * S), dim3(256), lds, (hipStream_t)stream,
+                       x, N, trans, P, D, T, S, g2buf, pa, pP);
+    return pngpd_launch_status();
+}
+
+int pngpd_trunk_bwd_e(const float *x, int B, int N, const float *trans,
+                      const float *w1, const float *b1, const float *s1c, const float *t1c,
+                      const float *w2p, const float *is1, const float *nm1, const float *is2, const float *nm2,
+                      const float *a1m, const float *a2m, const float *dsc2, const float *w2tp,
+                      const float *g2buf, float *pc, float *pR, void *stream) {
+    if (!x || !w1 || !b1 || !s1c || !t1c || !w2p || !is1 || !nm1 || !is2 || !nm2 || !a1m || !a2m || !dsc2 ||
+        !w2tp || !g2buf || !pc || !pR || B <= 0 || N <= 0)
+        return PNGPD_ERR_INVALID_ARG;
+    const int T = (N + TP - 1) / TP, S = train_splits(B, T);
+    TrainChan P = make_chan(w1, b1, s1c, t1c, w2p, nullptr, nullptr);
+    BwdEParams E; E.is1 = is1; E.nm1 = nm1; E.is2 = is2; E.nm2 = nm2; E.a1m = a1m; E.a2m = a2m; E.dsc2 = dsc2;
+    E.w2tp = w2tp;
+    const size_t lds = BWD_E_LDS_FLOATS * sizeof(float);
+    hipLaunchKernelGGL(trunk_bwd_e_kernel, dim3((unsigned)B * S), dim3(256), lds, (hipStream_t)stream,
+                       x, N, trans, P, E, T, S, g2buf, pc, pR);
+    return pngpd_launch_status();
+}
+
+int pngpd_bn1d_fwd_train(const float *z, int B, int C, const float *gamma, const float *beta, float eps,
+                         int relu, float *y, float *mean, float *var, void *stream) {
+    if (!z || !gamma || !beta || !y || !mean || !var || B <= 0 || C <= 0) return PNGPD_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(bn1d_fwd_train_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream,
+                       z, B, C, gamma, beta, eps, relu, y, mean, var);
+    return pngpd_launch_status();
+}
+
+int pngpd_bn1d_bwd(const float *dy, const float *z, const float *y, int B, int C, const float *gamma,
+                   const float *mean, const float *var, float eps, int relu,
+                   float *dz, float *dgamma, float *dbeta, void *stream) {
+    if (!dy || !z || !y || !gamma || !mean || !var || !dz || !dgamma || !dbeta || B <= 0 || C <= 0)
+        return PNGPD_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(bn1d_bwd_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream,
+                       dy, z, y, B, C, gamma, mean, var, eps, relu, dz, dgamma, dbeta);
+    return pngpd_launch_status();
+}
+
+int pngpd_log_softmax_bwd(const float *g, const float *logp, int B, int K, float *dlogits, void *stream) {
+    if (!g || !logp || !dlogits || B <= 0 || K <= 0) return PNGPD_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(log_softmax_bwd_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       g, logp, B, K, dlogits);
+    return pngpd_launch_status();
+}
+
+}  // extern "C"

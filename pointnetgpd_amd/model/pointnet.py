@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import ops
+from .. import ops, train
 
 _TRUNK_WIDTHS = (64, 128, 1024)
 
@@ -123,10 +123,10 @@ def _trunk_aten(mod, x, relu_last):
     return torch.max(x, dim=2)[0]
 
 
-def _train_on_cuda():
-    raise NotImplementedError(
-        "train-mode (batch-statistics BatchNorm, backward) HIP kernels are not available in this "
-        "build; call .eval() for the HIP inference path or run training on CPU tensors")
+def _check_train_batch(x):
+    if x.shape[0] < 2:
+        # same condition nn.BatchNorm1d enforces on the (B,C) FC activations in train mode
+        raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")
 
 
 # ---------------------------------------------------------------------------------------
@@ -153,13 +153,20 @@ class STN3d(_HipModule):
         _check_points(x, self.num_points, self.conv1.in_channels)
         if x.is_cuda:
             if self.training:
-                _train_on_cuda()
+                return self._forward_hip_train(x)
             return self._forward_hip_infer(x)
         g = _trunk_aten(self, x, relu_last=True)
         g = F.relu(self.bn4(self.fc1(g)))
         g = F.relu(self.bn5(self.fc2(g)))
         g = self.fc3(g)
         return (g + torch.eye(3, dtype=g.dtype, device=g.device).reshape(1, 9)).view(-1, 3, 3)
+
+    def _forward_hip_train(self, x):
+        _check_train_batch(x)
+        pooled = train.trunk_train(self, x.contiguous(), None, relu_last=True)
+        g = train.fc_bn_relu_train(self.fc1, self.bn4, pooled)
+        g = train.fc_bn_relu_train(self.fc2, self.bn5, g)
+        return train.fc_epilogue_train(self.fc3, g, ops.EPI_ADD_IDEN3).view(-1, 3, 3)
 
     def _forward_hip_infer(self, x):
         dev = x.device
@@ -189,10 +196,10 @@ class PointNetfeat(_HipModule):
     def forward(self, x):
         _check_points(x, self.num_points, self.conv1.in_channels)
         if x.is_cuda and self.global_feat:
-            if self.training:
-                _train_on_cuda()
             x = x.contiguous()
             trans = self.stn(x)
+            if self.training:
+                return train.trunk_train(self, x, trans.contiguous(), relu_last=False), trans
             pooled = ops.trunk_fwd_infer(x, trans.contiguous(), *_trunk_infer_weights(self, x.device),
                                          relu_last=False)
             return pooled, trans
@@ -228,7 +235,9 @@ class PointNetCls(_HipModule):
         g, trans = self.feat(x)
         if g.is_cuda:
             if self.training:
-                _train_on_cuda()
+                g = train.fc_bn_relu_train(self.fc1, self.bn1, g)
+                g = train.fc_bn_relu_train(self.fc2, self.bn2, g)
+                return train.fc_epilogue_train(self.fc3, g, ops.EPI_LOG_SOFTMAX), trans
             (w1, b1), (w2, b2), (w3, b3) = _fc_infer_weights(self, [("fc1", "bn1"), ("fc2", "bn2"), ("fc3", None)],
                                                              g.device)
             g = ops.fc_fwd(g, w1, b1, ops.EPI_RELU)

@@ -96,3 +96,149 @@ def fc_fwd(inp, W, bias, epilogue):
         _lib.check(lib.pngpd_fc_fwd(_ptr(inp), B, K, _ptr(W), _ptr(bias), Nout, int(epilogue), _ptr(out),
                                     _stream(inp)), "fc_fwd")
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# training passes (include/pngpd.h "Training path")
+# ---------------------------------------------------------------------------------------------
+def _call(name, ref, *args):
+    """Generic C-ABI call: tensors -> device pointers, None -> NULL, scalars as is; the stream of
+    ``ref``'s device is appended.  Every tensor must be CUDA + contiguous (dtype is the callee's
+    contract and is checked by the typed wrappers below)."""
+    lib = _lib.load()
+    conv = []
+    for a in args:
+        if isinstance(a, torch.Tensor):
+            if not a.is_cuda or not a.is_contiguous():
+                raise RuntimeError(f"{name}: expected contiguous CUDA tensors")
+            conv.append(ctypes.c_void_p(a.data_ptr()))
+        elif a is None:
+            conv.append(ctypes.c_void_p(0))
+        else:
+            conv.append(a)
+    with torch.cuda.device(ref.device):
+        _lib.check(getattr(lib, name)(*conv, _stream(ref)), name)
+
+
+def _f32(t, name, shape=None):
+    return _req(t, name, shape)
+
+
+def train_splits(B, N):
+    return _lib.load().pngpd_trunk_train_splits(int(B), int(N))
+
+
+def set_train_target_blocks(v):
+    _lib.check(_lib.load().pngpd_train_set_target_blocks(int(v)), "train_set_target_blocks")
+
+
+def pack_mfma_b(W, scale=None):
+    """(C,K) fp32 -> MFMA_B packed flat tensor (optionally rows scaled by ``scale``)."""
+    C, K = W.shape
+    zb = torch.zeros(C, device=W.device, dtype=torch.float32)
+    wp, _ = fold_conv_bn(W, zb, bn_weight=scale, layout=LAYOUT_MFMA_B) if scale is None else \
+        _fold_scale(W, zb, scale)
+    return wp
+
+
+def _fold_scale(W, b, scale):
+    lib = _lib.load()
+    W = _req(W.detach().contiguous(), "W"); C, K = W.shape
+    scale = _req(scale.detach().contiguous(), "scale", (C,))
+    wf = torch.empty(C * K, device=W.device, dtype=torch.float32)
+    bf = torch.empty(C, device=W.device, dtype=torch.float32)
+    with torch.cuda.device(W.device):
+        _lib.check(lib.pngpd_fold_conv_bn(_ptr(W), _ptr(b), _ptr(scale), None, None, None, 0.0, C, K,
+                                          LAYOUT_MFMA_B, _ptr(wf), _ptr(bf), _stream(W)), "fold(scale)")
+    return wf, bf
+
+
+def cloud_moments(x):
+    B, _, N = x.shape
+    mom = torch.empty(B, 9, device=x.device, dtype=torch.float64)
+    _call("pngpd_cloud_moments", x, _f32(x, "x"), B, N, mom)
+    return mom
+
+
+def trunk_bn2_stats(x, trans, w1, b1, s1c, t1c, w2p):
+    B, _, N = x.shape
+    blk = B * train_splits(B, N)
+    part = torch.empty(blk, 128, 2, device=x.device, dtype=torch.float32)
+    _call("pngpd_trunk_bn2_stats", x, x, B, N, trans, w1, b1, s1c, t1c, w2p, part)
+    return part
+
+
+def trunk_fwd_train(x, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, w3sp):
+    B, _, N = x.shape
+    S = train_splits(B, N)
+    pmax = torch.empty(B, S, 1024, device=x.device, dtype=torch.float32)
+    parg = torch.empty(B, S, 1024, device=x.device, dtype=torch.int32)
+    psum = torch.empty(B * S, 2, 1024, device=x.device, dtype=torch.float32)
+    _call("pngpd_trunk_fwd_train", x, x, B, N, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, w3sp, pmax, parg, psum)
+    return pmax, parg, psum
+
+
+def trunk_h_moments(x, trans, w1, b1, s1c, t1c, w2p, s2c, t2c):
+    B, _, N = x.shape
+    ps2 = torch.empty(B, 128, 128, device=x.device, dtype=torch.float32)
+    ps1 = torch.empty(B, 64, 64, device=x.device, dtype=torch.float32)
+    psh = torch.empty(B, 192, device=x.device, dtype=torch.float32)
+    _call("pngpd_trunk_h_moments", x, x, B, N, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, ps2, ps1, psh)
+    return ps2, ps1, psh
+
+
+def trunk_bwd_gather(x, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, idx, coef, clouds_per_range=16):
+    B, _, N = x.shape
+    R = (B + clouds_per_range - 1) // clouds_per_range
+    Gp = torch.empty(R, 1024, 128, device=x.device, dtype=torch.float32)
+    _call("pngpd_trunk_bwd_gather", x, x, B, N, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, idx, coef,
+          int(clouds_per_range), Gp)
+    return Gp
+
+
+def trunk_bwd_d(x, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, is2, nm2, Ap, cvec, w3, idx, coef):
+    B, _, N = x.shape
+    blk = B * train_splits(B, N)
+    g2buf = torch.empty(B, N, 128, device=x.device, dtype=torch.float32)
+    pa = torch.empty(blk, 128, 2, device=x.device, dtype=torch.float32)
+    pP = torch.empty(blk, 128, 64, device=x.device, dtype=torch.float32)
+    _call("pngpd_trunk_bwd_d", x, x, B, N, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, is2, nm2, Ap, cvec, w3,
+          idx, coef, g2buf, pa, pP)
+    return g2buf, pa, pP
+
+
+def trunk_bwd_e(x, trans, w1, b1, s1c, t1c, w2p, is1, nm1, is2, nm2, a1m, a2m, dsc2, w2tp, g2buf):
+    B, _, N = x.shape
+    S = train_splits(B, N)
+    pc = torch.empty(B * S, 64, 2, device=x.device, dtype=torch.float32)
+    pR = torch.empty(B, S, 64, 3, device=x.device, dtype=torch.float32)
+    _call("pngpd_trunk_bwd_e", x, x, B, N, trans, w1, b1, s1c, t1c, w2p, is1, nm1, is2, nm2, a1m, a2m, dsc2,
+          w2tp, g2buf, pc, pR)
+    return pc, pR
+
+
+def bn1d_fwd_train(z, gamma, beta, eps, relu):
+    B, C = z.shape
+    y = torch.empty_like(z)
+    mean = torch.empty(C, device=z.device, dtype=torch.float32)
+    var = torch.empty(C, device=z.device, dtype=torch.float32)
+    _call("pngpd_bn1d_fwd_train", z, _f32(z, "z"), B, C, _f32(gamma, "gamma", (C,)), _f32(beta, "beta", (C,)),
+          float(eps), int(relu), y, mean, var)
+    return y, mean, var
+
+
+def bn1d_bwd(dy, z, y, gamma, mean, var, eps, relu):
+    B, C = z.shape
+    dz = torch.empty_like(z)
+    dgamma = torch.empty(C, device=z.device, dtype=torch.float32)
+    dbeta = torch.empty(C, device=z.device, dtype=torch.float32)
+    _call("pngpd_bn1d_bwd", z, _f32(dy, "dy", (B, C)), z, y, B, C, gamma, mean, var, float(eps), int(relu),
+          dz, dgamma, dbeta)
+    return dz, dgamma, dbeta
+
+
+def log_softmax_bwd(g, logp):
+    B, K = logp.shape
+    out = torch.empty_like(logp)
+    _call("pngpd_log_softmax_bwd", logp, _f32(g, "g", (B, K)), logp, B, K, out)
+    return out

@@ -1,0 +1,191 @@
+"""GPU parity of the train-mode HIP path (forward with batch-statistics BatchNorm, nll_loss,
+backward, running-stat updates) against (a) the golden vectors recorded from the reference and
+(b) the fp64 oracle (autograd through the reference's ATen op sequence).
+
+Tolerances (fp32 kernels vs fp64 truth): log-probs / loss 1e-3 absolute (north_star), per-tensor
+gradient error ||g - g_ref|| <= 2e-3 * ||g_ref|| (+ tiny absolute floor for the conv biases whose
+true gradient is exactly zero under train-mode BN)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import pointnet_oracle as po
+from tests.helpers import golden_files, build_model, assert_checksums, state_dict_cpu, synth_cloud
+from tests.train_algo_prototype import trunk_fwd, trunk_bwd
+
+pytestmark = pytest.mark.gpu
+TRAIN = golden_files("pointnet_train_")
+REL = 2e-3
+
+
+def _rel(a, b):
+    a = a.double().flatten(); b = b.double().flatten()
+    return (a - b).norm().item() / max(b.norm().item(), 1e-30)
+
+
+def _trunk_params(mod, dtype=torch.float64):
+    P = {}
+    for i in (1, 2, 3):
+        conv, bn = getattr(mod, f"conv{i}"), getattr(mod, f"bn{i}")
+        P[f"W{i}"] = conv.weight.detach()[:, :, 0].to(dtype).cpu()
+        P[f"b{i}"] = conv.bias.detach().to(dtype).cpu()
+        P[f"g{i}"] = bn.weight.detach().to(dtype).cpu()
+        P[f"be{i}"] = bn.bias.detach().to(dtype).cpu()
+    return P
+
+
+@pytest.mark.parametrize("B,N,use_t", [(4, 64, False), (3, 100, True), (5, 200, True), (2, 64, True), (6, 130, False)])
+def test_trunk_train_vs_prototype(B, N, use_t, cuda_device):
+    """One trunk, forward + backward, against the fp64 pass-structured prototype (which is itself
+    checked against autograd)."""
+    from pointnetgpd_amd import train
+    m = build_model(N, 2, 70 + B, 4400 + N).train()
+    mod = m.feat if use_t else m.feat.stn
+    P = _trunk_params(mod)
+    x = synth_cloud(B, N, 11 * B + N, "gauss") * 5.0
+    T = None
+    if use_t:
+        g = torch.Generator().manual_seed(9)
+        T = (torch.eye(3)[None] + 0.2 * torch.randn(B, 3, 3, generator=g)).float()
+    dp = torch.randn(B, 1024, generator=torch.Generator().manual_seed(3))
+    pooled_ref, sv = trunk_fwd(x.double(), T.double() if use_t else None, P, relu_last=not use_t)
+    gref = trunk_bwd(dp.double(), P, sv)
+    m = m.to(cuda_device)
+    mod = m.feat if use_t else m.feat.stn
+    Tg = T.to(cuda_device).requires_grad_(True) if use_t else None
+    pooled = train.trunk_train(mod, x.to(cuda_device), Tg, relu_last=not use_t)
+    assert "libpngpd.so" in open("/proc/self/maps").read()
+    np.testing.assert_allclose(pooled.detach().cpu().numpy(), pooled_ref.numpy(), atol=2e-4, rtol=2e-4)
+    (pooled * dp.to(cuda_device)).sum().backward()
+    pairs = [("W1", mod.conv1.weight), ("g1", mod.bn1.weight), ("be1", mod.bn1.bias),
+             ("W2", mod.conv2.weight), ("g2", mod.bn2.weight), ("be2", mod.bn2.bias),
+             ("W3", mod.conv3.weight), ("g3", mod.bn3.weight), ("be3", mod.bn3.bias)]
+    for name, p in pairs:
+        r = _rel(p.grad.cpu().reshape(gref[name].shape), gref[name])
+        assert r < REL, (name, r)
+    for name, p in [("b1", mod.conv1.bias), ("b2", mod.conv2.bias), ("b3", mod.conv3.bias)]:
+        assert p.grad.abs().max().item() < 1e-5
+    if use_t:
+        assert _rel(Tg.grad.cpu(), gref["T"]) < REL
+    # (running statistics are checked by the model-level tests below)
+
+
+@pytest.mark.parametrize("path", TRAIN, ids=lambda p: p.split("pointnet_train_")[-1][:-4])
+def test_golden_train(path, cuda_device):
+    """Forward + nll_loss + backward on the reference's recorded case."""
+    fx = np.load(path)
+    m = build_model(fx["num_points"], fx["k"], fx["seed_w"], fx["seed_bn"]).train()
+    assert_checksums(m, fx)
+    m = m.to(cuda_device)
+    x = torch.from_numpy(fx["x"]).to(cuda_device)
+    y = torch.from_numpy(fx["y"]).to(cuda_device)
+    logp, trans = m(x)
+    loss = F.nll_loss(logp, y)
+    loss.backward()
+    assert "libpngpd.so" in open("/proc/self/maps").read()
+    assert abs(loss.item() - float(fx["loss"])) < 1e-3
+    np.testing.assert_allclose(logp.detach().cpu().numpy(), fx["logp"], atol=1e-3, rtol=0)
+    np.testing.assert_allclose(trans.detach().cpu().numpy(), fx["trans"], atol=1e-3, rtol=0)
+    # The gradient is a discontinuous function of the inputs (arg-max / ReLU flips), so two fp32
+    # implementations differ by about the reference's own fp32-vs-fp64 error.  Yardstick: the fp64
+    # oracle on the same case.  |g_hip - g_ref32| <= 4*|g_ref32 - g_64| + 2e-3*|g_64|.
+    m0 = build_model(fx["num_points"], fx["k"], fx["seed_w"], fx["seed_bn"])
+    _, _, _, g64, _ = po.train_step_torch(state_dict_cpu(m0), torch.from_numpy(fx["x"]), torch.from_numpy(fx["y"]),
+                                          dtype=torch.float64)
+    # fp32 results of this case are machine-dependent at the flip level (the fixture was recorded on
+    # another CPU): also measure the oracle's fp32 run on THIS host and take the larger deviation.
+    _, _, _, g32here, _ = po.train_step_torch(state_dict_cpu(m0), torch.from_numpy(fx["x"]),
+                                              torch.from_numpy(fx["y"]), dtype=torch.float32)
+    params = dict(m.named_parameters())
+    for i, n in enumerate(str(s) for s in fx["grad_names"]):
+        g = params[n].grad.detach().cpu()
+        ref_norm = float(fx["grad_norm"][i])
+        if ref_norm < 1e-5:      # conv biases ahead of train-mode BN: exactly zero in exact arithmetic
+            assert g.abs().max().item() < 1e-4, n
+            continue
+        if "grad/" + n in fx:
+            ref32 = torch.from_numpy(fx["grad/" + n]).double().flatten(); got = g.double().flatten()
+            t64 = g64[n].double().flatten(); h32 = g32here[n].double().flatten()
+        else:
+            ix = torch.from_numpy(fx["gradidx/" + n])
+            ref32 = torch.from_numpy(fx["gradsample/" + n]).double(); got = g.double().flatten()[ix]
+            t64 = g64[n].double().flatten()[ix]; h32 = g32here[n].double().flatten()[ix]
+        tol = 4 * max((ref32 - t64).norm().item(), (h32 - t64).norm().item()) + 2e-3 * t64.norm().item()
+        assert (got - ref32).norm().item() <= tol, (n, (got - ref32).norm().item(), tol)
+    sd = m.state_dict()
+    for k in [k for k in fx.files if k.startswith("stat/")]:
+        np.testing.assert_allclose(sd[k[5:]].cpu().numpy(), fx[k], atol=2e-5, rtol=2e-4, err_msg=k)
+        nbt = k[5:].rsplit(".", 1)[0] + ".num_batches_tracked"
+        assert int(sd[nbt]) == 1
+
+
+@pytest.mark.parametrize("B,N,k", [(16, 750, 2), (5, 100, 3), (32, 1024, 3), (3, 64, 2)])
+def test_train_step_vs_oracle(B, N, k, cuda_device):
+    """Whole model vs the fp64 oracle (autograd over the reference's ATen sequence)."""
+    m = build_model(N, k, 80 + B, 4500 + B).train()
+    sd = state_dict_cpu(m)
+    x = synth_cloud(B, N, 900 + B, "box")
+    y = (torch.arange(B) * 7 % k).long()
+    loss_ref, logp_ref, trans_ref, grads_ref, stats_ref = po.train_step_torch(sd, x, y, dtype=torch.float64)
+    _, _, _, grads32, _ = po.train_step_torch(sd, x, y, dtype=torch.float32)   # the reference's own fp32 error
+    m = m.to(cuda_device)
+    logp, trans = m(x.to(cuda_device))
+    loss = F.nll_loss(logp, y.to(cuda_device))
+    loss.backward()
+    assert abs(loss.item() - loss_ref.item()) < 1e-3
+    np.testing.assert_allclose(logp.detach().cpu().numpy(), logp_ref.numpy(), atol=1e-3, rtol=0)
+    np.testing.assert_allclose(trans.detach().cpu().numpy(), trans_ref.numpy(), atol=1e-3, rtol=0)
+    worst = ("", 0.0)
+    for n, p in m.named_parameters():
+        ref = grads_ref[n]
+        if ref.double().norm().item() < 1e-9:
+            assert p.grad.abs().max().item() < 1e-4, n
+            continue
+        r = _rel(p.grad.cpu(), ref)
+        r32 = _rel(grads32[n], ref)
+        if r > worst[1]:
+            worst = (n, r)
+        # fp32 yardstick: not worse than 4x the reference's own ATen-fp32 error (+2e-3 floor)
+        assert r < 4 * r32 + REL, (n, r, r32)
+    cur = m.state_dict()
+    for n, v in stats_ref.items():
+        np.testing.assert_allclose(cur[n].cpu().numpy(), v.float().numpy(), atol=2e-5, rtol=2e-4, err_msg=n)
+
+
+def test_sgd_steps_track_oracle(cuda_device):
+    """Three Adam steps (main_1v.py:60,75-76: Adam lr 0.005) on the HIP path vs the oracle's
+    functional model under the same optimizer: losses stay together."""
+    B, N, k = 16, 128, 2
+    m = build_model(N, k, 91, 4600).train()
+    sd = state_dict_cpu(m)
+    x = synth_cloud(B, N, 1234, "box"); y = (torch.arange(B) % k).long()
+    # oracle side: parameters as leaf tensors
+    work = {n: v.clone().requires_grad_(v.is_floating_point() and "running_" not in n) for n, v in sd.items()}
+    opt_ref = torch.optim.Adam([v for v in work.values() if v.requires_grad], lr=0.005)
+    losses_ref = []
+    for _ in range(3):
+        opt_ref.zero_grad()
+        lp, _ = po.forward_torch(work, x, training=True)
+        l = F.nll_loss(lp, y); l.backward(); opt_ref.step(); losses_ref.append(l.item())
+    m = m.to(cuda_device)
+    opt = torch.optim.Adam(m.parameters(), lr=0.005)
+    xg, yg = x.to(cuda_device), y.to(cuda_device)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        lp, _ = m(xg)
+        l = F.nll_loss(lp, yg); l.backward(); opt.step(); losses.append(l.item())
+    np.testing.assert_allclose(losses, losses_ref, atol=5e-3)
+    # eval after training uses the updated running stats through the (re-folded) inference path
+    m.eval()
+    with torch.no_grad():
+        lp_e, _ = m(xg)
+        lp_ref, _ = po.forward_torch({n: v.detach() for n, v in work.items()}, x, training=False)
+    np.testing.assert_allclose(lp_e.cpu().numpy(), lp_ref.numpy(), atol=2e-2)
+
+
+def test_train_batch_of_one_raises(cuda_device):
+    m = build_model(64, 2, 1, -1).train().to(cuda_device)
+    with pytest.raises(ValueError, match="more than 1 value"):
+        m(torch.zeros(1, 3, 64, device=cuda_device))
