@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--num-points", type=int, default=1024)
     ap.add_argument("--classes", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step leg")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -130,6 +131,49 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     assert torch.isfinite(out).all()
+
+    # ---- training step (main_1v.py:72-76): forward (batch-stat BN) + nll_loss + backward + Adam
+    train_res = None
+    if not args.no_train:
+        import torch.nn.functional as F
+        tmodel = build_model(N, k, dev).train()
+        opt = torch.optim.Adam(tmodel.parameters(), lr=0.005)
+        y = (torch.arange(B, device=dev) % k).long()
+        params = [p for p in tmodel.parameters()]
+        tsteps = max(3, args.steps // 4)
+
+        def train_step():
+            opt.zero_grad(set_to_none=True)
+            lp, _ = tmodel(x)
+            loss = F.nll_loss(lp, y)
+            loss.backward()
+            if dist is not None:   # data-parallel: average gradients over ranks (RCCL all-reduce)
+                flat = torch.cat([p.grad.reshape(-1) for p in params])
+                dist.all_reduce(flat)
+                flat.div_(world)
+                off = 0
+                for p in params:
+                    n = p.numel(); p.grad.copy_(flat[off:off + n].view_as(p.grad)); off += n
+            opt.step()
+            return loss
+
+        for _ in range(max(2, args.warmup // 4)):
+            train_step()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(tsteps):
+            loss = train_step()
+        sync_all()
+        tdt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([tdt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tdt = t.item()
+        assert torch.isfinite(loss).all()
+        train_res = {"value": round(world * B * tsteps / tdt, 1), "unit": "grasps/s", "steps": tsteps,
+                     "ms_per_step": round(tdt / tsteps * 1e3, 3),
+                     "step": "fwd(batch-stat BN)+nll_loss+bwd+Adam" + ("+RCCL grad all-reduce" if dist else ""),
+                     "tflops_effective_3x_fwd": round(world * B * tsteps / tdt * 3 * flops_per_grasp(N, k) / 1e12, 2)}
 
     # ---- dominant kernel (fused trunk) timed live with events on the launch stream
     from pointnetgpd_amd import ops
@@ -179,6 +223,8 @@ def main():
                          "avg_launch_ms": round(trunk_ms, 4),
                          "flops_per_launch": trunk_flops},
         }
+        if train_res is not None:
+            res["train"] = train_res
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(N, k)
         print(json.dumps(res), flush=True)
