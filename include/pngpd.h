@@ -170,6 +170,27 @@ int pngpd_bn1d_bwd(const float *dy, const float *z, const float *y, int B, int C
 /* backward of F.log_softmax (pointnet.py:194): dlogits = g - exp(logp) * rowsum(g) */
 int pngpd_log_softmax_bwd(const float *g, const float *logp, int B, int K, float *dlogits, void *stream);
 
+/* =======================================================================================
+ * Batched in-gripper crop + resample (upstream of the scorer).
+ * A grasp frame is 18 doubles: origin[3], M[9] (rows approach, binormal, minor), lo[3], hi[3];
+ * a cloud point p is kept iff lo < M (p - origin) < hi component-wise (strict, fp64) —
+ * dataset.py:53-69 (training box: origin = jaw centre, +-w/4, +-w/2, +-w/4) and
+ * kinect2grasp.py:186-229 (inference box: origin = hand bottom, (0,hand_depth), +-w/2, +-w/4).
+ * cloud: (P,3) row-major, fp64 if cloud_is_f64 else fp32 (promoted to fp64, kinect2grasp.py:188).
+ * ======================================================================================= */
+/* counts (G) = number of in-box points; idx (G,max_keep) = their point indices in ascending
+ * order (np.where order), truncated to max_keep.                                              */
+int pngpd_crop_count_compact(const void *cloud, int cloud_is_f64, int P, const double *frames, int G,
+                             int max_keep, int *counts, int *idx, void *stream);
+/* out (G,3,N) fp32 = N resampled in-box points per grasp in the hand frame (the `.T` layout of
+ * dataset.py:440-444); valid (G) = count >= min_points (dataset.py:71, kinect2grasp.py:462).
+ * mode 0: without replacement iff m > N (dataset.py:439); mode 1: iff m >= N (kinect2grasp.py:474),
+ * m = min(count, max_keep).  sel (G,N) int32 ranks in [0,m) injects the draw (else device RNG
+ * keyed by seed).  Invalid grasps are zero-filled.                                              */
+int pngpd_crop_resample(const void *cloud, int cloud_is_f64, const double *frames, int G, const int *counts,
+                        const int *idx, int max_keep, int N, int mode, int min_points,
+                        unsigned long long seed, const int *sel, float *out, unsigned char *valid, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

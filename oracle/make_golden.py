@@ -196,6 +196,30 @@ def crop_cases():
     print("crop counts", counts.tolist(), "none", is_none.tolist())
 
 
+def dataset_cases():
+    """What the reference's four Dataset classes return on the synthetic miniature tree of
+    tests/synth_dataset.py (indices, numpy seed and ctor kwargs recorded there)."""
+    import tempfile
+    from tests import synth_dataset
+    rec = {}
+    with tempfile.TemporaryDirectory() as root:
+        synth_dataset.build(root)
+        items = synth_dataset.replay(ref_dataset, root)
+    none_mask = []
+    for n, (name, i, item) in enumerate(items):
+        none_mask.append(item is None)
+        if item is None:
+            continue
+        rec[f"pc_{n}"] = np.asarray(item[0])
+        rec[f"label_{n}"] = int(item[1])
+        if len(item) > 2:
+            rec[f"obj_{n}"] = str(item[2])
+    rec["none_mask"] = np.array(none_mask)
+    rec["names"] = np.array([it[0] for it in items]); rec["indices"] = np.array([it[1] for it in items])
+    np.savez_compressed(os.path.join(OUT, "dataset_items.npz"), **rec)
+    print("dataset items", len(items), "none:", int(np.sum(none_mask)))
+
+
 if __name__ == "__main__":
     eval_case("n64_k2", 64, 2, 3, 11, 4321, 101, "box")
     eval_case("n750_k2", 750, 2, 2, 12, 4322, 102, "box")
@@ -206,3 +230,4 @@ if __name__ == "__main__":
     train_case("n200_k3", 200, 3, 16, 22, 4332, 202, "box")
     kat_cases()
     crop_cases()
+    dataset_cases()   # last: it re-points PointNetGPD_FOLDER at a temporary tree

@@ -45,6 +45,12 @@ SIGNATURES = {
     "pngpd_bn1d_bwd": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, c_f32p,
                                       ctypes.c_float, ctypes.c_int, c_f32p, c_f32p, c_f32p, c_void]),
     "pngpd_log_softmax_bwd": (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, c_f32p, c_void]),
+    # ---- crop / resample
+    "pngpd_crop_count_compact": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, ctypes.c_int,
+                                                ctypes.c_int, c_void, c_void, c_void]),
+    "pngpd_crop_resample": (ctypes.c_int, [c_void, ctypes.c_int, c_void, ctypes.c_int, c_void, c_void,
+                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_ulonglong, c_void, c_void, c_void, c_void]),
 }
 
 

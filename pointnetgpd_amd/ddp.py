@@ -1,0 +1,86 @@
+"""Data-parallel training helper: one process per GPU, gradients averaged with ONE flat all-reduce
+(RCCL over xGMI on MI355X — backend "nccl" is RCCL on ROCm; "gloo" for the CPU tests).
+
+Replaces the reference's single-process ``nn.DataParallel(model, device_ids=[0,1,2,3])``
+(PointNetGPD/main_1v.py:158-165, main_fullv.py:104-111):
+
+* DataParallel re-broadcasts the 6.4 MB of parameters on every forward and reduces gradients onto
+  device 0; here every rank owns a replica, parameters are broadcast once, and the 1,604,363
+  gradients travel as one 6.4 MB bucket (at 8 GPUs a ring all-reduce moves 2*(7/8)*6.4 MB per GPU —
+  tens of microseconds on 7x153 GB/s xGMI links, small against a ~15 ms step).
+* BatchNorm statistics stay per replica, exactly as under DataParallel; running
+  statistics of rank 0 are broadcast before each forward (``broadcast_buffers``), which is what
+  DataParallel's replica-0-wins behaviour amounts to.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradAverager:
+    def __init__(self, model, process_group=None, broadcast_buffers=True):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.model = model
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        self.broadcast_buffers = broadcast_buffers
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self._flat = None
+        self.sync_parameters()
+
+    def sync_parameters(self):
+        """Rank 0's parameters and buffers become everyone's (done once, and after a checkpoint load)."""
+        with torch.no_grad():
+            for t in list(self.model.parameters()) + list(self.model.buffers()):
+                dist.broadcast(t.data, src=0, group=self.group)
+
+    def sync_buffers(self):
+        if not self.broadcast_buffers:
+            return
+        with torch.no_grad():
+            for b in self.model.buffers():
+                dist.broadcast(b.data, src=0, group=self.group)
+
+    def average_gradients(self):
+        """All-reduce(sum)/world of every parameter gradient through one flat bucket."""
+        if self.world == 1:
+            return
+        grads = []
+        for p in self.params:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            grads.append(p.grad)
+        total = sum(g.numel() for g in grads)
+        if self._flat is None or self._flat.numel() != total or self._flat.device != grads[0].device:
+            self._flat = torch.empty(total, device=grads[0].device, dtype=grads[0].dtype)
+        off = 0
+        for g in grads:
+            n = g.numel()
+            self._flat[off:off + n].copy_(g.reshape(-1))
+            off += n
+        dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.group)
+        self._flat.div_(self.world)
+        off = 0
+        for g in grads:
+            n = g.numel()
+            g.copy_(self._flat[off:off + n].view_as(g))
+            off += n
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from torchrun's environment (RANK / WORLD_SIZE / LOCAL_RANK /
+    MASTER_*).  Returns (rank, world, local_rank); world == 1 -> nothing is initialised."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    return rank, world, local_rank

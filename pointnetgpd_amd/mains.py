@@ -1,0 +1,274 @@
+"""Train / eval loops of the PointNet variants, with the reference's CLI.
+
+One implementation behind four entry points that mirror the reference scripts
+(same flags, same hyper-parameters, same printed lines, same checkpoint naming):
+
+    main_1v.py       PointGraspOneViewDataset            N=750  k=2  good=bad=0.6   reference main_1v.py
+    main_1v_mc.py    PointGraspOneViewMultiClassDataset  N=750  k=3  good=0.5 bad=1.2   main_1v_mc.py
+    main_fullv.py    PointGraspDataset (50k pts, 20 views) N=1000 k=2  good=bad=0.6     main_fullv.py
+    main_fullv_mc.py PointGraspMultiClassDataset         N=1000 k=3  good=0.5 bad=1.2   main_fullv_mc.py
+
+Reference behaviour kept: Adam(lr 0.005) + StepLR(30, 0.5) with
+``scheduler.step()`` at the start of every epoch; ``main_1v`` re-creates optimizer and scheduler every
+epoch (main_1v.py:60-62) while the others keep one (main_fullv.py:112-116); ``F.nll_loss`` (mean) for
+training, summed for eval; whole-module pickles ``<model-path>/<tag>_<epoch>.model``.
+
+What changes: the reference's ``nn.DataParallel`` over ids [0,1,2,3] (``--gpu -1``) becomes one
+process per GPU under ``torchrun`` with an RCCL gradient all-reduce (``pointnetgpd_amd.ddp``);
+``torch.load`` passes ``weights_only=False`` (whole-module pickles fail otherwise on torch >= 2.6).
+Additive flags: ``--seed --num-workers --synthetic --max-batches --persistent-optimizer``.
+"""
+import argparse
+import json
+import os
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+import torch.optim as optim
+import torch.utils.data
+from torch.optim.lr_scheduler import StepLR
+
+from . import ddp
+from .model.pointnet import PointNetCls
+
+VARIANTS = {
+    "1v": dict(dataset="PointGraspOneViewDataset", fullview=False, k=2, num_points=750, good=0.6, bad=0.6,
+               recreate_optimizer=True),
+    "1v_mc": dict(dataset="PointGraspOneViewMultiClassDataset", fullview=False, k=3, num_points=750, good=0.5,
+                  bad=1.2, recreate_optimizer=False),
+    "fullv": dict(dataset="PointGraspDataset", fullview=True, k=2, num_points=1000, good=0.6, bad=0.6,
+                  recreate_optimizer=False),
+    "fullv_mc": dict(dataset="PointGraspMultiClassDataset", fullview=True, k=3, num_points=1000, good=0.5,
+                     bad=1.2, recreate_optimizer=False),
+}
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="pointnetGPD")
+    p.add_argument("--tag", type=str, default="default")
+    p.add_argument("--epoch", type=int, default=200)
+    p.add_argument("--mode", choices=["train", "test"], required=True)
+    p.add_argument("--batch-size", type=int, default=1)
+    p.add_argument("--cuda", action="store_true")
+    p.add_argument("--gpu", type=int, default=0)
+    p.add_argument("--lr", type=float, default=0.005)
+    p.add_argument("--load-model", type=str, default="")
+    p.add_argument("--load-epoch", type=int, default=-1)
+    p.add_argument("--model-path", type=str, default="./assets/learned_models", help="pre-trained model path")
+    p.add_argument("--log-interval", type=int, default=10)
+    p.add_argument("--save-interval", type=int, default=1)
+    # additive (defaults reproduce the reference)
+    p.add_argument("--seed", type=int, default=None, help="fix numpy/torch seeds (reference: time-based)")
+    p.add_argument("--num-workers", type=int, default=32)
+    p.add_argument("--synthetic", type=int, default=0, metavar="G",
+                   help="train/eval on G synthetic in-gripper clouds instead of the YCB files")
+    p.add_argument("--max-batches", type=int, default=0, help="stop every epoch after this many batches")
+    p.add_argument("--persistent-optimizer", action="store_true",
+                   help="main_1v only: keep one optimizer/scheduler (fixes main_1v.py:60-62)")
+    p.add_argument("--log-dir", type=str, default="./assets/log/")
+    return p
+
+
+class _ScalarLog:
+    """``logger.add_scalar`` sink: tensorboardX / torch.utils.tensorboard when importable, else JSONL."""
+
+    def __init__(self, path):
+        os.makedirs(path, exist_ok=True)
+        self.w = None
+        try:
+            from tensorboardX import SummaryWriter
+            self.w = SummaryWriter(path)
+        except Exception:
+            try:
+                from torch.utils.tensorboard import SummaryWriter
+                self.w = SummaryWriter(path)
+            except Exception:
+                self.f = open(os.path.join(path, "scalars.jsonl"), "a")
+
+    def add_scalar(self, name, value, step):
+        if self.w is not None:
+            self.w.add_scalar(name, value, step)
+        else:
+            self.f.write(json.dumps({"tag": name, "value": float(value), "step": int(step)}) + "\n")
+            self.f.flush()
+
+
+def worker_init_fn(pid):
+    np.random.seed(torch.initial_seed() % (2 ** 31 - 1))          # main_1v.py:44-45
+
+
+def my_collate(batch):
+    batch = list(filter(lambda x: x is not None, batch))            # main_1v.py:48-50
+    return torch.utils.data.dataloader.default_collate(batch)
+
+
+class SyntheticGraspDataset(torch.utils.data.Dataset):
+    """G random in-gripper clouds with the reference's item layout ((3,N) float64, label[, name]);
+    a deterministic stand-in for the YCB files, which are not redistributable."""
+
+    def __init__(self, amount, num_points, k, with_obj=False, seed=0):
+        self.amount, self.num_points, self.k, self.with_obj, self.seed = amount, num_points, k, with_obj, seed
+
+    def __len__(self):
+        return self.amount
+
+    def __getitem__(self, i):
+        rng = np.random.default_rng(self.seed * 1000003 + i)
+        label = int(rng.integers(0, self.k))
+        w = 0.085
+        pc = (rng.random((3, self.num_points)) - 0.5) * np.array([[w / 2], [w], [w / 2]])
+        pc[0] += 0.004 * label          # a learnable signal: class shifts the cloud along the approach axis
+        if self.with_obj:
+            return pc, label, f"synthetic_{i % 7}"
+        return pc, label
+
+
+def _make_loaders(cfg, args):
+    from .model import dataset as ds
+    common = dict(batch_size=args.batch_size, num_workers=args.num_workers, pin_memory=True, shuffle=True,
+                  worker_init_fn=worker_init_fn, collate_fn=my_collate)
+    if args.synthetic:
+        tr = SyntheticGraspDataset(args.synthetic, cfg["num_points"], cfg["k"], seed=1)
+        te = SyntheticGraspDataset(max(args.synthetic // 4, args.batch_size), cfg["num_points"], cfg["k"],
+                                   with_obj=True, seed=2)
+    else:
+        cls = getattr(ds, cfg["dataset"])
+        kw = dict(grasp_points_num=cfg["num_points"], thresh_good=cfg["good"], thresh_bad=cfg["bad"])
+        if cfg["fullview"]:
+            kw.update(obj_points_num=50000, pc_file_used_num=20)
+        tr = cls(tag="train", grasp_amount_per_file=6500, **kw)
+        te = cls(tag="test", grasp_amount_per_file=500, with_obj=True, **kw)
+    sampler = None
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        sampler = torch.utils.data.distributed.DistributedSampler(tr, shuffle=True)
+        common_tr = dict(common, shuffle=False, sampler=sampler)
+    else:
+        common_tr = common
+    return (torch.utils.data.DataLoader(tr, **common_tr), torch.utils.data.DataLoader(te, **common), sampler)
+
+
+def run(variant, argv=None):
+    cfg = VARIANTS[variant]
+    args = build_parser().parse_args(argv)
+    args.cuda = args.cuda if torch.cuda.is_available else False      # sic: main_1v.py:35 never calls it
+    os.makedirs(args.model_path, exist_ok=True)
+    rank, world, local_rank = ddp.init_from_env("nccl" if args.cuda else "gloo")
+    if args.cuda:
+        torch.cuda.manual_seed(1)
+    if args.seed is None:
+        np.random.seed(int(time.time()))
+    else:
+        np.random.seed(args.seed); torch.manual_seed(args.seed)
+    logger = _ScalarLog(os.path.join(args.log_dir, args.tag)) if rank == 0 else None
+    train_loader, test_loader, sampler = _make_loaders(cfg, args)
+
+    device = torch.device("cpu")
+    if args.cuda:
+        dev_index = local_rank if world > 1 else (args.gpu if args.gpu != -1 else 0)
+        torch.cuda.set_device(dev_index)
+        device = torch.device("cuda", dev_index)
+
+    is_resume = 1 if (args.load_model and args.load_epoch != -1) else 0
+    if is_resume or args.mode == "test":
+        from . import install_reference_aliases
+        install_reference_aliases()
+        model = torch.load(args.load_model, map_location=device, weights_only=False)
+        print("load model {}".format(args.load_model))
+    else:
+        model = PointNetCls(num_points=cfg["num_points"], input_chann=3, k=cfg["k"])
+    model = model.to(device)
+    averager = ddp.GradAverager(model) if world > 1 else None
+
+    state = {"optimizer": None, "scheduler": None}
+
+    def new_optimizer():
+        state["optimizer"] = optim.Adam(model.parameters(), lr=args.lr)
+        state["scheduler"] = StepLR(state["optimizer"], step_size=30, gamma=0.5)
+
+    recreate = cfg["recreate_optimizer"] and not args.persistent_optimizer
+    if not recreate:
+        new_optimizer()
+
+    def train(epoch):
+        if recreate:
+            new_optimizer()
+        optimizer, scheduler = state["optimizer"], state["scheduler"]
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            scheduler.step()                                           # legacy order, main_1v.py:62
+        model.train()
+        torch.set_grad_enabled(True)
+        if sampler is not None:
+            sampler.set_epoch(epoch)
+        correct, dataset_size = 0, 0
+        for batch_idx, (data, target) in enumerate(train_loader):
+            if args.max_batches and batch_idx >= args.max_batches:
+                break
+            dataset_size += data.shape[0]
+            data, target = data.float(), target.long().squeeze()
+            data, target = data.to(device), target.to(device)
+            if averager is not None:
+                averager.sync_buffers()
+            optimizer.zero_grad()
+            output, _ = model(data)
+            loss = F.nll_loss(output, target)
+            loss.backward()
+            if averager is not None:
+                averager.average_gradients()
+            optimizer.step()
+            pred = output.data.max(1, keepdim=True)[1]
+            correct += pred.eq(target.view_as(pred)).long().cpu().sum()
+            if batch_idx % args.log_interval == 0 and rank == 0:
+                percentage = 100. * batch_idx * args.batch_size / len(train_loader.dataset)
+                print(f"Train Epoch: {epoch} [{batch_idx * args.batch_size}/{len(train_loader.dataset)} "
+                      f"({percentage}%)]\tLoss: {loss.item()}\t{args.tag}")
+                logger.add_scalar("train_loss", loss.cpu().item(), batch_idx + epoch * len(train_loader))
+        return float(correct) / float(max(dataset_size, 1))
+
+    def test():
+        model.eval()
+        torch.set_grad_enabled(False)
+        test_loss, correct, dataset_size, res = 0, 0, 0, []
+        for batch_idx, (data, target, obj_name) in enumerate(test_loader):
+            if args.max_batches and batch_idx >= args.max_batches:
+                break
+            dataset_size += data.shape[0]
+            data, target = data.float().to(device), target.long().squeeze().to(device)
+            output, _ = model(data)
+            test_loss += F.nll_loss(output, target, reduction="sum").cpu().item()   # size_average=False
+            pred = output.data.max(1, keepdim=True)[1]
+            correct += pred.eq(target.view_as(pred)).long().cpu().sum()
+            for i, j, k in zip(obj_name, pred.data.cpu().numpy(), target.data.cpu().numpy()):
+                res.append((i, j[0], k))
+        test_loss /= len(test_loader.dataset)
+        torch.set_grad_enabled(True)
+        return float(correct) / float(max(dataset_size, 1)), test_loss
+
+    result = {}
+    if args.mode == "train":
+        for epoch in range(is_resume * args.load_epoch, args.epoch):
+            acc_train = train(epoch)
+            if rank == 0:
+                print("Train done, acc={}".format(acc_train))
+            acc, loss = test()
+            if rank == 0:
+                print("Test done, acc={}, loss={}".format(acc, loss))
+                logger.add_scalar("train_acc", acc_train, epoch)
+                logger.add_scalar("test_acc", acc, epoch)
+                logger.add_scalar("test_loss", loss, epoch)
+                if epoch % args.save_interval == 0:
+                    path = os.path.join(args.model_path, args.tag + "_{}.model".format(epoch))
+                    torch.save(model, path)
+                    print("Save model @ {}".format(path))
+            result = dict(train_acc=acc_train, test_acc=acc, test_loss=loss, epoch=epoch)
+    else:
+        print("testing...")
+        acc, loss = test()
+        print("Test done, acc={}, loss={}".format(acc, loss))
+        result = dict(test_acc=acc, test_loss=loss)
+    if world > 1:
+        torch.distributed.barrier()
+    return result

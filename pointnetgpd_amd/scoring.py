@@ -1,0 +1,96 @@
+"""Batched grasp scoring: crop -> resample -> PointNet -> vote -> threshold -> sort, one pass per
+scene instead of the reference's per-grasp B=1 Python loop.
+
+Reference semantics reproduced (paths relative to the reference root):
+
+* ``test_network(model, local_pc)``           PointNetGPD/main_test.py:59-69
+* the scoring loop of ``kinect2grasp.py``      dex-net/apps/kinect2grasp.py:443-514
+  - grasps with fewer than ``minimal_points_send_to_point_net`` (20) in-box points are bad (:462-468)
+  - ``repeat`` resamplings per grasp, majority vote over the predicted class (:471-483)
+  - score = mean probability of the *best* class over the votes that agree with the majority (:488)
+  - good grasp iff vote == best class (1 for 2-class, 2 for 3-class models) (:484-494)
+  - good grasps sorted by score, descending (:507-514)
+"""
+import numpy as np
+import torch
+
+from . import crop
+
+
+def test_network(model_, local_pc, device=None):
+    """Drop-in for main_test.py:59-69: (N,3) numpy in-gripper cloud -> (pred (1,), probs ndarray (1,k)).
+    softmax(log_softmax(z)) == softmax(z), as in the reference."""
+    p = next(model_.parameters())
+    device = device or p.device
+    pc = torch.as_tensor(np.ascontiguousarray(np.asarray(local_pc).T[np.newaxis, ...]), dtype=torch.float32)
+    pc = pc.to(device)
+    with torch.no_grad():
+        output, _ = model_(pc)
+        output = output.softmax(1)
+        pred = output.max(1, keepdim=True)[1]
+    return pred[0], output.cpu().numpy()
+
+
+class GraspScorer:
+    """Scores G candidate grasps of one scene cloud on one GPU.
+
+    grasps: (G,5,3) rows [bottom_center, approach, binormal, minor, bottom_modified] as produced by
+    ``GpgGraspSamplerPcl.sample_grasps`` (grasp_sampler.py:1616-1618)."""
+
+    def __init__(self, model, num_points, gripper=crop.ROBOTIQ_85, repeat=1, batch=4096,
+                 min_points=crop.MIN_POINTS_TO_NET, max_keep=4096, seed=0):
+        self.model = model.eval()
+        self.num_points = int(num_points)
+        self.gripper = gripper
+        self.repeat = int(repeat)
+        self.batch = int(batch)
+        self.min_points = int(min_points)
+        self.max_keep = int(max_keep)
+        self.seed = int(seed)
+        k = model.fc3.out_features
+        self.best_class = 2 if k == 3 else 1          # kinect2grasp.py:484-487
+
+    @torch.no_grad()
+    def score(self, scene_cloud, grasps):
+        """-> dict(pred (G,) int64 voted class, score (G,) fp32, counts (G,) int32, valid (G,) bool,
+        good (G,) bool, order: indices of the good grasps sorted by score descending)."""
+        dev = next(self.model.parameters()).device
+        cloud = torch.as_tensor(scene_cloud).to(dev)
+        if cloud.dtype not in (torch.float32, torch.float64):
+            cloud = cloud.float()
+        frames = torch.from_numpy(crop.frames_from_grasps_infer(grasps, self.gripper)).to(dev)
+        G = frames.shape[0]
+        k = self.model.fc3.out_features
+        counts, idx = crop.crop_count_compact(cloud, frames, self.max_keep)
+        probs = torch.zeros(self.repeat, G, k, device=dev)
+        valid = None
+        for rep in range(self.repeat):
+            for s in range(0, G, self.batch):
+                e = min(G, s + self.batch)
+                pts, v = crop.crop_resample(cloud, frames[s:e], counts[s:e], idx[s:e], self.num_points,
+                                            crop.MODE_INFER, self.min_points,
+                                            seed=self.seed + 1000003 * rep + s)
+                logp, _ = self.model(pts)
+                probs[rep, s:e] = logp.softmax(1)
+                if rep == 0:
+                    valid = v if valid is None else torch.cat([valid, v])
+        votes = probs.argmax(2)                                     # (repeat, G)
+        onehot = torch.nn.functional.one_hot(votes, k).sum(0)       # (G, k) vote histogram
+        pred = onehot.argmax(1)                                     # scipy.stats.mode: smallest label on ties
+        agree = (votes == pred.unsqueeze(0)).float()                # (repeat, G)
+        best = probs[:, :, self.best_class]
+        score = (best * agree).sum(0) / agree.sum(0).clamp_min(1)
+        pred = torch.where(valid, pred, torch.zeros_like(pred))     # too few points -> class 0 (:466)
+        score = torch.where(valid, score, torch.zeros_like(score))  # and score 0.0 (:467)
+        good = valid & (pred == self.best_class)
+        gi = torch.nonzero(good).squeeze(1)
+        order = gi[torch.argsort(score[gi], descending=True, stable=True)]
+        return dict(pred=pred, score=score, counts=counts, valid=valid, good=good, order=order, probs=probs)
+
+
+def shard_grasps(num_grasps, rank, world):
+    """Contiguous candidate slice of rank ``rank`` (BASELINE config 5: candidates batched across
+    GPUs, scene cloud replicated, no collective in the scoring path)."""
+    per = (num_grasps + world - 1) // world
+    s = min(num_grasps, rank * per)
+    return s, min(num_grasps, s + per)

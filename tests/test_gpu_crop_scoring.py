@@ -1,0 +1,163 @@
+"""GPU parity of the batched crop / resample kernels and the grasp-scoring service against the numpy
+oracle (bit-exact index sets, fp64 transforms rounded to fp32) and the reference's golden crop record."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import crop_oracle as co
+from oracle import pointnet_oracle as po
+from tests.helpers import GOLDEN, build_model, state_dict_cpu
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(G, P, seed):
+    """SURVEY.md §8d config-5 style scene: cloud U(-0.15,0.15)^2 x U(0,0.2), random grasp frames whose
+    bottom centre sits 5 cm behind a cloud point."""
+    rng = np.random.default_rng(seed)
+    pc = np.stack([rng.uniform(-0.15, 0.15, P), rng.uniform(-0.15, 0.15, P), rng.uniform(0, 0.2, P)], 1)
+    q = rng.normal(size=(G, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    w, x, y, z = q.T
+    R = np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], 1),
+                  np.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], 1),
+                  np.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], 1)], 1)
+    approach, binormal, minor = R[:, :, 0], R[:, :, 1], R[:, :, 2]
+    bottom = pc[rng.integers(0, P, G)] - 0.05 * approach
+    grasps = np.stack([bottom, approach, binormal, minor, bottom], 1)
+    return pc, grasps
+
+
+def test_crop_kernel_vs_reference_record(cuda_device):
+    """Training-style crop on the reference's recorded cases: counts and index sets exactly."""
+    from pointnetgpd_amd import crop
+    fx = np.load(os.path.join(GOLDEN, "crop_train.npz"))
+    for c in range(len(fx["grasps"])):
+        frames = crop.frames_from_grasps_train(fx["grasps"][c][None], fx["Ts"][c])
+        cloud = torch.from_numpy(fx["pcs"][c]).to(cuda_device)            # fp64 cloud, like the .npy files
+        counts, idx = crop.crop_count_compact(cloud, torch.from_numpy(frames).to(cuda_device), max_keep=1024)
+        n = int(counts[0])
+        assert n == int(fx["counts"][c])
+        np.testing.assert_array_equal(idx[0, :n].cpu().numpy(), fx[f"ind_{c}"])
+        # resample with an injected draw: out[:, j] == pts[sel[j]] rounded to fp32; None <-> invalid
+        N = 64
+        sel = torch.from_numpy(np.random.default_rng(c).integers(0, max(n, 1), size=(1, N)).astype(np.int32)).to(cuda_device)
+        out, valid = crop.crop_resample(cloud, torch.from_numpy(frames).to(cuda_device), counts, idx, N,
+                                        crop.MODE_TRAIN, crop.MIN_POINT_LIMIT, sel=sel)
+        assert bool(valid[0]) == (not bool(fx["is_none"][c]))
+        if valid[0]:
+            ref = fx[f"pts_{c}"][sel[0].cpu().numpy()].T.astype(np.float32)
+            np.testing.assert_allclose(out[0].cpu().numpy(), ref, rtol=0, atol=1e-7)
+        else:
+            assert float(out.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_infer_crop_vs_oracle(dtype, cuda_device):
+    from pointnetgpd_amd import crop
+    pc, grasps = _scene(64, 20000, 7)
+    pc = pc.astype(np.float32 if dtype == torch.float32 else np.float64)
+    ind_ref, pts_ref = co.collect_pc_infer(grasps, pc)
+    frames = torch.from_numpy(crop.frames_from_grasps_infer(grasps)).to(cuda_device)
+    cloud = torch.from_numpy(pc).to(cuda_device)
+    counts, idx = crop.crop_count_compact(cloud, frames, max_keep=2048)
+    assert counts.max().item() <= 2048
+    for g in range(len(grasps)):
+        n = int(counts[g])
+        assert n == len(ind_ref[g])
+        np.testing.assert_array_equal(idx[g, :n].cpu().numpy(), ind_ref[g])
+    # device RNG resampling: every output column is one of the grasp's in-box points (fp32-rounded);
+    # without replacement (m >= N) -> all distinct point indices
+    N = 32
+    out, valid = crop.crop_resample(cloud, frames, counts, idx, N, crop.MODE_INFER, crop.MIN_POINTS_TO_NET, seed=11)
+    out2, _ = crop.crop_resample(cloud, frames, counts, idx, N, crop.MODE_INFER, crop.MIN_POINTS_TO_NET, seed=11)
+    assert torch.equal(out, out2)                                   # reproducible per seed
+    out3, _ = crop.crop_resample(cloud, frames, counts, idx, N, crop.MODE_INFER, crop.MIN_POINTS_TO_NET, seed=12)
+    assert not torch.equal(out, out3)
+    for g in range(len(grasps)):
+        m = len(ind_ref[g])
+        assert bool(valid[g]) == (m >= crop.MIN_POINTS_TO_NET)
+        if not valid[g]:
+            continue
+        ref32 = pts_ref[g].astype(np.float32)
+        cols = out[g].cpu().numpy().T                                # (N,3)
+        match = [np.where((ref32 == c).all(1))[0] for c in cols]
+        assert all(len(mm) >= 1 for mm in match)
+        if m >= N:
+            assert len({int(mm[0]) for mm in match}) == N
+
+
+def test_max_keep_truncation(cuda_device):
+    from pointnetgpd_amd import crop
+    pc, grasps = _scene(4, 60000, 9)
+    frames = torch.from_numpy(crop.frames_from_grasps_infer(grasps)).to(cuda_device)
+    cloud = torch.from_numpy(pc.astype(np.float32)).to(cuda_device)
+    counts, idx = crop.crop_count_compact(cloud, frames, max_keep=16)
+    ind_ref, _ = co.collect_pc_infer(grasps, pc.astype(np.float32))
+    for g in range(4):
+        assert int(counts[g]) == len(ind_ref[g])                    # count is the true count
+        np.testing.assert_array_equal(idx[g, :min(16, len(ind_ref[g]))].cpu().numpy(), ind_ref[g][:16])
+
+
+def test_scorer_end_to_end(cuda_device):
+    """GraspScorer == the reference's per-grasp loop semantics, evaluated by the oracle on the very points
+    the crop kernel produced (kinect2grasp.py:454-497 with repeat=1)."""
+    from pointnetgpd_amd import crop
+    from pointnetgpd_amd.scoring import GraspScorer, test_network
+    N, k = 64, 3
+    m = build_model(N, k, 33, 4700).eval()
+    sd = state_dict_cpu(m)
+    pc, grasps = _scene(40, 30000, 21)
+    pc32 = pc.astype(np.float32)
+    mg = m.to(cuda_device)
+    scorer = GraspScorer(mg, num_points=N, repeat=1, batch=16, seed=5)
+    res = scorer.score(pc32, grasps)
+    ind_ref, _ = co.collect_pc_infer(grasps, pc32)
+    counts_ref = np.array([len(i) for i in ind_ref])
+    np.testing.assert_array_equal(res["counts"].cpu().numpy(), counts_ref)
+    np.testing.assert_array_equal(res["valid"].cpu().numpy(), counts_ref >= 20)
+    # re-run the resample with the scorer's seeds to get the exact clouds it scored
+    frames = torch.from_numpy(crop.frames_from_grasps_infer(grasps)).to(cuda_device)
+    cloud = torch.from_numpy(pc32).to(cuda_device)
+    counts, idx = crop.crop_count_compact(cloud, frames, 4096)
+    probs = res["probs"][0].cpu().numpy()
+    for s in range(0, 40, 16):
+        e = min(40, s + 16)
+        pts, v = crop.crop_resample(cloud, frames[s:e], counts[s:e], idx[s:e], N, crop.MODE_INFER, 20, seed=5 + s)
+        with torch.no_grad():
+            lp_ref, _ = po.forward_torch(sd, pts.cpu())
+        np.testing.assert_allclose(probs[s:e], lp_ref.softmax(1).numpy(), atol=1e-3)
+    pred = res["pred"].cpu().numpy(); score = res["score"].cpu().numpy(); valid = res["valid"].cpu().numpy()
+    assert (pred[~valid] == 0).all() and (score[~valid] == 0).all()
+    np.testing.assert_array_equal(pred[valid], probs[valid].argmax(1))
+    np.testing.assert_allclose(score[valid], probs[valid][:, 2], atol=1e-6)      # best class of a 3-class model
+    good = res["good"].cpu().numpy()
+    np.testing.assert_array_equal(good, valid & (pred == 2))
+    order = res["order"].cpu().numpy()
+    assert set(order.tolist()) == set(np.nonzero(good)[0].tolist())
+    assert (np.diff(score[order]) <= 1e-7).all()
+    # test_network (main_test.py:59-69) on one cloud agrees with the batched path
+    g0 = int(np.nonzero(valid)[0][0])
+    s0 = (g0 // 16) * 16
+    pts, _ = crop.crop_resample(cloud, frames[s0:s0 + 16], counts[s0:s0 + 16], idx[s0:s0 + 16], N,
+                                crop.MODE_INFER, 20, seed=5 + s0)
+    p1, pr1 = test_network(mg, pts[g0 - s0].cpu().numpy().T)
+    assert int(p1) == int(pred[g0])
+    np.testing.assert_allclose(pr1[0], probs[g0], atol=1e-5)
+
+
+def test_scorer_vote_repeat(cuda_device):
+    from pointnetgpd_amd.scoring import GraspScorer
+    m = build_model(32, 2, 34, 4701).eval().to(cuda_device)
+    pc, grasps = _scene(24, 30000, 22)
+    res = GraspScorer(m, num_points=32, repeat=5, batch=8, seed=1).score(pc.astype(np.float32), grasps)
+    probs = res["probs"].cpu().numpy()                               # (5, G, 2)
+    votes = probs.argmax(2)
+    valid = res["valid"].cpu().numpy()
+    for g in np.nonzero(valid)[0]:
+        vals, cnts = np.unique(votes[:, g], return_counts=True)
+        maj = vals[np.argmax(cnts)]                                  # scipy.stats.mode: smallest of the most frequent
+        assert int(res["pred"][g]) == int(maj)
+        agree = votes[:, g] == maj
+        np.testing.assert_allclose(float(res["score"][g]), probs[agree, g, 1].mean(), atol=1e-6)

@@ -1,0 +1,129 @@
+"""CPU: the train/eval CLI end to end (BASELINE config 1 plumbing: CPU tensors -> ATen composite),
+whole-module checkpoints, and the data-parallel gradient averaging over gloo with world_size 2."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cli_train_then_test_cpu(tmp_path):
+    from pointnetgpd_amd import mains
+    common = ["--batch-size", "16", "--num-workers", "0", "--synthetic", "64", "--max-batches", "2",
+              "--model-path", str(tmp_path / "models"), "--log-dir", str(tmp_path / "log"), "--seed", "3",
+              "--tag", "t"]
+    r = mains.run("1v", ["--mode", "train", "--epoch", "1"] + common)
+    assert 0.0 <= r["train_acc"] <= 1.0 and np.isfinite(r["test_loss"])
+    ckpt = tmp_path / "models" / "t_0.model"
+    assert ckpt.exists()
+    # eval from the whole-module pickle (main_1v.py:152-155, weights_only=False)
+    r2 = mains.run("1v", ["--mode", "test", "--load-model", str(ckpt)] + common)
+    assert np.isfinite(r2["test_loss"])
+    # the pickled module is OUR class and round-trips its state_dict keys (44 params + 30 buffers)
+    m = torch.load(ckpt, weights_only=False)
+    assert type(m).__module__ == "pointnetgpd_amd.model.pointnet"
+    assert len(list(m.named_parameters())) == 44
+    assert len([k for k in m.state_dict() if "running_" in k or "num_batches" in k]) == 30
+
+
+@pytest.mark.parametrize("variant,k,n", [("1v_mc", 3, 750), ("fullv", 2, 1000), ("fullv_mc", 3, 1000)])
+def test_cli_variants_cpu(variant, k, n, tmp_path):
+    from pointnetgpd_amd import mains
+    assert mains.VARIANTS[variant]["k"] == k and mains.VARIANTS[variant]["num_points"] == n
+    r = mains.run(variant, ["--mode", "train", "--epoch", "1", "--batch-size", "8", "--num-workers", "0",
+                            "--synthetic", "16", "--max-batches", "1", "--model-path", str(tmp_path / "m"),
+                            "--log-dir", str(tmp_path / "l"), "--seed", "1"])
+    assert np.isfinite(r["test_loss"])
+
+
+def test_reference_flag_surface():
+    """Every flag of the reference parser (main_1v.py:18-33) exists with the same default."""
+    from pointnetgpd_amd import mains
+    p = mains.build_parser()
+    d = vars(p.parse_args(["--mode", "train"]))
+    ref = dict(tag="default", epoch=200, batch_size=1, cuda=False, gpu=0, lr=0.005, load_model="", load_epoch=-1,
+               model_path="./assets/learned_models", log_interval=10, save_interval=1)
+    for k_, v in ref.items():
+        assert d[k_] == v, k_
+
+
+def test_reference_pickle_alias_roundtrip(tmp_path):
+    """A module pickled under the reference's module path ``model.pointnet`` loads onto the mirror."""
+    import pointnetgpd_amd
+    from pointnetgpd_amd.model import pointnet as pn
+    pointnetgpd_amd.install_reference_aliases()
+    import importlib
+    import pickle
+    ref_mod = importlib.import_module("model.pointnet")
+    assert ref_mod.PointNetCls is pn.PointNetCls
+    assert importlib.import_module("model.dataset").PointGraspOneViewDataset is not None
+    # a pickle that names the class by the reference's path resolves to the mirror
+    blob = pickle.dumps(("model.pointnet", "PointNetCls"))
+    mod_name, cls_name = pickle.loads(blob)
+    cls = getattr(importlib.import_module(mod_name), cls_name)
+    m = cls(64, 3, 2)
+    assert isinstance(m, pn.PointNetCls)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _ddp_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    import torch.nn.functional as F
+    from pointnetgpd_amd import ddp
+    from pointnetgpd_amd.model.pointnet import PointNetCls
+    r, w, _ = ddp.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(100 + rank)                 # different initial weights per rank on purpose
+    m = PointNetCls(64, 3, 2).train()
+    avg = ddp.GradAverager(m)                     # -> rank 0's weights everywhere
+    g = torch.Generator().manual_seed(5)
+    x_all = torch.randn(8, 3, 64, generator=g); y_all = torch.arange(8) % 2
+    xs, ys = x_all[rank * 4:(rank + 1) * 4], y_all[rank * 4:(rank + 1) * 4]
+    with torch.no_grad():
+        m.feat.bn1.running_mean.add_(rank)        # rank-local drift that sync_buffers must undo
+    avg.sync_buffers()
+    logp, _ = m(xs)
+    F.nll_loss(logp, ys).backward()
+    local = {n: p.grad.clone() for n, p in m.named_parameters()}
+    avg.average_gradients()
+    torch.save(dict(local=local, avg={n: p.grad.clone() for n, p in m.named_parameters()},
+                    w0=m.fc3.weight.detach().clone(), rm=m.feat.bn1.running_mean.clone()),
+               os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_averager_gloo_world2(tmp_path):
+    world, port = 2, _free_port()
+    mp.start_processes(_ddp_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    r0 = torch.load(tmp_path / "r0.pt"); r1 = torch.load(tmp_path / "r1.pt")
+    assert torch.equal(r0["w0"], r1["w0"])                       # parameters were broadcast from rank 0
+    for n in r0["local"]:
+        mean = (r0["local"][n] + r1["local"][n]) / 2
+        assert torch.allclose(r0["avg"][n], mean, atol=1e-7), n  # all-reduce(sum)/world
+        assert torch.equal(r0["avg"][n], r1["avg"][n]), n        # identical on both ranks
+    # per-rank BN statistics differ (as under nn.DataParallel) -> local grads differ
+    assert not torch.allclose(r0["local"]["fc1.weight"], r1["local"]["fc1.weight"])
+    # running stats: rank 1's drift was overwritten by rank 0's buffers before the forward, then each
+    # rank applied its own batch statistics
+    assert abs(r1["rm"].mean().item() - r0["rm"].mean().item()) < 0.5
+
+
+def test_shard_grasps():
+    from pointnetgpd_amd.scoring import shard_grasps
+    spans = [shard_grasps(100000, r, 8) for r in range(8)]
+    assert spans[0][0] == 0 and spans[-1][1] == 100000
+    assert all(spans[i][1] == spans[i + 1][0] for i in range(7))
+    assert sum(e - s for s, e in spans) == 100000
+    assert shard_grasps(5, 7, 8) == (5, 5)
