@@ -82,7 +82,9 @@ def test_infer_crop_vs_oracle(dtype, cuda_device):
             continue
         ref32 = pts_ref[g].astype(np.float32)
         cols = out[g].cpu().numpy().T                                # (N,3)
-        match = [np.where((ref32 == c).all(1))[0] for c in cols]
+        # index sets are exact; coordinates agree with numpy's BLAS product to 1 fp32 ulp (the 3-term dot
+        # products are summed in a different order there): 1e-8 absolute at |y| <= 0.125
+        match = [np.where(np.abs(ref32 - c).max(1) <= 1e-8)[0] for c in cols]
         assert all(len(mm) >= 1 for mm in match)
         if m >= N:
             assert len({int(mm[0]) for mm in match}) == N
