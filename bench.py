@@ -108,6 +108,9 @@ def main():
     torch.cuda.set_device(dev)
 
     B, N, k = args.batch, args.num_points, args.classes
+    if os.environ.get("PNGPD_TRUNK_BLOCKS"):      # tuning experiments only
+        from pointnetgpd_amd import ops as _ops
+        _ops.set_option("trunk_target_blocks", int(os.environ["PNGPD_TRUNK_BLOCKS"]))
     model = build_model(N, k, dev)
     x = synth_clouds(B, N, 1234 + rank, dev)
 

@@ -112,6 +112,33 @@ __device__ __forceinline__ void k128_mfma(const float *tile, const float *__rest
     }
 }
 
+// The same product split in two so the caller can software-pipeline the weight fragments:
+// load_wfrag() issues the 16 coalesced 1-KiB fragment loads of channel block cb, k128_compute()
+// consumes a fragment set that is already (being) loaded.
+__device__ __forceinline__ void load_wfrag(f32x4 (&wf)[16], const float *__restrict__ wp128, int cb, const Lane &L) {
+    const f32x4 *wp = (const f32x4 *)wp128 + (size_t)(cb * 16) * 64 + L.lane;
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) wf[kb] = wp[kb * 64];
+}
+
+__device__ __forceinline__ void k128_compute(const float *tile, const f32x4 (&wf)[16], const Lane &L,
+                                             f32x16 &acc0, f32x16 &acc1) {
+    const float *a0p = tile + L.j * H2S + L.h * 4;
+    const float *a1p = tile + (32 + L.j) * H2S + L.h * 4;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) {
+        f32x4 a0 = *(const f32x4 *)(a0p + kb * 8);
+        f32x4 a1 = *(const f32x4 *)(a1p + kb * 8);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            acc0 = mfma32(a0[t], wf[kb][t], acc0);
+            acc1 = mfma32(a1[t], wf[kb][t], acc1);
+        }
+    }
+}
+
 // Split of a cloud's T tiles over S workgroups.
 __device__ __forceinline__ void tile_range(int s, int S, int T, int &t0, int &t1) {
     t0 = (int)(((long)s * T) / S);

@@ -1,0 +1,249 @@
+// libpngpd — inference trunk: fused per-point MLP 3->64->128->1024 + global max-pool.
+// Hand-written for gfx950 (MI355X): 64-wide waves, v_mfma_f32_32x32x2_f32 (exact fp32),
+// activations staged in LDS, the (B,1024,N) layer-3 activation never touches HBM.
+//
+// Reference call sites replaced (eval mode, BatchNorm folded by pngpd_fold_conv_bn):
+//   PointNetGPD/model/pointnet.py:29-33   STN3d trunk + MaxPool1d          (relu_last = 1)
+//   PointNetGPD/model/pointnet.py:140-149 PointNetfeat bmm + trunk + pool  (relu_last = 0, trans)
+//
+// One workgroup (4 waves) owns cloud b and a contiguous range of 64-point tiles.  Per tile:
+//   [xs <- x (x' = x^T T)] | layer 1 VALU -> h1 (LDS) | layer 2 MFMA -> h2 (LDS) |
+//   layer 3 MFMA; the max over the tile's points is an in-register reduction (a lane's 16 accumulator
+//   registers are 16 points of ONE channel); the per-channel running max over tiles lives in LDS.
+// Bias (+ReLU) of layer 3 commute with the max and are applied once at the end.
+#include "pngpd_tile.h"
+
+// LDS tiles of this kernel are UNPADDED and XOR-swizzled at float4 granularity instead of using the
+// +4-float row pad of pngpd_tile.h: element (row, col) lives at row*W + (((col>>2) ^ (row&15))<<2) + (col&3).
+// A wave's ds_read_b128 A-fragment read (lane i -> row i, one float4 column) then hits 16 distinct 16-B
+// slots per 16-lane group (conflict-free) and the footprint drops to 54,016 B -> 3 workgroups per CU.
+#define I1S 64
+#define I2S 128
+#define TRUNK_LDS_FLOATS (TP * I1S + TP * I2S + 3 * TP + 1024)
+
+__device__ __forceinline__ int swz(int row, int col, int width) {
+    return row * width + ((((col >> 2) ^ (row & 15)) << 2) | (col & 3));
+}
+
+// K-contraction of a swizzled [64][W] tile against register-resident MFMA_B fragments (NKB k-blocks).
+template <int W, int NKB>
+__device__ __forceinline__ void swz_compute(const float *tile, const f32x4 (&wf)[NKB], const Lane &L,
+                                            f32x16 &acc0, f32x16 &acc1) {
+    const float *r0 = tile + L.j * W, *r1 = tile + (32 + L.j) * W;
+    const int sx = L.j & 15;   // (32 + j) & 15 == j & 15
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        const int c4 = ((kb * 2 + L.h) ^ sx) << 2;
+        f32x4 a0 = *(const f32x4 *)(r0 + c4);
+        f32x4 a1 = *(const f32x4 *)(r1 + c4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            acc0 = mfma32(a0[t], wf[kb][t], acc0);
+            acc1 = mfma32(a1[t], wf[kb][t], acc1);
+        }
+    }
+}
+
+#ifndef TRUNK_PREFETCH
+#define TRUNK_PREFETCH 1
+#endif
+#ifndef TRUNK_WPS
+#define TRUNK_WPS 2
+#endif
+__global__ __launch_bounds__(256, TRUNK_WPS) void trunk_infer_kernel(
+    const float *__restrict__ x, int N, const float *__restrict__ trans,
+    const float *__restrict__ w1, const float *__restrict__ b1,
+    const float *__restrict__ w2p, const float *__restrict__ b2,
+    const float *__restrict__ w3p, const float *__restrict__ b3,
+    int relu_last, int T, int S, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *h1 = smem;              // [TP][I1S] swizzled
+    float *h2 = h1 + TP * I1S;     // [TP][I2S] swizzled
+    float *xs = h2 + TP * I2S;     // [3][TP]
+    float *rm = xs + 3 * TP;       // [1024] running max of the layer-3 pre-bias output
+    const Lane L;
+    const int b = blockIdx.x / S, s = blockIdx.x - b * S;
+    int t0, t1; tile_range(s, S, T, t0, t1);
+    const float *xb = x + (size_t)b * 3 * N;
+    float tm[9] = {0};
+    const bool has_t = trans != nullptr;
+    if (has_t) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) tm[i] = trans[(size_t)b * 9 + i];
+    }
+    for (int i = L.tid; i < 1024; i += 256) rm[i] = -INFINITY;
+    // layer-3 weight fragments are double-buffered in registers: while channel block ci is on the
+    // MFMA pipe the 16 KiB of block ci+1 are in flight from L2 (the last block of a tile prefetches the
+    // first block of the next tile, which also covers the tile prologue).
+    f32x4 wa[16];
+#if TRUNK_PREFETCH
+    f32x4 wb[16];
+    load_wfrag(wa, w3p, L.wave, L);
+#endif
+    // the tile's points are fetched one tile ahead (threads 0..63 hold one point each in registers)
+    float px0 = 0.f, px1 = 0.f, px2 = 0.f;
+    if (L.tid < TP) {
+        int n = t0 * TP + L.tid; n = n < N ? n : N - 1;   // tail: replicate the last point (max unaffected)
+        px0 = xb[n]; px1 = xb[N + n]; px2 = xb[2 * N + n];
+    }
+
+    for (int tile = t0; tile < t1; ++tile) {
+        if (L.tid < TP) {
+            float x0 = px0, x1 = px1, x2 = px2;
+            if (has_t) {   // x' = x^T @ trans (pointnet.py:140-143)
+                x0 = fmaf(px2, tm[6], fmaf(px1, tm[3], px0 * tm[0]));
+                x1 = fmaf(px2, tm[7], fmaf(px1, tm[4], px0 * tm[1]));
+                x2 = fmaf(px2, tm[8], fmaf(px1, tm[5], px0 * tm[2]));
+            }
+            xs[L.tid] = x0; xs[TP + L.tid] = x1; xs[2 * TP + L.tid] = x2;
+            if (tile + 1 < t1) {
+                int n = (tile + 1) * TP + L.tid; n = n < N ? n : N - 1;
+                px0 = xb[n]; px1 = xb[N + n]; px2 = xb[2 * N + n];
+            }
+        }
+        __syncthreads();
+        {   // layer 1 (3 -> 64), VALU: thread = (point p = lane, 16-channel group = wave)
+            const int p = L.lane;
+            const float x0 = xs[p], x1 = xs[TP + p], x2 = xs[2 * TP + p];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = L.wave * 16 + g * 4 + e;   // wave-uniform -> scalar loads
+                    v[e] = fmaxf(fmaf(w1[c * 3 + 2], x2, fmaf(w1[c * 3 + 1], x1, fmaf(w1[c * 3], x0, b1[c]))), 0.f);
+                }
+                *(f32x4 *)(h1 + swz(p, L.wave * 16 + g * 4, I1S)) = v;
+            }
+        }
+        __syncthreads();
+        {   // layer 2 (64 -> 128), MFMA: wave owns channel block cb = wave, both point blocks
+            f32x16 a0, a1;
+            const int cb = L.wave;
+            f32x4 w2f[8];
+            const f32x4 *wp = (const f32x4 *)w2p + (size_t)(cb * 8) * 64 + L.lane;
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) w2f[kb] = wp[kb * 64];
+            swz_compute<I1S, 8>(h1, w2f, L, a0, a1);
+            const float bias = b2[cb * 32 + L.j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mfma_row(r, L.lane);
+                h2[swz(row, cb * 32 + L.j, I2S)] = fmaxf(a0[r] + bias, 0.f);
+                h2[swz(32 + row, cb * 32 + L.j, I2S)] = fmaxf(a1[r] + bias, 0.f);
+            }
+        }
+        __syncthreads();
+#if !TRUNK_PREFETCH
+#pragma unroll 1
+        for (int ci = 0; ci < 8; ++ci) {
+            const int cb = L.wave + 4 * ci;
+            f32x16 a0, a1;
+            load_wfrag(wa, w3p, cb, L);
+            swz_compute<I2S, 16>(h2, wa, L, a0, a1);
+            float m = fmaxf(a0[0], a1[0]);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) m = fmaxf(m, fmaxf(a0[r], a1[r]));
+            m = fmaxf(m, __shfl_xor(m, 32));
+            if (L.h == 0) rm[cb * 32 + L.j] = fmaxf(rm[cb * 32 + L.j], m);
+        }
+#else
+#pragma unroll 1
+        for (int cp = 0; cp < 4; ++cp) {
+            const int cbA = L.wave + 8 * cp, cbB = cbA + 4, cbN = L.wave + ((8 * cp + 8) & 31);
+            f32x16 a0, a1;
+            load_wfrag(wb, w3p, cbB, L);
+            swz_compute<I2S, 16>(h2, wa, L, a0, a1);
+            float m = fmaxf(a0[0], a1[0]);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) m = fmaxf(m, fmaxf(a0[r], a1[r]));
+            m = fmaxf(m, __shfl_xor(m, 32));   // the other half-wave holds the tile's other rows
+            if (L.h == 0) rm[cbA * 32 + L.j] = fmaxf(rm[cbA * 32 + L.j], m);
+            load_wfrag(wa, w3p, cbN, L);
+            swz_compute<I2S, 16>(h2, wb, L, a0, a1);
+            m = fmaxf(a0[0], a1[0]);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) m = fmaxf(m, fmaxf(a0[r], a1[r]));
+            m = fmaxf(m, __shfl_xor(m, 32));
+            if (L.h == 0) rm[cbB * 32 + L.j] = fmaxf(rm[cbB * 32 + L.j], m);
+        }
+#endif
+        // no barrier here: the next tile's xs/h1 writes do not alias h2, and the barrier before its
+        // layer 2 orders the h2 rewrite after every wave's layer-3 reads.
+    }
+    if (L.h == 0) {   // each (wave, lane<32) reads back exactly the rm entries it wrote
+        float *o = out + ((size_t)b * S + s) * 1024;
+#pragma unroll
+        for (int ci = 0; ci < 8; ++ci) {
+            const int c = (L.wave + 4 * ci) * 32 + L.j;
+            float v = rm[c] + b3[c];
+            if (relu_last) v = fmaxf(v, 0.f);
+            o[c] = v;
+        }
+    }
+}
+
+__global__ void pool_reduce_kernel(const float *__restrict__ part, int S, float *__restrict__ out, int total) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over B*1024
+    if (idx >= total) return;
+    int b = idx >> 10, c = idx & 1023;
+    const float *p = part + (size_t)b * S * 1024 + c;
+    float m = p[0];
+    for (int s = 1; s < S; ++s) m = fmaxf(m, p[(size_t)s * 1024]);
+    out[idx] = m;
+}
+
+static int g_trunk_target_blocks = 2048;
+
+static int trunk_splits(int B, int T) {
+    int S = (g_trunk_target_blocks + B - 1) / B;
+    if (S < 1) S = 1;
+    if (S > T) S = T;
+    return S;
+}
+
+extern "C" {
+
+int pngpd_set_option(const char *name, int value) {
+    if (!name) return PNGPD_ERR_INVALID_ARG;
+    if (!strcmp(name, "trunk_target_blocks")) { g_trunk_target_blocks = value > 0 ? value : 1; return PNGPD_OK; }
+    return PNGPD_ERR_INVALID_ARG;
+}
+
+size_t pngpd_trunk_workspace_bytes(int B, int N) {
+    if (B <= 0 || N <= 0) return 0;
+    int T = (N + TP - 1) / TP;
+    // sized for the largest split count any option setting can choose (S <= T)
+    return (size_t)B * T * 1024 * sizeof(float);
+}
+
+int pngpd_trunk_fwd_infer(const float *x, int B, int N, const float *trans,
+                          const float *w1, const float *b1, const float *w2p, const float *b2,
+                          const float *w3p, const float *b3, int relu_last,
+                          float *out_pool, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!x || !w1 || !b1 || !w2p || !b2 || !w3p || !b3 || !out_pool || B <= 0 || N <= 0)
+        return PNGPD_ERR_INVALID_ARG;
+    const int T = (N + TP - 1) / TP;
+    const int S = trunk_splits(B, T);
+    float *dst = out_pool;
+    if (S > 1) {
+        if (!workspace || workspace_bytes < (size_t)B * S * 1024 * sizeof(float)) return PNGPD_ERR_WORKSPACE;
+        dst = (float *)workspace;
+    }
+    const size_t lds = TRUNK_LDS_FLOATS * sizeof(float);
+    hipLaunchKernelGGL(trunk_infer_kernel, dim3((unsigned)B * S), dim3(256), lds, (hipStream_t)stream,
+                       x, N, trans, w1, b1, w2p, b2, w3p, b3, relu_last, T, S, dst);
+    int st = pngpd_launch_status();
+    if (st != PNGPD_OK) return st;
+    if (S > 1) {
+        int total = B * 1024;
+        hipLaunchKernelGGL(pool_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                           (const float *)workspace, S, out_pool, total);
+        st = pngpd_launch_status();
+    }
+    return st;
+}
+
+}  // extern "C"
