@@ -127,6 +127,8 @@ __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
     int t0, t1; tile_range(s, S, T, t0, t1);
     const float *xb = x + (size_t)b * 3 * N;
     for (int i = L.tid; i < 1024; i += 256) { rm[i] = -INFINITY; ri[i] = 0; ss[i] = 0.f; sq[i] = 0.f; }
+    f32x4 wa[16], wb[16];
+    load_wfrag(wa, w3sp, L.wave, L);
     float tm[9] = {0};
     const bool has_t = trans != nullptr;
     if (has_t) {
@@ -153,11 +155,8 @@ __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
         __syncthreads();
         const int nbase = tile * TP;
         const bool full = nbase + TP <= N;
-#pragma unroll 1
-        for (int ci = 0; ci < 8; ++ci) {
-            const int cb = L.wave + 4 * ci;
-            f32x16 a0, a1;
-            k128_mfma(h2, w3sp, cb, L, a0, a1);
+        // layer-3 weight fragments double-buffered in registers (see trunk_infer_kernel)
+        auto reduce_block = [&](int cb, const f32x16 &a0, const f32x16 &a1) {
             // max / argmax over this lane's 32 rows (ascending row order, strict >: first wins)
             float m = a0[0]; int am = mfma_row(0, L.lane);
 #pragma unroll
@@ -185,6 +184,17 @@ __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
                 if (m > rm[c]) { rm[c] = m; int n = nbase + am; ri[c] = n < N ? n : N - 1; }
                 ss[c] += su; sq[c] += qu;
             }
+        };
+#pragma unroll 1
+        for (int cp = 0; cp < 4; ++cp) {
+            const int cbA = L.wave + 8 * cp, cbB = cbA + 4, cbN = L.wave + ((8 * cp + 8) & 31);
+            f32x16 a0, a1;
+            load_wfrag(wb, w3sp, cbB, L);
+            k128_compute(h2, wa, L, a0, a1);
+            reduce_block(cbA, a0, a1);
+            load_wfrag(wa, w3sp, cbN, L);
+            k128_compute(h2, wb, L, a0, a1);
+            reduce_block(cbB, a0, a1);
         }
     }
     if (L.h == 0) {
