@@ -47,3 +47,15 @@ def synth_cloud(b, n, seed, kind="box"):
 
 def state_dict_cpu(model):
     return {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+
+
+def grad_tol(batch, r32):
+    """Tolerance for a whole-model gradient vs the fp64 oracle.
+
+    The gradient is a discontinuous function of the inputs: one ReLU of the (B,512) / (B,256) FC
+    activations (or one arg-max of the pool) sitting within fp32 round-off of its threshold flips between
+    any two fp32 implementations and moves every upstream gradient by about 1/sqrt(#active units).  So the
+    bound is: 4x the deviation the reference's own ATen-fp32 run shows on this host (r32), a 2e-3 floor,
+    plus the size of ONE such flip.  Tight kernel-level checks (1e-4..2e-3, no flip ambiguity) live in
+    test_trunk_train_vs_prototype / test_trunk_backward_intermediates."""
+    return 4 * r32 + 2e-3 + 2.5 / (batch * 512) ** 0.5

@@ -11,7 +11,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import pointnet_oracle as po
-from tests.helpers import golden_files, build_model, assert_checksums, state_dict_cpu, synth_cloud
+from tests.helpers import golden_files, build_model, assert_checksums, state_dict_cpu, synth_cloud, grad_tol
 from tests.train_algo_prototype import trunk_fwd, trunk_bwd
 
 pytestmark = pytest.mark.gpu
@@ -147,7 +147,7 @@ def test_train_step_vs_oracle(B, N, k, cuda_device):
         if r > worst[1]:
             worst = (n, r)
         # fp32 yardstick: not worse than 4x the reference's own ATen-fp32 error (+2e-3 floor)
-        assert r < 4 * r32 + REL, (n, r, r32)
+        assert r < grad_tol(B, r32), (n, r, r32)
     cur = m.state_dict()
     for n, v in stats_ref.items():
         np.testing.assert_allclose(cur[n].cpu().numpy(), v.float().numpy(), atol=2e-5, rtol=2e-4, err_msg=n)
@@ -189,3 +189,45 @@ def test_train_batch_of_one_raises(cuda_device):
     m = build_model(64, 2, 1, -1).train().to(cuda_device)
     with pytest.raises(ValueError, match="more than 1 value"):
         m(torch.zeros(1, 3, 64, device=cuda_device))
+
+
+def test_trunk_backward_intermediates(cuda_device):
+    """Model-level scenario, kernel-level check: every accumulated quantity of the feat-trunk backward
+    (sums, second moments, gather, g2, closed-form dW, dT) vs the fp64 prototype fed with the SAME trans and
+    the SAME upstream gradient the HIP run produced — no flip ambiguity, so the bound is tight (2e-4)."""
+    from pointnetgpd_amd import train
+    B, N, k = 16, 750, 2
+    m = build_model(N, k, 96, 4516).train()
+    x = synth_cloud(B, N, 916, "box") * 4.0
+    y = (torch.arange(B) * 7 % k).long()
+    P = _trunk_params(m.feat)
+    mg = m.to(cuda_device)
+    caps = []
+    orig = train.TrunkTrainFn.backward
+
+    def wrapped(ctx, dp):
+        train.DEBUG_STASH = {}
+        out = orig(ctx, dp)
+        caps.append(dict(train.DEBUG_STASH))
+        train.DEBUG_STASH = None
+        return out
+
+    train.TrunkTrainFn.backward = staticmethod(wrapped)
+    try:
+        logp, trans = mg(x.to(cuda_device))
+        F.nll_loss(logp, y.to(cuda_device)).backward()
+    finally:
+        train.TrunkTrainFn.backward = orig
+    feat = caps[0]                                   # the feat trunk runs its backward first
+    T = trans.detach().double().cpu()
+    _, sv = trunk_fwd(x.double(), T, P, relu_last=False)
+    g = trunk_bwd(feat["dp"].cpu(), P, sv)
+    dbg = g["_dbg"]
+    assert (feat["idx"].cpu().long() != dbg["idx"]).double().mean().item() < 1e-3
+    for kx in ["dg3", "dbe3", "S2", "S1", "sh", "sh1", "G", "A", "cvec", "a1", "a2", "Pm", "c1", "c2", "Rb", "g2buf"]:
+        # a1/a2/c1/c2 are sums of signed per-point gradients that largely cancel (they vanish identically
+        # for an affine-free BN); their error is measured against their own small norm
+        tol = 5e-3 if kx in ("a1", "a2", "c1", "c2", "Rb") else 5e-4
+        assert _rel(feat[kx].cpu(), dbg[kx]) < tol, (kx, _rel(feat[kx].cpu(), dbg[kx]))
+    for kx, ky in [("dW1", "W1"), ("dW2", "W2"), ("dW3", "W3"), ("dT", "T")]:
+        assert _rel(feat[kx].cpu(), g[ky]) < 2e-4, (kx, _rel(feat[kx].cpu(), g[ky]))
