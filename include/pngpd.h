@@ -142,23 +142,24 @@ int pngpd_trunk_bwd_gather(const float *x, int B, int N, const float *trans,
                            const float *w2p, const float *s2c, const float *t2c,
                            const int *idx, const float *coef, int clouds_per_range, float *Gp, void *stream);
 
-/* backward pass D: g2buf (B,N,128) = dL/d(bn2 out);  pa (blk,128,2) = sum g2, sum g2*zhat2;
- *   pP (blk,128,64) = sum_points g2 h1^T.   zhat2 = z2*is2 + nm2;  Ap = MFMA_B(A), A (128,128)
+/* backward pass D: g2buf (B,N,128) = dL/d(bn2 out);  pa (blk,128,2) = sum g2, sum g2*zhat2.
+ *   zhat2 = z2*is2 + nm2;  Ap = MFMA_B(A), A (128,128)
  *   symmetric; dh2 = cvec - h2 A + sum_{c: idx[b][c]==n} coef[b][c] W3[c]; w3 (1024,128) raw.  */
 int pngpd_trunk_bwd_d(const float *x, int B, int N, const float *trans,
                       const float *w1, const float *b1, const float *s1c, const float *t1c,
                       const float *w2p, const float *s2c, const float *t2c,
                       const float *is2, const float *nm2, const float *Ap, const float *cvec,
                       const float *w3, const int *idx, const float *coef,
-                      float *g2buf, float *pa, float *pP, void *stream);
+                      float *g2buf, float *pa, void *stream);
 
 /* backward pass E: dz2 = dsc2*(g2 - a1m - zhat2*a2m); dh1 = W2^T dz2 (w2tp = MFMA_B(W2^T as (64,128)));
- *   g1 = dh1*(h1>0); pc (blk,64,2) = sum g1, sum g1*zhat1; pR (blk,64,3) = sum_points g1 x^T (original x) */
+ *   g1 = dh1*(h1>0); pc (blk,64,2) = sum g1, sum g1*zhat1; pR (blk,64,3) = sum_points g1 x^T (original x);
+ *   pW2 (blk,128,64) = sum_points dz2 h1^T — the workgroup's share of dL/dW2                          */
 int pngpd_trunk_bwd_e(const float *x, int B, int N, const float *trans,
                       const float *w1, const float *b1, const float *s1c, const float *t1c,
                       const float *w2p, const float *is1, const float *nm1, const float *is2, const float *nm2,
                       const float *a1m, const float *a2m, const float *dsc2, const float *w2tp,
-                      const float *g2buf, float *pc, float *pR, void *stream);
+                      const float *g2buf, float *pc, float *pR, float *pW2, void *stream);
 
 /* BatchNorm1d over the batch dimension for the FC stacks (pointnet.py:35-36,191-192, train mode),
  * optional fused ReLU; biased variance returned (the caller updates running stats). */
@@ -169,6 +170,43 @@ int pngpd_bn1d_bwd(const float *dy, const float *z, const float *y, int B, int C
                    float *dz, float *dgamma, float *dbeta, void *stream);
 /* backward of F.log_softmax (pointnet.py:194): dlogits = g - exp(logp) * rowsum(g) */
 int pngpd_log_softmax_bwd(const float *g, const float *logp, int B, int K, float *dlogits, void *stream);
+
+/* ---- finalize kernels: the parameter-sized fp64 algebra between the passes (pngpd_train_glue.hip) ----
+ * stats1 f64[140] = mx[3], Cx[9], mu1[64], var1[64];  stats2 f64[256] = mu2r[128], var2[128];
+ * stats3 f64[2048] = mu3s[1024], var3[1024] (of the sign-folded z3s);  chan1 f32 (4,64) = s1c,t1c,is1,nm1;
+ * chan2 f32 (4,128) = s2c,t2c,is2,nm2.  rm/rv/nbt: BatchNorm running_mean / running_var / num_batches_tracked
+ * (nullable), updated in place with `momentum` and the unbiased variance like nn.BatchNorm1d.            */
+int pngpd_bn1_finalize(const double *mom, const float *trans, int B, int N, const float *w1, const float *b1,
+                       const float *g1, const float *be1, float eps, float momentum, float *rm, float *rv,
+                       long long *nbt, float *chan1, double *stats1, void *stream);
+/* tot2 f64 (128,2) / tot3 f64 (2,1024): pngpd_reduce_partials of the pass-B / pass-C partial sums */
+int pngpd_bn2_finalize(const double *tot2, int B, int N, const float *b2, const float *g2,
+                       const float *be2, float eps, float momentum, float *rm, float *rv, long long *nbt,
+                       float *chan2, double *stats2, void *stream);
+int pngpd_bn3_finalize(const double *tot3, int B, int N, const float *b3, const float *g3,
+                       float momentum, float *rm, float *rv, long long *nbt, double *stats3, void *stream);
+/* pooled (B,1024) = [relu](g3*zhat + be3), idx (B,1024) arg-extremum point, zhat (B,1024) */
+int pngpd_pool_finalize(const float *pmax, const int *parg, int B, int S, const double *stats3, const float *g3,
+                        const float *be3, float eps, int relu_last, float *pooled, int *idx, float *zhat,
+                        void *stream);
+/* coef (B,1024) = masked dp * g3/sig3; dg3, dbe3 (1024); m12 f64[2048] = m1, m2 */
+int pngpd_bn3_bwd_prep(const float *dp, const float *pooled, const float *zhat, int B, int N, const float *g3,
+                       const double *stats3, float eps, int relu_last, float *coef, float *dg3, float *dbe3,
+                       double *m12, void *stream);
+/* out (outer,n) f64 = sum over r of in (outer,R,n) f32 — deterministic reduction of per-workgroup partials */
+int pngpd_reduce_partials(const float *in, int outer, int R, int n, double *out, void *stream);
+/* dW3 (1024,128); Ap = MFMA_B(A) (128x128), cvec (128): the operands of pngpd_trunk_bwd_d */
+int pngpd_dw3_finalize(const double *G, const double *S2, const double *sh, int B, int N, const float *w3,
+                       const float *g3, const double *stats3, const double *m12, float eps, float *dW3,
+                       float *Ap, float *cvec, void *stream);
+/* a12 f64 (128,2) = sum g2, sum g2*zhat2 -> dg2, dbe2 (128); evec (3,128) = a1/M, a2/M, g2/sig2: the
+ * operands of pngpd_trunk_bwd_e */
+int pngpd_bwd_e_prep(const double *a12, int B, int N, const float *g2, const double *stats2, float eps,
+                     float *dg2, float *dbe2, float *evec, void *stream);
+/* dW1 (64,3), dg1, dbe1 (64); dT (B,3,3) or NULL.  Rb f64 (B,64,3), c12 f64 (64,2) */
+int pngpd_dw1_finalize(const double *Rb, const float *trans, const double *mom, int B, int N, const double *c12,
+                       const double *stats1, const float *w1, const float *b1, const float *g1, float eps,
+                       float *dW1, float *dg1, float *dbe1, float *dT, void *stream);
 
 /* =======================================================================================
  * Batched in-gripper crop + resample (upstream of the scorer).

@@ -38,13 +38,31 @@ SIGNATURES = {
     "pngpd_trunk_h_moments": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 11 + [c_void]),
     "pngpd_trunk_bwd_gather": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 10 +
                                [ctypes.c_int, c_f32p, c_void]),
-    "pngpd_trunk_bwd_d": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 18 + [c_void]),
-    "pngpd_trunk_bwd_e": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 17 + [c_void]),
+    "pngpd_trunk_bwd_d": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 17 + [c_void]),
+    "pngpd_trunk_bwd_e": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 18 + [c_void]),
     "pngpd_bn1d_fwd_train": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, ctypes.c_float,
                                             ctypes.c_int, c_f32p, c_f32p, c_f32p, c_void]),
     "pngpd_bn1d_bwd": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, c_f32p,
                                       ctypes.c_float, ctypes.c_int, c_f32p, c_f32p, c_f32p, c_void]),
     "pngpd_log_softmax_bwd": (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, c_f32p, c_void]),
+    # ---- finalize kernels
+    "pngpd_bn1_finalize": (ctypes.c_int, [c_void, c_void, ctypes.c_int, ctypes.c_int] + [c_void] * 4 +
+                           [ctypes.c_float, ctypes.c_float] + [c_void] * 5 + [c_void]),
+    "pngpd_bn2_finalize": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int] + [c_void] * 3 +
+                           [ctypes.c_float, ctypes.c_float] + [c_void] * 5 + [c_void]),
+    "pngpd_bn3_finalize": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, c_void,
+                                          ctypes.c_float] + [c_void] * 4 + [c_void]),
+    "pngpd_pool_finalize": (ctypes.c_int, [c_void, c_void, ctypes.c_int, ctypes.c_int, c_void, c_void, c_void,
+                                           ctypes.c_float, ctypes.c_int, c_void, c_void, c_void, c_void]),
+    "pngpd_bn3_bwd_prep": (ctypes.c_int, [c_void, c_void, c_void, ctypes.c_int, ctypes.c_int, c_void, c_void,
+                                          ctypes.c_float, ctypes.c_int] + [c_void] * 4 + [c_void]),
+    "pngpd_reduce_partials": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void, c_void]),
+    "pngpd_dw3_finalize": (ctypes.c_int, [c_void, c_void, c_void, ctypes.c_int, ctypes.c_int] + [c_void] * 4 +
+                           [ctypes.c_float] + [c_void] * 3 + [c_void]),
+    "pngpd_bwd_e_prep": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, c_void, ctypes.c_float,
+                                        c_void, c_void, c_void, c_void]),
+    "pngpd_dw1_finalize": (ctypes.c_int, [c_void, c_void, c_void, ctypes.c_int, ctypes.c_int] + [c_void] * 5 +
+                           [ctypes.c_float] + [c_void] * 4 + [c_void]),
     # ---- crop / resample
     "pngpd_crop_count_compact": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, ctypes.c_int,
                                                 ctypes.c_int, c_void, c_void, c_void]),

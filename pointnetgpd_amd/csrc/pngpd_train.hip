@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_gather_kernel(
 
 // ---------------------------------------------------------------------------------------
 // backward pass D: g2 = dL/d(bn2 output) per point, written to HBM (B,N,128); accumulates
-//   pa [blk][128][2] = sum g2, sum g2*zhat2 ;  pP [blk][128][64] = sum_points g2 h1^T
+//   pa [blk][128][2] = sum g2, sum g2*zhat2
 //   dh2[point][k] = cvec[k] - (h2 Asym)[point][k] + sum_{c: idx[b][c]==point} coef[b][c] W3[c][k]
 // ---------------------------------------------------------------------------------------
 struct BwdDParams {
@@ -386,15 +386,17 @@ struct BwdDParams {
     const int *idx;             // (B,1024)
     const float *coef;          // (B,1024)
 };
-#define BWD_D_LDS_FLOATS (TP * H1S + 2 * TP * H2S + 3 * TP + 4 * 256 + 4)
+// LDS: h2 tile + one tile that is first h1 (dead after layer 2) and then the sparse term -> 72.5 KB,
+// two workgroups per CU.
+#define BWD_D_LDS_FLOATS (2 * TP * H2S + 3 * TP + 4 * 256 + 4)
 
-__global__ __launch_bounds__(256, 1) void trunk_bwd_d_kernel(
+__global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
     const float *__restrict__ x, int N, const float *__restrict__ trans, TrainChan P, BwdDParams D,
-    int T, int S, float *__restrict__ g2buf, float *__restrict__ pa, float *__restrict__ pP) {
+    int T, int S, float *__restrict__ g2buf, float *__restrict__ pa) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *h1 = smem;
-    float *h2 = h1 + TP * H1S;
-    float *sp = h2 + TP * H2S;            // sparse term, later the g2 tile
+    float *h2 = smem;
+    float *sp = h2 + TP * H2S;            // h1 during layers 1-2, then the sparse term
+    float *h1 = sp;
     float *xs = sp + TP * H2S;
     int *hits = (int *)(xs + 3 * TP);     // [4][256]  (c << 8) | local point
     int *hcnt = hits + 4 * 256;           // [4]
@@ -410,9 +412,6 @@ __global__ __launch_bounds__(256, 1) void trunk_bwd_d_kernel(
     }
     const int *idxb = D.idx + (size_t)b * 1024;
     const float *coefb = D.coef + (size_t)b * 1024;
-    f32x16 pp0, pp1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { pp0[r] = 0.f; pp1[r] = 0.f; }
     float a1s = 0.f, a2s = 0.f;
     const int cb = L.wave;
     const int c2 = cb * 32 + L.j;
@@ -420,7 +419,6 @@ __global__ __launch_bounds__(256, 1) void trunk_bwd_d_kernel(
     for (int tile = t0; tile < t1; ++tile) {
         const int nbase = tile * TP;
         stage_points(xb, N, tile, has_t, tm, xs, nullptr, L.tid);
-        for (int i = L.tid; i < TP * H2S; i += 256) sp[i] = 0.f;
         __syncthreads();
         layer1_tile(xs, P.w1, P.b1, P.s1c, P.t1c, h1, L);
         // ordered compaction of this tile's arg-extremum hits: wave w scans channels [256w, 256w+256)
@@ -455,6 +453,9 @@ __global__ __launch_bounds__(256, 1) void trunk_bwd_d_kernel(
                 a0[r] = fmaf(a0[r], sc2, sh2);   // keep the pre-activation sign for the ReLU mask
                 a1[r] = fmaf(a1[r], sc2, sh2);
             }
+            __syncthreads();   // every wave is done reading h1: its storage becomes the sparse tile
+            for (int i = L.tid; i < TP * H2S; i += 256) sp[i] = 0.f;
+            __syncthreads();
             // sparse term (deterministic order: waves' lists in order, ascending channel)
             {
                 const int k = L.tid & 127, half = L.tid >> 7;
@@ -480,23 +481,11 @@ __global__ __launch_bounds__(256, 1) void trunk_bwd_d_kernel(
                 g1 = (v1 && a1[r] > 0.f) ? g1 : 0.f;
                 a1s += g0 + g1;
                 a2s = fmaf(g0, zh0[r], fmaf(g1, zh1[r], a2s));
-                sp[row * H2S + c2] = g0;            // same element this lane just read
-                sp[(32 + row) * H2S + c2] = g1;
                 if (v0) g2buf[((size_t)b * N + nbase + row) * 128 + c2] = g0;
                 if (v1) g2buf[((size_t)b * N + nbase + 32 + row) * 128 + c2] = g1;
             }
         }
-        __syncthreads();
-        // P += g2^T h1 : rows o = cb*32 + i, columns c = {0,1}*32 + j, contraction over the 64 points
-#pragma unroll 4
-        for (int st = 0; st < 32; ++st) {
-            const int pt = 2 * st + L.h;
-            const float av = sp[pt * H2S + cb * 32 + L.j];
-            const float *hr = h1 + pt * H1S + L.j;
-            pp0 = mfma32(av, hr[0], pp0);
-            pp1 = mfma32(av, hr[32], pp1);
-        }
-        __syncthreads();
+        __syncthreads();   // the next tile's layer 1 rewrites h1 (= sp)
     }
     a1s += __shfl_xor(a1s, 32);
     a2s += __shfl_xor(a2s, 32);
@@ -504,18 +493,12 @@ __global__ __launch_bounds__(256, 1) void trunk_bwd_d_kernel(
         float *o = pa + ((size_t)blockIdx.x * 128 + c2) * 2;
         o[0] = a1s; o[1] = a2s;
     }
-    float *oP = pP + (size_t)blockIdx.x * 128 * 64;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int o = cb * 32 + mfma_row(r, L.lane);
-        oP[o * 64 + L.j] = pp0[r];
-        oP[o * 64 + 32 + L.j] = pp1[r];
-    }
 }
 
 // ---------------------------------------------------------------------------------------
 // backward pass E: dz2 -> dh1 = W2^T dz2 -> g1 = dL/d(bn1 output); accumulates
 //   pc [blk][64][2] = sum g1, sum g1*zhat1 ;  pR [blk][64][3] = sum_points g1 x^T (original x)
+//   pW2 [blk][128][64] = sum_points dz2 h1^T  (= this workgroup's share of dL/dW2, contracted on the MFMA)
 // ---------------------------------------------------------------------------------------
 struct BwdEParams {
     const float *is1, *nm1;       // zhat1 = z1*is1 + nm1
@@ -528,7 +511,8 @@ struct BwdEParams {
 
 __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
     const float *__restrict__ x, int N, const float *__restrict__ trans, TrainChan P, BwdEParams E,
-    int T, int S, const float *__restrict__ g2buf, float *__restrict__ pc, float *__restrict__ pR) {
+    int T, int S, const float *__restrict__ g2buf, float *__restrict__ pc, float *__restrict__ pR,
+    float *__restrict__ pW2) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *h1 = smem;
     float *dz = h1 + TP * H1S;    // [TP][H2S]
@@ -551,6 +535,9 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
     const float w10 = P.w1[c1 * 3], w11 = P.w1[c1 * 3 + 1], w12 = P.w1[c1 * 3 + 2], bb1 = P.b1[c1];
     const float is1 = E.is1[c1], nm1 = E.nm1[c1];
     float c1s = 0.f, c2s = 0.f, r0 = 0.f, r1 = 0.f, r2 = 0.f;
+    f32x16 pw0, pw1;   // dW2 rows o = cb*32 + i, columns {0,1}*32 + j
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { pw0[r] = 0.f; pw1[r] = 0.f; }
     for (int tile = t0; tile < t1; ++tile) {
         const int nbase = tile * TP;
         stage_points(xb, N, tile, has_t, tm, xs, xo, L.tid);
@@ -599,7 +586,25 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
                 r2 = fmaf(g1v, xo[2 * TP + pt], r2);
             }
         }
+        // dW2 += dz^T h1 : contraction over the tile's 64 points (rows past N carry dz == 0)
+#pragma unroll 4
+        for (int st = 0; st < 32; ++st) {
+            const int pt = 2 * st + L.h;
+            const float av = dz[pt * H2S + cb * 32 + L.j];
+            const float *hr = h1 + pt * H1S + L.j;
+            pw0 = mfma32(av, hr[0], pw0);
+            pw1 = mfma32(av, hr[32], pw1);
+        }
         __syncthreads();
+    }
+    {
+        float *oW = pW2 + (size_t)blockIdx.x * 128 * 64;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = cb * 32 + mfma_row(r, L.lane);
+            oW[o * 64 + L.j] = pw0[r];
+            oW[o * 64 + 32 + L.j] = pw1[r];
+        }
     }
     c1s += __shfl_xor(c1s, 32); c2s += __shfl_xor(c2s, 32);
     r0 += __shfl_xor(r0, 32); r1 += __shfl_xor(r1, 32); r2 += __shfl_xor(r2, 32);
@@ -623,37 +628,37 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
 
 // ---------------------------------------------------------------------------------------
 // BatchNorm1d over the batch (FC stacks) — train forward / backward, optional fused ReLU.
-// block = 32 channels x 8 row lanes.
+// block = 32 channels x 32 row lanes (1024 threads).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn1d_fwd_train_kernel(
+__global__ __launch_bounds__(1024) void bn1d_fwd_train_kernel(
     const float *__restrict__ z, int B, int C, const float *__restrict__ gamma,
     const float *__restrict__ beta, float eps, int relu, float *__restrict__ y,
     float *__restrict__ mean_out, float *__restrict__ var_out) {
-    __shared__ float red[8][33];
+    __shared__ float red[32][33];
     const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cx;
     const bool ok = c < C;
     float s = 0.f;
-    if (ok) for (int b = ry; b < B; b += 8) s += z[(size_t)b * C + c];
+    if (ok) for (int b = ry; b < B; b += 32) s += z[(size_t)b * C + c];
     red[ry][cx] = s;
     __syncthreads();
     float mean = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) mean += red[i][cx];
+    for (int i = 0; i < 32; ++i) mean += red[i][cx];
     mean /= (float)B;
     __syncthreads();
     float q = 0.f;
-    if (ok) for (int b = ry; b < B; b += 8) { float d = z[(size_t)b * C + c] - mean; q = fmaf(d, d, q); }
+    if (ok) for (int b = ry; b < B; b += 32) { float d = z[(size_t)b * C + c] - mean; q = fmaf(d, d, q); }
     red[ry][cx] = q;
     __syncthreads();
     float var = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) var += red[i][cx];
+    for (int i = 0; i < 32; ++i) var += red[i][cx];
     var /= (float)B;
     if (!ok) return;
     const float inv = 1.0f / sqrtf(var + eps);
     const float g = gamma[c], be = beta[c];
-    for (int b = ry; b < B; b += 8) {
+    for (int b = ry; b < B; b += 32) {
         float v = (z[(size_t)b * C + c] - mean) * inv * g + be;
         if (relu) v = fmaxf(v, 0.f);
         y[(size_t)b * C + c] = v;
@@ -662,18 +667,18 @@ __global__ __launch_bounds__(256) void bn1d_fwd_train_kernel(
 }
 
 // dy: gradient wrt the (post-ReLU if relu) output y.  dz, dgamma, dbeta out.
-__global__ __launch_bounds__(256) void bn1d_bwd_kernel(
+__global__ __launch_bounds__(1024) void bn1d_bwd_kernel(
     const float *__restrict__ dy, const float *__restrict__ z, const float *__restrict__ y, int B, int C,
     const float *__restrict__ gamma, const float *__restrict__ mean, const float *__restrict__ var,
     float eps, int relu, float *__restrict__ dz, float *__restrict__ dgamma, float *__restrict__ dbeta) {
-    __shared__ float red[2][8][33];
+    __shared__ float red[2][32][33];
     const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cx;
     const bool ok = c < C;
     float mu = 0.f, inv = 0.f;
     if (ok) { mu = mean[c]; inv = 1.0f / sqrtf(var[c] + eps); }
     float s1 = 0.f, s2 = 0.f;
-    if (ok) for (int b = ry; b < B; b += 8) {
+    if (ok) for (int b = ry; b < B; b += 32) {
         const size_t i = (size_t)b * C + c;
         float g = dy[i];
         if (relu && !(y[i] > 0.f)) g = 0.f;
@@ -684,10 +689,10 @@ __global__ __launch_bounds__(256) void bn1d_bwd_kernel(
     __syncthreads();
     float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { t1 += red[0][i][cx]; t2 += red[1][i][cx]; }
+    for (int i = 0; i < 32; ++i) { t1 += red[0][i][cx]; t2 += red[1][i][cx]; }
     if (!ok) return;
     const float gi = gamma[c] * inv, m1 = t1 / (float)B, m2 = t2 / (float)B;
-    for (int b = ry; b < B; b += 8) {
+    for (int b = ry; b < B; b += 32) {
         const size_t i = (size_t)b * C + c;
         float g = dy[i];
         if (relu && !(y[i] > 0.f)) g = 0.f;
@@ -798,9 +803,9 @@ int pngpd_trunk_bwd_d(const float *x, int B, int N, const float *trans,
                       const float *w2p, const float *s2c, const float *t2c,
                       const float *is2, const float *nm2, const float *Ap, const float *cvec,
                       const float *w3, const int *idx, const float *coef,
-                      float *g2buf, float *pa, float *pP, void *stream) {
+                      float *g2buf, float *pa, void *stream) {
     if (!x || !w1 || !b1 || !s1c || !t1c || !w2p || !s2c || !t2c || !is2 || !nm2 || !Ap || !cvec || !w3 ||
-        !idx || !coef || !g2buf || !pa || !pP || B <= 0 || N <= 0)
+        !idx || !coef || !g2buf || !pa || B <= 0 || N <= 0)
         return PNGPD_ERR_INVALID_ARG;
     const int T = (N + TP - 1) / TP, S = train_splits(B, T);
     TrainChan P = make_chan(w1, b1, s1c, t1c, w2p, s2c, t2c);
@@ -809,7 +814,7 @@ int pngpd_trunk_bwd_d(const float *x, int B, int N, const float *trans,
     static bool attr_set = false;
     if (!attr_set) { allow_lds((const void *)trunk_bwd_d_kernel, lds); attr_set = true; }
     hipLaunchKernelGGL(trunk_bwd_d_kernel, dim3((unsigned)B * S), dim3(256), lds, (hipStream_t)stream,
-                       x, N, trans, P, D, T, S, g2buf, pa, pP);
+                       x, N, trans, P, D, T, S, g2buf, pa);
     return pngpd_launch_status();
 }
 
@@ -817,9 +822,9 @@ int pngpd_trunk_bwd_e(const float *x, int B, int N, const float *trans,
                       const float *w1, const float *b1, const float *s1c, const float *t1c,
                       const float *w2p, const float *is1, const float *nm1, const float *is2, const float *nm2,
                       const float *a1m, const float *a2m, const float *dsc2, const float *w2tp,
-                      const float *g2buf, float *pc, float *pR, void *stream) {
+                      const float *g2buf, float *pc, float *pR, float *pW2, void *stream) {
     if (!x || !w1 || !b1 || !s1c || !t1c || !w2p || !is1 || !nm1 || !is2 || !nm2 || !a1m || !a2m || !dsc2 ||
-        !w2tp || !g2buf || !pc || !pR || B <= 0 || N <= 0)
+        !w2tp || !g2buf || !pc || !pR || !pW2 || B <= 0 || N <= 0)
         return PNGPD_ERR_INVALID_ARG;
     const int T = (N + TP - 1) / TP, S = train_splits(B, T);
     TrainChan P = make_chan(w1, b1, s1c, t1c, w2p, nullptr, nullptr);
@@ -827,14 +832,14 @@ int pngpd_trunk_bwd_e(const float *x, int B, int N, const float *trans,
     E.w2tp = w2tp;
     const size_t lds = BWD_E_LDS_FLOATS * sizeof(float);
     hipLaunchKernelGGL(trunk_bwd_e_kernel, dim3((unsigned)B * S), dim3(256), lds, (hipStream_t)stream,
-                       x, N, trans, P, E, T, S, g2buf, pc, pR);
+                       x, N, trans, P, E, T, S, g2buf, pc, pR, pW2);
     return pngpd_launch_status();
 }
 
 int pngpd_bn1d_fwd_train(const float *z, int B, int C, const float *gamma, const float *beta, float eps,
                          int relu, float *y, float *mean, float *var, void *stream) {
     if (!z || !gamma || !beta || !y || !mean || !var || B <= 0 || C <= 0) return PNGPD_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(bn1d_fwd_train_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(bn1d_fwd_train_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream,
                        z, B, C, gamma, beta, eps, relu, y, mean, var);
     return pngpd_launch_status();
 }
@@ -844,7 +849,7 @@ int pngpd_bn1d_bwd(const float *dy, const float *z, const float *y, int B, int C
                    float *dz, float *dgamma, float *dbeta, void *stream) {
     if (!dy || !z || !y || !gamma || !mean || !var || !dz || !dgamma || !dbeta || B <= 0 || C <= 0)
         return PNGPD_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(bn1d_bwd_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(bn1d_bwd_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream,
                        dy, z, y, B, C, gamma, mean, var, eps, relu, dz, dgamma, dbeta);
     return pngpd_launch_status();
 }

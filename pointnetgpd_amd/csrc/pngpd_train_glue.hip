@@ -1,0 +1,470 @@
+// libpngpd — parameter-sized fp64 algebra between the training passes ("finalize" kernels):
+// BatchNorm statistics -> per-channel affine forms (+ running-stat update), pooled output from the
+// per-workgroup maxima, deterministic fp64 reduction of per-workgroup partial sums, and the closed-form
+// weight gradients / pass-D operands (DESIGN.md "Training passes"; algebra verified in fp64 against
+// autograd by tests/train_algo_prototype.py).  Everything here is tiny (<= 1024x128 matrices); the point is
+// to replace ~500 launch-bound framework ops per step by ~40 kernels on the same stream.
+#include "pngpd_common.h"
+
+#define NT 256
+
+__device__ __forceinline__ double block_sum(double v, double *red) {   // red: [NT] shared
+    const int tid = threadIdx.x;
+    red[tid] = v;
+    __syncthreads();
+    for (int s = NT / 2; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+}
+
+__device__ __forceinline__ void running_update(float *rm, float *rv, int c, double mean, double var_b,
+                                               double M, double mom) {
+    if (!rm) return;
+    const double unb = var_b * (M / (M > 1.0 ? M - 1.0 : 1.0));
+    rm[c] = (float)((1.0 - mom) * (double)rm[c] + mom * mean);
+    rv[c] = (float)((1.0 - mom) * (double)rv[c] + mom * unb);
+}
+
+// ---------------------------------------------------------------------------------------
+// BN1: closed-form batch statistics of z1 = W1 x' + b1 from the per-cloud input moments.
+//   mom (B,9) f64 = {sx,sy,sz,sxx,sxy,sxz,syy,syz,szz};  trans (B,3,3) or NULL (x' = x^T T)
+//   chan (4,64) f32 = s1c, t1c, is1, nm1 ;  stats f64 = mx[3], Cx[9], mu1[64], var1[64]
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void bn1_finalize_kernel(
+    const double *__restrict__ mom, const float *__restrict__ trans, int B, double M,
+    const float *__restrict__ w1, const float *__restrict__ b1, const float *__restrict__ g1,
+    const float *__restrict__ be1, double eps, double momentum, float *rm, float *rv, long long *nbt,
+    float *__restrict__ chan, double *__restrict__ stats) {
+    __shared__ double red[NT];
+    __shared__ double tot[12];
+    const int tid = threadIdx.x;
+    double a[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) a[i] = 0.0;
+    for (int b = tid; b < B; b += NT) {
+        const double *m = mom + (size_t)b * 9;
+        const double mb[3] = {m[0], m[1], m[2]};
+        const double S[3][3] = {{m[3], m[4], m[5]}, {m[4], m[6], m[7]}, {m[5], m[7], m[8]}};
+        if (trans) {
+            double T[3][3];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) T[i / 3][i % 3] = (double)trans[(size_t)b * 9 + i];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) a[j] += mb[0] * T[0][j] + mb[1] * T[1][j] + mb[2] * T[2][j];
+            double ST[3][3];   // S T
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) ST[i][j] = S[i][0] * T[0][j] + S[i][1] * T[1][j] + S[i][2] * T[2][j];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) a[3 + i * 3 + j] += T[0][i] * ST[0][j] + T[1][i] * ST[1][j] + T[2][i] * ST[2][j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) a[j] += mb[j];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) a[3 + i * 3 + j] += S[i][j];
+        }
+    }
+    for (int i = 0; i < 12; ++i) {
+        const double r = block_sum(a[i], red);
+        if (tid == 0) tot[i] = r;
+    }
+    __syncthreads();
+    double mx[3], Cx[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) mx[j] = tot[j] / M;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Cx[i][j] = tot[3 + i * 3 + j] / M - mx[i] * mx[j];
+    if (tid < 3) stats[tid] = mx[tid];
+    if (tid < 9) stats[3 + tid] = Cx[tid / 3][tid % 3];
+    if (tid < 64) {
+        const int c = tid;
+        const double w[3] = {(double)w1[c * 3], (double)w1[c * 3 + 1], (double)w1[c * 3 + 2]};
+        const double mu = w[0] * mx[0] + w[1] * mx[1] + w[2] * mx[2] + (double)b1[c];
+        double var = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) var += w[i] * Cx[i][j] * w[j];
+        var = var > 0.0 ? var : 0.0;
+        const double is = 1.0 / sqrt(var + eps);
+        const double sc = (double)g1[c] * is;
+        chan[c] = (float)sc;
+        chan[64 + c] = (float)((double)be1[c] - mu * sc);
+        chan[128 + c] = (float)is;
+        chan[192 + c] = (float)(-mu * is);
+        stats[12 + c] = mu;
+        stats[76 + c] = var;
+        running_update(rm, rv, c, mu, var, M, momentum);
+    }
+    if (tid == 0 && nbt) *nbt += 1;
+}
+
+// ---------------------------------------------------------------------------------------
+// BN2: tot (128,2) f64 = sum / sum of squares of z2 (pngpd_reduce_partials of the pass-B partials)
+//   -> chan (4,128) f32 = s2c,t2c,is2,nm2 ; stats f64 = mu2r[128], var2[128]
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void bn2_finalize_kernel(
+    const double *__restrict__ tot, double M, const float *__restrict__ b2,
+    const float *__restrict__ g2, const float *__restrict__ be2, double eps, double momentum,
+    float *rm, float *rv, long long *nbt, float *__restrict__ chan, double *__restrict__ stats) {
+    const int c = threadIdx.x;
+    const double mu = tot[c * 2] / M;
+    double var = tot[c * 2 + 1] / M - mu * mu;
+    var = var > 0.0 ? var : 0.0;
+    const double is = 1.0 / sqrt(var + eps);
+    const double sc = (double)g2[c] * is;
+    chan[c] = (float)sc;
+    chan[128 + c] = (float)((double)be2[c] - mu * sc);
+    chan[256 + c] = (float)is;
+    chan[384 + c] = (float)(-mu * is);
+    stats[c] = mu;
+    stats[128 + c] = var;
+    running_update(rm, rv, c, mu + (double)b2[c], var, M, momentum);
+    if (c == 0 && nbt) *nbt += 1;
+}
+
+// ---------------------------------------------------------------------------------------
+// BN3: tot (2,1024) f64 (pngpd_reduce_partials of the pass-C psum) -> stats f64 = mu3s[1024], var3[1024]
+// (of the sign-folded z3s)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void bn3_finalize_kernel(
+    const double *__restrict__ tot /* (2,1024) */, double M, const float *__restrict__ b3,
+    const float *__restrict__ g3, double momentum, float *rm, float *rv, long long *nbt,
+    double *__restrict__ stats) {
+    const int c = blockIdx.x * NT + threadIdx.x;
+    const double mu = tot[c] / M;
+    double var = tot[1024 + c] / M - mu * mu;
+    var = var > 0.0 ? var : 0.0;
+    stats[c] = mu;
+    stats[1024 + c] = var;
+    const double sgn = g3[c] >= 0.f ? 1.0 : -1.0;
+    running_update(rm, rv, c, sgn * mu + (double)b3[c], var, M, momentum);
+    if (c == 0 && nbt) *nbt += 1;
+}
+
+// pooled[b][c] = (relu?)(g3 * zhat + be3), zhat = sgn*(max_s pmax - mu3s)/sig3 ; idx = arg of the max
+__global__ __launch_bounds__(NT) void pool_finalize_kernel(
+    const float *__restrict__ pmax, const int *__restrict__ parg, int S, const double *__restrict__ stats,
+    const float *__restrict__ g3, const float *__restrict__ be3, double eps, int relu_last, int total,
+    float *__restrict__ pooled, int *__restrict__ idx, float *__restrict__ zhat) {
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= total) return;
+    const int b = i >> 10, c = i & 1023;
+    const float *p = pmax + (size_t)b * S * 1024 + c;
+    const int *a = parg + (size_t)b * S * 1024 + c;
+    float m = p[0]; int am = a[0];
+    for (int s = 1; s < S; ++s) {
+        const float v = p[(size_t)s * 1024];
+        if (v > m) { m = v; am = a[(size_t)s * 1024]; }   // strict: the earliest split wins ties
+    }
+    const double sgn = g3[c] >= 0.f ? 1.0 : -1.0;
+    const double zh = sgn * ((double)m - stats[c]) / sqrt(stats[1024 + c] + eps);
+    double y = (double)g3[c] * zh + (double)be3[c];
+    if (relu_last && !(y > 0.0)) y = 0.0;
+    pooled[i] = (float)y;
+    idx[i] = am;
+    zhat[i] = (float)zh;
+}
+
+// ---------------------------------------------------------------------------------------
+// backward of BN3 affine + the sparse-term weights:
+//   d = dp (masked by pooled>0 if relu_last);  dbe3 = sum_b d;  dg3 = sum_b d*zhat
+//   coef[b][c] = d * g3/sig3 ;  m12 f64 = m1[1024] (= dbe3/M), m2[1024] (= dg3/M)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void bn3_bwd_prep_kernel(
+    const float *__restrict__ dp, const float *__restrict__ pooled, const float *__restrict__ zhat, int B,
+    double M, const float *__restrict__ g3, const double *__restrict__ stats, double eps, int relu_last,
+    float *__restrict__ coef, float *__restrict__ dg3, float *__restrict__ dbe3, double *__restrict__ m12) {
+    __shared__ double r1[32][33], r2[32][33];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
+    const double s3 = (double)g3[c] / sqrt(stats[1024 + c] + eps);
+    double a1 = 0.0, a2 = 0.0;
+    for (int b = ry; b < B; b += 32) {
+        const size_t i = (size_t)b * 1024 + c;
+        float d = dp[i];
+        if (relu_last && !(pooled[i] > 0.f)) d = 0.f;
+        a1 += (double)d;
+        a2 += (double)d * (double)zhat[i];
+        coef[i] = (float)((double)d * s3);
+    }
+    r1[ry][cx] = a1; r2[ry][cx] = a2;
+    __syncthreads();
+    if (ry == 0) {
+        double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { t1 += r1[i][cx]; t2 += r2[i][cx]; }
+        dbe3[c] = (float)t1;
+        dg3[c] = (float)t2;
+        m12[c] = t1 / M;
+        m12[1024 + c] = t2 / M;
+    }
+}
+
+// out[o][j] = sum_r in[o][r][j]   (fp32 partials -> fp64), deterministic order.
+// block = 32 columns x 32 row-lanes (rows strided by 32, then a fixed-order LDS tree over the lanes).
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float *__restrict__ in, int R, int n,
+                                                              double *__restrict__ out) {
+    __shared__ double red[32][33];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + cx;
+    double s = 0.0;
+    if (j < n) {
+        const float *p = in + (size_t)blockIdx.y * R * n + j;
+        for (int r = ry; r < R; r += 32) s += (double)p[(size_t)r * n];
+    }
+    red[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && j < n) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) t += red[i][cx];
+        out[(size_t)blockIdx.y * n + j] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// dW3[c][j] = G[c][j] - s3 (m1 sh[j] + (m2/sig3) (W3 Sc)[c][j]),  Sc = S2 - sh sh^T / M
+// block = one channel c, 128 threads = j
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void dw3_finalize_kernel(
+    const double *__restrict__ G, const double *__restrict__ S2, const double *__restrict__ sh, double M,
+    const float *__restrict__ w3, const float *__restrict__ g3, const double *__restrict__ stats,
+    const double *__restrict__ m12, double eps, float *__restrict__ dW3) {
+    __shared__ double wrow[128];
+    __shared__ double red[128];
+    const int c = blockIdx.x, j = threadIdx.x;
+    wrow[j] = (double)w3[(size_t)c * 128 + j];
+    red[j] = wrow[j] * sh[j];
+    __syncthreads();
+    for (int s = 64; s > 0; s >>= 1) { if (j < s) red[j] += red[j + s]; __syncthreads(); }
+    const double ws = red[0];
+    double dot = 0.0;
+    for (int k = 0; k < 128; ++k) dot += wrow[k] * S2[(size_t)k * 128 + j];
+    const double w3sc = dot - ws * sh[j] / M;
+    const double sig = sqrt(stats[1024 + c] + eps);
+    const double s3 = (double)g3[c] / sig;
+    dW3[(size_t)c * 128 + j] = (float)(G[(size_t)c * 128 + j] - s3 * (m12[c] * sh[j] + (m12[1024 + c] / sig) * w3sc));
+}
+
+// A = W3^T diag(g3 m2/sig3^2) W3 (written MFMA_B-packed, fp32), cvec = A mh - W3^T (s3 m1).
+// block = row i of A, 128 threads = j.
+__global__ __launch_bounds__(512) void a_cvec_finalize_kernel(
+    const float *__restrict__ w3, const float *__restrict__ g3, const double *__restrict__ stats,
+    const double *__restrict__ m12, const double *__restrict__ sh, double M, double eps,
+    float *__restrict__ Ap, float *__restrict__ cvec) {
+    __shared__ double part[4][128];
+    __shared__ double upart[4];
+    __shared__ double red[128];
+    const int i = blockIdx.x, j = threadIdx.x & 127, q = threadIdx.x >> 7;   // q: quarter of the channel range
+    double a = 0.0, u = 0.0;
+    for (int c = q * 256; c < q * 256 + 256; ++c) {
+        const double var = stats[1024 + c] + eps;
+        const double wi = (double)w3[(size_t)c * 128 + i];
+        a += wi * ((double)g3[c] * m12[1024 + c] / var) * (double)w3[(size_t)c * 128 + j];
+        if (j == 0) u += wi * ((double)g3[c] / sqrt(var)) * m12[c];
+    }
+    part[q][j] = a;
+    if (j == 0) upart[q] = u;
+    __syncthreads();
+    if (q == 0) {
+        a = part[0][j] + part[1][j] + part[2][j] + part[3][j];
+        const int cb = i >> 5, jj = i & 31, kb = j >> 3, h = (j >> 2) & 1, t = j & 3;   // MFMA_B packing of (i, j)
+        Ap[(((cb * 16 + kb) * 64) + h * 32 + jj) * 4 + t] = (float)a;
+        red[j] = a * (sh[j] / M);
+    }
+    __syncthreads();
+    for (int s = 64; s > 0; s >>= 1) { if (q == 0 && j < s) red[j] += red[j + s]; __syncthreads(); }
+    if (threadIdx.x == 0) cvec[i] = (float)(red[0] - (upart[0] + upart[1] + upart[2] + upart[3]));
+}
+
+// a12 (128,2) f64 = sum g2, sum g2*zhat2  ->  dg2 = a2, dbe2 = a1 and the pass-E vectors
+//   evec (3,128) f32 = a1/M, a2/M, g2/sig2.
+__global__ __launch_bounds__(128) void bwd_e_prep_kernel(
+    const double *__restrict__ a12, double M, const float *__restrict__ g2, const double *__restrict__ stats2,
+    double eps, float *__restrict__ dg2, float *__restrict__ dbe2, float *__restrict__ evec) {
+    const int o = threadIdx.x;
+    const double a1 = a12[o * 2], a2 = a12[o * 2 + 1];
+    dg2[o] = (float)a2; dbe2[o] = (float)a1;
+    evec[o] = (float)(a1 / M); evec[128 + o] = (float)(a2 / M);
+    evec[256 + o] = (float)((double)g2[o] / sqrt(stats2[128 + o] + eps));
+}
+
+// dW1[c][j] = s1 (Rp[c][j] - c1 mx[j] - (c2/sig1) (W1 Cx)[c][j]),  Rp = sum_b Rb[b] T_b  (or sum_b Rb[b])
+// block = channel c, NT threads over b.   Rb f64 (B,64,3).
+__global__ __launch_bounds__(NT) void dw1_finalize_kernel(
+    const double *__restrict__ Rb, const float *__restrict__ trans, int B, const double *__restrict__ c12 /*(64,2)*/,
+    const double *__restrict__ stats1, const float *__restrict__ w1, const float *__restrict__ g1, double eps,
+    float *__restrict__ dW1, float *__restrict__ dg1, float *__restrict__ dbe1) {
+    __shared__ double red[NT];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    double r[3] = {0.0, 0.0, 0.0};
+    for (int b = tid; b < B; b += NT) {
+        const double *rb = Rb + ((size_t)b * 64 + c) * 3;
+        if (trans) {
+            const float *T = trans + (size_t)b * 9;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) r[j] += rb[0] * (double)T[j] + rb[1] * (double)T[3 + j] + rb[2] * (double)T[6 + j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) r[j] += rb[j];
+        }
+    }
+    double Rp[3];
+    for (int j = 0; j < 3; ++j) Rp[j] = block_sum(r[j], red);
+    if (tid == 0) {
+        const double *mx = stats1, *Cx = stats1 + 3;
+        const double sig = sqrt(stats1[76 + c] + eps);
+        const double s1 = (double)g1[c] / sig;
+        const double c1 = c12[c * 2], c2 = c12[c * 2 + 1];
+        const double w[3] = {(double)w1[c * 3], (double)w1[c * 3 + 1], (double)w1[c * 3 + 2]};
+        for (int j = 0; j < 3; ++j) {
+            const double wcx = w[0] * Cx[0 * 3 + j] + w[1] * Cx[1 * 3 + j] + w[2] * Cx[2 * 3 + j];
+            dW1[c * 3 + j] = (float)(s1 * (Rp[j] - c1 * mx[j] - (c2 / sig) * wcx));
+        }
+        dg1[c] = (float)c2; dbe1[c] = (float)c1;
+    }
+}
+
+// dT_b = Y_b W1,  Y_b[i][c] = s1 (Rb[b][c][i] - m_b[i] c1/M - term3 c2/M),
+//   term3 = ((S_b T_b)[i][:] . W1[c] + m_b[i] (b1 - mu1)) / sig1.     block = cloud b, 64 threads = c
+__global__ __launch_bounds__(64) void dtrans_finalize_kernel(
+    const double *__restrict__ Rb, const float *__restrict__ trans, const double *__restrict__ mom, double M,
+    const double *__restrict__ c12, const double *__restrict__ stats1, const float *__restrict__ w1,
+    const float *__restrict__ b1, const float *__restrict__ g1, double eps, float *__restrict__ dT) {
+    __shared__ double red[9][64];
+    const int b = blockIdx.x, c = threadIdx.x;
+    const double *m = mom + (size_t)b * 9;
+    const double mb[3] = {m[0], m[1], m[2]};
+    const double S[3][3] = {{m[3], m[4], m[5]}, {m[4], m[6], m[7]}, {m[5], m[7], m[8]}};
+    double T[3][3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) T[i / 3][i % 3] = (double)trans[(size_t)b * 9 + i];
+    const double w[3] = {(double)w1[c * 3], (double)w1[c * 3 + 1], (double)w1[c * 3 + 2]};
+    const double sig = sqrt(stats1[76 + c] + eps);
+    const double s1 = (double)g1[c] / sig;
+    const double c1 = c12[c * 2] / M, c2 = c12[c * 2 + 1] / M;
+    const double bmu = (double)b1[c] - stats1[12 + c];
+    const double *rb = Rb + ((size_t)b * 64 + c) * 3;
+    double Y[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double st = 0.0;   // (S T)[i][:] . w
+#pragma unroll
+        for (int j = 0; j < 3; ++j) st += (S[i][0] * T[0][j] + S[i][1] * T[1][j] + S[i][2] * T[2][j]) * w[j];
+        const double term3 = (st + mb[i] * bmu) / sig;
+        Y[i] = s1 * (rb[i] - mb[i] * c1 - term3 * c2);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) red[i * 3 + j][c] = Y[i] * w[j];
+    __syncthreads();
+    if (c < 9) {
+        double s = 0.0;
+        for (int k = 0; k < 64; ++k) s += red[c][k];
+        dT[(size_t)b * 9 + c] = (float)s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+#define LAUNCH(kernel, grid, block, ...) \
+    hipLaunchKernelGGL(kernel, grid, block, 0, (hipStream_t)stream, __VA_ARGS__); \
+    return pngpd_launch_status()
+
+extern "C" {
+
+int pngpd_bn1_finalize(const double *mom, const float *trans, int B, int N, const float *w1, const float *b1,
+                       const float *g1, const float *be1, float eps, float momentum, float *rm, float *rv,
+                       long long *nbt, float *chan, double *stats, void *stream) {
+    if (!mom || !w1 || !b1 || !g1 || !be1 || !chan || !stats || B <= 0 || N <= 0) return PNGPD_ERR_INVALID_ARG;
+    LAUNCH(bn1_finalize_kernel, dim3(1), dim3(NT), mom, trans, B, (double)B * N, w1, b1, g1, be1, (double)eps,
+           (double)momentum, rm, rv, nbt, chan, stats);
+}
+
+int pngpd_bn2_finalize(const double *tot, int B, int N, const float *b2, const float *g2,
+                       const float *be2, float eps, float momentum, float *rm, float *rv, long long *nbt,
+                       float *chan, double *stats, void *stream) {
+    if (!tot || !b2 || !g2 || !be2 || !chan || !stats || B <= 0 || N <= 0) return PNGPD_ERR_INVALID_ARG;
+    LAUNCH(bn2_finalize_kernel, dim3(1), dim3(128), tot, (double)B * N, b2, g2, be2, (double)eps,
+           (double)momentum, rm, rv, nbt, chan, stats);
+}
+
+int pngpd_bn3_finalize(const double *tot, int B, int N, const float *b3, const float *g3,
+                       float momentum, float *rm, float *rv, long long *nbt, double *stats, void *stream) {
+    if (!tot || !b3 || !g3 || !stats || B <= 0 || N <= 0) return PNGPD_ERR_INVALID_ARG;
+    LAUNCH(bn3_finalize_kernel, dim3(1024 / NT), dim3(NT), tot, (double)B * N, b3, g3, (double)momentum,
+           rm, rv, nbt, stats);
+}
+
+int pngpd_pool_finalize(const float *pmax, const int *parg, int B, int S, const double *stats, const float *g3,
+                        const float *be3, float eps, int relu_last, float *pooled, int *idx, float *zhat,
+                        void *stream) {
+    if (!pmax || !parg || !stats || !g3 || !be3 || !pooled || !idx || !zhat || B <= 0 || S <= 0)
+        return PNGPD_ERR_INVALID_ARG;
+    const int total = B * 1024;
+    LAUNCH(pool_finalize_kernel, dim3((total + NT - 1) / NT), dim3(NT), pmax, parg, S, stats, g3, be3, (double)eps,
+           relu_last, total, pooled, idx, zhat);
+}
+
+int pngpd_bn3_bwd_prep(const float *dp, const float *pooled, const float *zhat, int B, int N, const float *g3,
+                       const double *stats, float eps, int relu_last, float *coef, float *dg3, float *dbe3,
+                       double *m12, void *stream) {
+    if (!dp || !pooled || !zhat || !g3 || !stats || !coef || !dg3 || !dbe3 || !m12 || B <= 0 || N <= 0)
+        return PNGPD_ERR_INVALID_ARG;
+    LAUNCH(bn3_bwd_prep_kernel, dim3(32), dim3(1024), dp, pooled, zhat, B, (double)B * N, g3, stats,
+           (double)eps, relu_last, coef, dg3, dbe3, m12);
+}
+
+int pngpd_reduce_partials(const float *in, int outer, int R, int n, double *out, void *stream) {
+    if (!in || !out || outer <= 0 || R <= 0 || n <= 0) return PNGPD_ERR_INVALID_ARG;
+    LAUNCH(reduce_partials_kernel, dim3((n + 31) / 32, outer), dim3(1024), in, R, n, out);
+}
+
+int pngpd_dw3_finalize(const double *G, const double *S2, const double *sh, int B, int N, const float *w3,
+                       const float *g3, const double *stats, const double *m12, float eps, float *dW3,
+                       float *Ap, float *cvec, void *stream) {
+    if (!G || !S2 || !sh || !w3 || !g3 || !stats || !m12 || !dW3 || !Ap || !cvec || B <= 0 || N <= 0)
+        return PNGPD_ERR_INVALID_ARG;
+    const double M = (double)B * N;
+    hipLaunchKernelGGL(dw3_finalize_kernel, dim3(1024), dim3(128), 0, (hipStream_t)stream, G, S2, sh, M, w3, g3,
+                       stats, m12, (double)eps, dW3);
+    int st = pngpd_launch_status();
+    if (st != PNGPD_OK) return st;
+    LAUNCH(a_cvec_finalize_kernel, dim3(128), dim3(512), w3, g3, stats, m12, sh, M, (double)eps, Ap, cvec);
+}
+
+int pngpd_bwd_e_prep(const double *a12, int B, int N, const float *g2, const double *stats2, float eps,
+                     float *dg2, float *dbe2, float *evec, void *stream) {
+    if (!a12 || !g2 || !stats2 || !dg2 || !dbe2 || !evec || B <= 0 || N <= 0) return PNGPD_ERR_INVALID_ARG;
+    LAUNCH(bwd_e_prep_kernel, dim3(1), dim3(128), a12, (double)B * N, g2, stats2, (double)eps, dg2, dbe2, evec);
+}
+
+int pngpd_dw1_finalize(const double *Rb, const float *trans, const double *mom, int B, int N, const double *c12,
+                       const double *stats1, const float *w1, const float *b1, const float *g1, float eps,
+                       float *dW1, float *dg1, float *dbe1, float *dT, void *stream) {
+    if (!Rb || !mom || !c12 || !stats1 || !w1 || !b1 || !g1 || !dW1 || !dg1 || !dbe1 || B <= 0 || N <= 0)
+        return PNGPD_ERR_INVALID_ARG;
+    if (dT && !trans) return PNGPD_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(dw1_finalize_kernel, dim3(64), dim3(NT), 0, (hipStream_t)stream, Rb, trans, B, c12, stats1,
+                       w1, g1, (double)eps, dW1, dg1, dbe1);
+    int st = pngpd_launch_status();
+    if (st != PNGPD_OK || !dT) return st;
+    LAUNCH(dtrans_finalize_kernel, dim3(B), dim3(64), Rb, trans, mom, (double)B * N, c12, stats1, w1, b1, g1,
+           (double)eps, dT);
+}
+
+}  // extern "C"

@@ -201,10 +201,9 @@ def trunk_bwd_d(x, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, is2, nm2, Ap, cvec, w
     blk = B * train_splits(B, N)
     g2buf = torch.empty(B, N, 128, device=x.device, dtype=torch.float32)
     pa = torch.empty(blk, 128, 2, device=x.device, dtype=torch.float32)
-    pP = torch.empty(blk, 128, 64, device=x.device, dtype=torch.float32)
     _call("pngpd_trunk_bwd_d", x, x, B, N, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, is2, nm2, Ap, cvec, w3,
-          idx, coef, g2buf, pa, pP)
-    return g2buf, pa, pP
+          idx, coef, g2buf, pa)
+    return g2buf, pa
 
 
 def trunk_bwd_e(x, trans, w1, b1, s1c, t1c, w2p, is1, nm1, is2, nm2, a1m, a2m, dsc2, w2tp, g2buf):
@@ -212,9 +211,10 @@ def trunk_bwd_e(x, trans, w1, b1, s1c, t1c, w2p, is1, nm1, is2, nm2, a1m, a2m, d
     S = train_splits(B, N)
     pc = torch.empty(B * S, 64, 2, device=x.device, dtype=torch.float32)
     pR = torch.empty(B, S, 64, 3, device=x.device, dtype=torch.float32)
+    pW2 = torch.empty(B * S, 128, 64, device=x.device, dtype=torch.float32)
     _call("pngpd_trunk_bwd_e", x, x, B, N, trans, w1, b1, s1c, t1c, w2p, is1, nm1, is2, nm2, a1m, a2m, dsc2,
-          w2tp, g2buf, pc, pR)
-    return pc, pR
+          w2tp, g2buf, pc, pR, pW2)
+    return pc, pR, pW2
 
 
 def bn1d_fwd_train(z, gamma, beta, eps, relu):

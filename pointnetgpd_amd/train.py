@@ -1,46 +1,48 @@
 """Train-mode forward/backward of the hot path as ``torch.autograd.Function``s over the libpngpd
 training passes (include/pngpd.h "Training path").
 
-What runs where
----------------
-* every per-point / per-sample computation (the per-point MLP recompute passes, the max-pool,
-  second moments, the FC GEMMs, BatchNorm1d over the batch, log-softmax backward) is a HIP kernel
-  reached through the C ABI;
-* the *parameter-sized* closed-form algebra that turns the passes' accumulated sums into BatchNorm
-  statistics and weight gradients (64x3 … 1024x128 matrices, fp64) and the reduction of
-  per-workgroup partial buffers is done here with torch ops on the same device/stream.
+Everything batch-sized AND the parameter-sized fp64 algebra between the passes (BatchNorm statistics ->
+affine forms, running-stat updates, reduction of per-workgroup partials, closed-form weight gradients) runs
+in HIP kernels reached through the C ABI; this module only sequences them on torch's current stream and owns
+the buffers (``torch.empty``).  The remaining torch ops are layout plumbing (transposes / zero padding for the
+FC backward GEMMs, ``.view``).
 
 The algebra is derived in DESIGN.md ("Training passes") and verified against autograd in fp64 by
 ``tests/train_algo_prototype.py``.  Semantics match the reference's train-mode graph
-(pointnet.py:27-45,137-154,189-194 under main_1v.py:72-76): batch-statistics BatchNorm with
-eps 1e-5, running statistics updated with momentum 0.1 and the unbiased variance.
+(pointnet.py:27-45,137-154,189-194 under main_1v.py:72-76): batch-statistics BatchNorm with eps 1e-5,
+running statistics updated with momentum 0.1 and the unbiased variance, num_batches_tracked += 1.
 """
 import torch
 
 from . import ops
+from .ops import _call
 
 F64 = torch.float64
-DEBUG_STASH = None   # set to a dict to capture backward intermediates (tools/diag_train.py)
+DEBUG_STASH = None   # set to a dict to capture backward intermediates (tests / tools/diag_train2.py)
 
 
-def _update_running(buffers, mean, var_biased, count, momentum):
-    """nn.BatchNorm1d running-stat update (momentum form, unbiased variance)."""
-    if buffers is None:
-        return
-    rm, rv, nbt = buffers
-    with torch.no_grad():
-        unbiased = var_biased * (count / max(count - 1, 1))
-        rm.mul_(1 - momentum).add_(mean.to(rm.dtype), alpha=momentum)
-        rv.mul_(1 - momentum).add_(unbiased.to(rv.dtype), alpha=momentum)
-        if nbt is not None:
-            nbt.add_(1)
+def _e(dev, *shape, dtype=torch.float32):
+    return torch.empty(*shape, device=dev, dtype=dtype)
 
 
-def _sym3(m6):
-    """(B,6) = xx,xy,xz,yy,yz,zz -> (B,3,3)."""
-    xx, xy, xz, yy, yz, zz = m6.unbind(1)
-    return torch.stack([torch.stack([xx, xy, xz], 1), torch.stack([xy, yy, yz], 1),
-                        torch.stack([xz, yz, zz], 1)], 1)
+def _bufs3(bufs):
+    return bufs if bufs is not None else (None, None, None)
+
+
+def _bump(bufs):
+    """The finalize kernels update running_mean / running_var / num_batches_tracked in place behind
+    torch's back: bump their version counters so version-keyed caches (the eval-mode fold cache) see it."""
+    if bufs is not None:
+        for t in bufs:
+            if t is not None:
+                torch.autograd.graph.increment_version(t)
+
+
+def _reduce(t, outer, R, n):
+    """(outer,R,n) fp32 partials -> (outer,n) fp64, deterministic."""
+    out = _e(t.device, outer, n, dtype=F64)
+    _call("pngpd_reduce_partials", t, t, int(outer), int(R), int(n), out)
+    return out
 
 
 class TrunkTrainFn(torch.autograd.Function):
@@ -52,147 +54,102 @@ class TrunkTrainFn(torch.autograd.Function):
     def forward(ctx, x, trans, W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, g3, be3, relu_last, eps,
                 momentum, bufs1, bufs2, bufs3):
         B, _, N = x.shape
-        M = B * N
         dev = x.device
         x = x.contiguous()
-        T = trans.contiguous() if trans is not None else None
-        w1 = W1.detach().reshape(64, 3).contiguous()
-        w2 = W2.detach().reshape(128, 64).contiguous()
-        w3 = W3.detach().reshape(1024, 128).contiguous()
-        f32 = lambda t: t.to(torch.float32).contiguous()
-        # ---- pass A: BN1 statistics in closed form from per-cloud moments (fp64)
+        T = trans.detach().contiguous() if trans is not None else None
+        c = lambda t: t.detach().contiguous()
+        w1, w2, w3 = c(W1).reshape(64, 3), c(W2).reshape(128, 64), c(W3).reshape(1024, 128)
+        b1c, g1c, be1c = c(b1), c(g1), c(be1)
+        b2c, g2c, be2c = c(b2), c(g2), c(be2)
+        b3c, g3c, be3c = c(b3), c(g3), c(be3)
+        S = ops.train_splits(B, N)
+        blk = B * S
+        # ---- pass A + BN1 (closed form from per-cloud moments)
         mom = ops.cloud_moments(x)
-        m_b, S_b = mom[:, :3], _sym3(mom[:, 3:])
-        if T is not None:
-            T64 = T.detach().to(F64)
-            mp_b = torch.einsum("bi,bij->bj", m_b, T64)
-            Sp_b = torch.einsum("bki,bkl,blj->bij", T64, S_b, T64)
-        else:
-            T64, mp_b, Sp_b = None, m_b, S_b
-        mx = mp_b.sum(0) / M
-        Cx = Sp_b.sum(0) / M - torch.outer(mx, mx)
-        W1d = w1.to(F64)
-        mu1 = W1d @ mx + b1.detach().to(F64)
-        var1 = torch.einsum("ci,ij,cj->c", W1d, Cx, W1d).clamp_min(0)
-        is1 = torch.rsqrt(var1 + eps)
-        s1c = g1.detach().to(F64) * is1
-        t1c = be1.detach().to(F64) - mu1 * s1c
-        nm1 = -mu1 * is1
-        b1f, s1cf, t1cf = f32(b1.detach()), f32(s1c), f32(t1c)
-        # ---- pass B: BN2 statistics
+        chan1, stats1 = _e(dev, 4, 64), _e(dev, 140, dtype=F64)
+        rm, rv, nbt = _bufs3(bufs1)
+        _call("pngpd_bn1_finalize", x, mom, T, B, N, w1, b1c, g1c, be1c, float(eps), float(momentum), rm, rv, nbt,
+              chan1, stats1)
+        _bump(bufs1)
+        s1c, t1c, is1, nm1 = chan1[0], chan1[1], chan1[2], chan1[3]
+        # ---- pass B + BN2
         w2p = ops.pack_mfma_b(w2)
-        part = ops.trunk_bn2_stats(x, T, w1, b1f, s1cf, t1cf, w2p)
-        tot = part.sum(0, dtype=F64)
-        mu2r = tot[:, 0] / M
-        var2 = (tot[:, 1] / M - mu2r * mu2r).clamp_min(0)
-        is2 = torch.rsqrt(var2 + eps)
-        s2c = g2.detach().to(F64) * is2
-        t2c = be2.detach().to(F64) - mu2r * s2c
-        nm2 = -mu2r * is2
-        s2cf, t2cf = f32(s2c), f32(t2c)
-        # ---- pass C: layer 3 (sign-folded), statistics + max/argmax
-        sgn = torch.where(g3.detach() >= 0, torch.ones_like(g3), -torch.ones_like(g3)).to(torch.float32)
-        w3sp = ops.pack_mfma_b(w3, scale=sgn.contiguous())
-        pmax, parg, psum = ops.trunk_fwd_train(x, T, w1, b1f, s1cf, t1cf, w2p, s2cf, t2cf, w3sp)
-        tot3 = psum.sum(0, dtype=F64)
-        mu3s = tot3[0] / M
-        var3 = (tot3[1] / M - mu3s * mu3s).clamp_min(0)
-        zmax, si = pmax.max(1)
-        idx = parg.gather(1, si.unsqueeze(1)).squeeze(1).contiguous()
-        sig3 = torch.sqrt(var3 + eps)
-        sgn64 = sgn.to(F64)
-        zhat_ext = sgn64 * (zmax.to(F64) - mu3s) / sig3
-        y = g3.detach().to(F64) * zhat_ext + be3.detach().to(F64)
-        pooled = (torch.relu(y) if relu_last else y).to(torch.float32)
-        # ---- running statistics of the reference's pre-BN activations
-        _update_running(bufs1, mu1, var1, M, momentum)
-        _update_running(bufs2, mu2r + b2.detach().to(F64), var2, M, momentum)
-        _update_running(bufs3, sgn64 * mu3s + b3.detach().to(F64), var3, M, momentum)
-        ctx.relu_last, ctx.eps, ctx.M, ctx.has_t = relu_last, eps, M, T is not None
-        ctx.save_for_backward(x, T if T is not None else x.new_empty(0), w1, b1f, g1.detach(), w2, g2.detach(),
-                              w3, g3.detach(), m_b, S_b, mx, Cx, mu1, var1, var2, var3, sig3, zhat_ext, y, idx,
-                              s1cf, t1cf, f32(is1), f32(nm1), w2p, s2cf, t2cf, f32(is2), f32(nm2))
+        part = ops.trunk_bn2_stats(x, T, w1, b1c, s1c, t1c, w2p)
+        chan2, stats2 = _e(dev, 4, 128), _e(dev, 256, dtype=F64)
+        rm, rv, nbt = _bufs3(bufs2)
+        tot2 = _reduce(part, 1, blk, 256)
+        _call("pngpd_bn2_finalize", x, tot2, B, N, b2c, g2c, be2c, float(eps), float(momentum), rm, rv, nbt,
+              chan2, stats2)
+        _bump(bufs2)
+        s2c, t2c, is2, nm2 = chan2[0], chan2[1], chan2[2], chan2[3]
+        # ---- pass C + BN3 + pool
+        sgn = torch.where(g3c >= 0, 1.0, -1.0).to(torch.float32)
+        w3sp = ops.pack_mfma_b(w3, scale=sgn)
+        pmax, parg, psum = ops.trunk_fwd_train(x, T, w1, b1c, s1c, t1c, w2p, s2c, t2c, w3sp)
+        stats3 = _e(dev, 2048, dtype=F64)
+        rm, rv, nbt = _bufs3(bufs3)
+        tot3 = _reduce(psum, 1, blk, 2048)
+        _call("pngpd_bn3_finalize", x, tot3, B, N, b3c, g3c, float(momentum), rm, rv, nbt, stats3)
+        _bump(bufs3)
+        pooled, idx, zhat = _e(dev, B, 1024), _e(dev, B, 1024, dtype=torch.int32), _e(dev, B, 1024)
+        _call("pngpd_pool_finalize", x, pmax, parg, B, S, stats3, g3c, be3c, float(eps), int(relu_last), pooled,
+              idx, zhat)
+        ctx.relu_last, ctx.eps, ctx.has_t, ctx.S = relu_last, eps, T is not None, S
+        ctx.save_for_backward(x, T if T is not None else x.new_empty(0), w1, b1c, g1c, w2, g2c, w3, g3c, mom,
+                              chan1, stats1, chan2, stats2, stats3, pooled, idx, zhat, w2p)
         return pooled
 
     @staticmethod
     def backward(ctx, dp):
-        (x, T, w1, b1f, g1, w2, g2, w3, g3, m_b, S_b, mx, Cx, mu1, var1, var2, var3, sig3, zhat_ext, y, idx,
-         s1cf, t1cf, is1f, nm1f, w2p, s2cf, t2cf, is2f, nm2f) = ctx.saved_tensors
+        (x, T, w1, b1c, g1c, w2, g2c, w3, g3c, mom, chan1, stats1, chan2, stats2, stats3, pooled, idx, zhat,
+         w2p) = ctx.saved_tensors
         T = T if ctx.has_t else None
-        M, eps = ctx.M, ctx.eps
+        eps, S = float(ctx.eps), ctx.S
         B, _, N = x.shape
-        f32 = lambda t: t.to(torch.float32).contiguous()
-        dp = dp.to(F64)
-        if ctx.relu_last:
-            dp = dp * (y > 0).to(F64)
-        g1d, g2d, g3d = g1.to(F64), g2.to(F64), g3.to(F64)
-        W1d, W2d, W3d = w1.to(F64), w2.to(F64), w3.to(F64)
-        # ---- BN3 affine grads + dense-correction scalars
-        dg3 = (dp * zhat_ext).sum(0)
-        dbe3 = dp.sum(0)
-        m1, m2 = dbe3 / M, dg3 / M
-        s3 = g3d / sig3
-        coef = f32(dp * s3[None, :])
-        # ---- hidden-activation moments, sparse gather
-        ps2, ps1, psh = ops.trunk_h_moments(x, T, w1, b1f, s1cf, t1cf, w2p, s2cf, t2cf)
-        S2 = ps2.sum(0, dtype=F64); S1 = ps1.sum(0, dtype=F64)
-        shs = psh.sum(0, dtype=F64); sh, sh1 = shs[:128], shs[128:]
-        mh, mh1 = sh / M, sh1 / M
-        Sc = S2 - M * torch.outer(mh, mh)
-        Sc1 = S1 - M * torch.outer(mh1, mh1)
-        Gp = ops.trunk_bwd_gather(x, T, w1, b1f, s1cf, t1cf, w2p, s2cf, t2cf, idx, coef)
-        G = Gp.sum(0, dtype=F64)
-        dW3 = G - s3[:, None] * (m1[:, None] * sh[None, :] + (m2 / sig3)[:, None] * (W3d @ Sc))
+        dev = x.device
+        blk = B * S
+        s1c, t1c, is1, nm1 = chan1[0], chan1[1], chan1[2], chan1[3]
+        s2c, t2c, is2, nm2 = chan2[0], chan2[1], chan2[2], chan2[3]
+        # ---- BN3 affine grads, sparse-term weights, dense-correction scalars
+        dp = dp.contiguous()
+        coef, dg3, dbe3, m12 = _e(dev, B, 1024), _e(dev, 1024), _e(dev, 1024), _e(dev, 2048, dtype=F64)
+        _call("pngpd_bn3_bwd_prep", x, dp, pooled, zhat, B, N, g3c, stats3, eps, int(ctx.relu_last), coef, dg3,
+              dbe3, m12)
+        # ---- hidden-activation moments + arg-extremum gather, reduced in fp64
+        ps2, ps1, psh = ops.trunk_h_moments(x, T, w1, b1c, s1c, t1c, w2p, s2c, t2c)
+        S2 = _reduce(ps2, 1, B, 128 * 128)[0]
+        sh = _reduce(psh, 1, B, 192)[0][:128]
+        Gp = ops.trunk_bwd_gather(x, T, w1, b1c, s1c, t1c, w2p, s2c, t2c, idx, coef)
+        G = _reduce(Gp, 1, Gp.shape[0], 1024 * 128)[0]
+        dW3, Ap, cvec = _e(dev, 1024, 128), _e(dev, 128 * 128), _e(dev, 128)
+        _call("pngpd_dw3_finalize", x, G, S2, sh, B, N, w3, g3c, stats3, m12, eps, dW3, Ap, cvec)
         # ---- pass D
-        Dv = g3d * m2 / (sig3 * sig3)
-        A = W3d.T @ (Dv[:, None] * W3d)
-        A = 0.5 * (A + A.T)
-        u = W3d.T @ (s3 * m1)
-        cvec = f32(A @ mh - u)
-        Ap = ops.pack_mfma_b(f32(A))
-        g2buf, pa, pP = ops.trunk_bwd_d(x, T, w1, b1f, s1cf, t1cf, w2p, s2cf, t2cf, is2f, nm2f, Ap, cvec, w3,
-                                        idx, coef)
-        pas = pa.sum(0, dtype=F64)
-        a1, a2 = pas[:, 0], pas[:, 1]
-        Pm = pP.sum(0, dtype=F64)
-        sig2 = torch.sqrt(var2 + eps)
-        s2 = g2d / sig2
-        dW2 = s2[:, None] * (Pm - (a1 / M)[:, None] * sh1[None, :] - (a2 / (M * sig2))[:, None] * (W2d @ Sc1))
-        # ---- pass E
+        g2buf, pa = ops.trunk_bwd_d(x, T, w1, b1c, s1c, t1c, w2p, s2c, t2c, is2, nm2, Ap, cvec, w3, idx, coef)
+        a12 = _reduce(pa, 1, blk, 256)[0]
+        dg2, dbe2, evec = _e(dev, 128), _e(dev, 128), _e(dev, 3, 128)
+        _call("pngpd_bwd_e_prep", x, a12, B, N, g2c, stats2, eps, dg2, dbe2, evec)
+        # ---- pass E (also contracts dW2 = sum_points dz2 h1^T on the MFMA)
         w2tp = ops.pack_mfma_b(w2.t().contiguous())
-        pc, pR = ops.trunk_bwd_e(x, T, w1, b1f, s1cf, t1cf, w2p, is1f, nm1f, is2f, nm2f, f32(a1 / M), f32(a2 / M),
-                                 f32(s2), w2tp, g2buf)
-        pcs = pc.sum(0, dtype=F64)
-        c1, c2 = pcs[:, 0], pcs[:, 1]
-        Rb = pR.sum(1, dtype=F64)                      # (B,64,3)
-        sig1 = torch.sqrt(var1 + eps)
-        s1 = g1d / sig1
-        if T is not None:
-            T64 = T.to(F64)
-            Rp = torch.einsum("bci,bij->cj", Rb, T64)
-        else:
-            Rp = Rb.sum(0)
-        dW1 = s1[:, None] * (Rp - (c1 / M)[:, None] * (mx * M)[None, :]
-                             - (c2 / (M * sig1))[:, None] * (W1d @ (Cx * M)))
-        dT = None
-        if T is not None and ctx.needs_input_grad[1]:
-            Sx_xp = torch.einsum("bik,bkj->bij", S_b, T64)
-            b1d = b1f.to(F64)
-            term3 = (torch.einsum("bij,cj->bic", Sx_xp, W1d) + m_b[:, :, None] * (b1d - mu1)[None, None, :]) \
-                / sig1[None, None, :]
-            Y = s1[None, None, :] * (Rb.transpose(1, 2) - m_b[:, :, None] * (c1 / M)[None, None, :]
-                                     - term3 * (c2 / M)[None, None, :])
-            dT = torch.einsum("bic,cj->bij", Y, W1d).to(torch.float32)
+        pc, pR, pW2 = ops.trunk_bwd_e(x, T, w1, b1c, s1c, t1c, w2p, is1, nm1, is2, nm2, evec[0], evec[1], evec[2],
+                                      w2tp, g2buf)
+        dW2 = _reduce(pW2, 1, blk, 128 * 64)[0].to(torch.float32)
+        c12 = _reduce(pc, 1, blk, 128)[0]
+        Rb = _reduce(pR, B, S, 192)
+        dW1, dg1, dbe1 = _e(dev, 64, 3), _e(dev, 64), _e(dev, 64)
+        dT = _e(dev, B, 3, 3) if (T is not None and ctx.needs_input_grad[1]) else None
+        _call("pngpd_dw1_finalize", x, Rb, T, mom, B, N, c12, stats1, w1, b1c, g1c, eps, dW1, dg1, dbe1, dT)
         if DEBUG_STASH is not None:
-            DEBUG_STASH.update(dict(dp=dp, dg3=dg3, dbe3=dbe3, S2=S2, S1=S1, sh=sh, sh1=sh1, G=G, A=A, cvec=cvec,
-                                    a1=a1, a2=a2, Pm=Pm, c1=c1, c2=c2, Rb=Rb, dW1=dW1, dW2=dW2, dW3=dW3, dT=dT,
-                                    g2buf=g2buf, idx=idx, coef=coef))
-        z = lambda t: torch.zeros_like(t, dtype=torch.float32)
-        o = lambda t, ref: t.to(torch.float32).reshape(ref)
+            DEBUG_STASH.update(dict(dp=dp.to(F64), dg3=dg3, dbe3=dbe3, S2=S2.view(128, 128), sh=sh,
+                                    G=G.view(1024, 128), cvec=cvec, a1=a12.view(128, 2)[:, 0],
+                                    a2=a12.view(128, 2)[:, 1], c1=c12.view(64, 2)[:, 0],
+                                    c2=c12.view(64, 2)[:, 1], Rb=Rb.view(B, 64, 3), dW1=dW1, dW2=dW2, dW3=dW3, dT=dT,
+                                    g2buf=g2buf, idx=idx, coef=coef,
+                                    A=Ap.view(4, 16, 2, 32, 4).permute(0, 3, 1, 2, 4).reshape(128, 128)))
+        z = lambda n: torch.zeros(n, device=dev, dtype=torch.float32)
         return (None, dT,
-                o(dW1, (64, 3, 1)), z(b1f), o(c2, (64,)), o(c1, (64,)),
-                o(dW2, (128, 64, 1)), z(g2), o(a2, (128,)), o(a1, (128,)),
-                o(dW3, (1024, 128, 1)), z(g3), o(dg3, (1024,)), o(dbe3, (1024,)),
+                dW1.view(64, 3, 1), z(64), dg1, dbe1,
+                dW2.view(128, 64, 1), z(128), dg2, dbe2,
+                dW3.view(1024, 128, 1), z(1024), dg3, dbe3,
                 None, None, None, None, None, None)
 
 
@@ -216,8 +173,20 @@ def _linear_bwd(g, inp, W):
     gp = _pad_cols(g)                          # (B, Nout')
     wt = _pad_cols(W.t())                      # (K, Nout')
     dinp = ops.fc_fwd(gp, wt, zero_k, ops.EPI_NONE)        # (B, K)
-    db = g.sum(0)
+    db = _reduce(g.contiguous(), 1, g.shape[0], Nout)[0].to(torch.float32)
     return dinp, dW, db
+
+
+def _update_running(buffers, mean, var_biased, count, momentum):
+    """nn.BatchNorm1d running-stat update for the (B,C) FC BatchNorms (tiny (C,) tensors)."""
+    if buffers is None:
+        return
+    rm, rv, nbt = buffers
+    with torch.no_grad():
+        rm.mul_(1 - momentum).add_(mean, alpha=momentum)
+        rv.mul_(1 - momentum).add_(var_biased, alpha=momentum * count / max(count - 1, 1))
+        if nbt is not None:
+            nbt.add_(1)
 
 
 class LinearBnReluFn(torch.autograd.Function):
