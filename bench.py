@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--classes", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step leg")
+    ap.add_argument("--no-fast", action="store_true", help="skip the opt-in bf16x3 inference leg")
     ap.add_argument("--graph", action="store_true", help="also time the train step replayed from a HIP graph")
     args = ap.parse_args()
 
@@ -135,6 +136,32 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     assert torch.isfinite(out).all()
+
+    # ---- opt-in fast path: the same forward with the trunk on split-bf16 (bf16x3) matrix-core products
+    fast_res = None
+    if not args.no_fast:
+        from pointnetgpd_amd.model import pointnet as pn
+        pn.set_inference_precision("bf16x3")
+        try:
+            with torch.no_grad():
+                for _ in range(args.warmup):
+                    fout, _ = model(x)
+                sync_all()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    fout, _ = model(x)
+                sync_all()
+                fdt = time.perf_counter() - t0
+            if dist is not None:
+                t = torch.tensor([fdt], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                fdt = t.item()
+            fast_res = {"mode": "bf16x3 split products on v_mfma_f32_32x32x16_bf16, fp32 accumulate (opt-in)",
+                        "value": round(world * B * args.steps / fdt, 1), "unit": "grasps/s",
+                        "ms_per_step": round(fdt / args.steps * 1e3, 4),
+                        "max_abs_dlogp_vs_fp32": float((fout - out).abs().max().item())}
+        finally:
+            pn.set_inference_precision("fp32")
 
     # ---- training step (main_1v.py:72-76): forward (batch-stat BN) + nll_loss + backward + Adam
     train_res = None
@@ -264,6 +291,8 @@ def main():
                          "avg_launch_ms": round(trunk_ms, 4),
                          "flops_per_launch": trunk_flops},
         }
+        if fast_res is not None:
+            res["infer_fast_bf16x3"] = fast_res
         if train_res is not None:
             res["train"] = train_res
         if not args.no_cpu_baseline and world == 1:

@@ -98,6 +98,19 @@ int pngpd_trunk_fwd_infer(const float *x, int B, int N, const float *trans,
 int pngpd_fc_fwd(const float *in, int B, int K, const float *W, const float *bias, int Nout,
                  int epilogue, float *out, void *stream);
 
+/*
+ * OPT-IN fast inference trunk ("bf16x3"): same contract as pngpd_trunk_fwd_infer, but the two GEMM layers run
+ * as 3-term split-bf16 products on v_mfma_f32_32x32x16_bf16 (a*w ~= a_hi*w_hi + a_hi*w_lo + a_lo*w_hi, fp32
+ * accumulate; relative product error <= ~2^-16).  Not bit-identical to fp32 arithmetic; log-probs stay within
+ * 1e-4 of the fp32 path.  w2x / w3x = pngpd_split_pack_bf16 of the BN-folded ROWMAJOR (128,64) / (1024,128)
+ * weights (2*C*K halfwords each).
+ */
+int pngpd_split_pack_bf16(const float *W, int C, int K, void *out, void *stream);
+int pngpd_trunk_fwd_infer_x3(const float *x, int B, int N, const float *trans,
+                             const float *w1, const float *b1, const void *w2x, const float *b2,
+                             const void *w3x, const float *b3, int relu_last,
+                             float *out_pool, void *workspace, size_t workspace_bytes, void *stream);
+
 /* =======================================================================================
  * Training path (batch-statistics BatchNorm, backward).  The trunk's forward/backward is a
  * sequence of recompute passes (DESIGN.md "Training passes"); the host composes them

@@ -1,0 +1,270 @@
+// libpngpd — OPT-IN fast inference trunk: the same fused per-point MLP + max-pool as pngpd_trunk_infer.hip,
+// with the two GEMM layers evaluated by "bf16x3" split arithmetic on the bf16 matrix cores:
+//     a = a_hi + a_lo,  w = w_hi + w_lo  (each part bf16, hi = rne(a), lo = rne(a - hi))
+//     a*w ~= a_hi*w_hi + a_hi*w_lo + a_lo*w_hi        (products exact in fp32, fp32 accumulate)
+// i.e. 3 v_mfma_f32_32x32x16_bf16 (16x the fp32-MFMA rate each) per fp32 product block.  The dropped
+// a_lo*w_lo term and the 16-bit split bound the relative error of every product by ~2^-16 (1.5e-5):
+// log-probabilities stay within 1e-4 of the exact-fp32 path (tests), inside the 1e-3 contract, but the
+// result is NOT bit-identical to fp32 arithmetic — hence opt-in (precision="bf16x3").
+//
+// One workgroup = 512 threads = 8 waves (2 per SIMD), one cloud, tiles of 128 points.
+//   LDS: h1 hi/lo [128][72] bf16, h2 hi/lo [128][136] bf16 (+8 halfword row pad: conflict-free
+//   ds_read_b128), xs [3][128] f32, running max [1024] f32  ->  ~112 KB, one workgroup per CU.
+#include "pngpd_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+#define XP 128          // points per tile
+#define X1S 72          // h1 row stride (halfwords)
+#define X2S 136         // h2 row stride (halfwords)
+#define X3_LDS_BYTES (2 * XP * X1S * 2 + 2 * XP * X2S * 2 + 3 * XP * 4 + 1024 * 4)
+
+__device__ __forceinline__ u16 bf16_bits(float x) { return __builtin_bit_cast(u16, (__bf16)x); }
+__device__ __forceinline__ float bf16_val(u16 b) { return __uint_as_float(((unsigned)b) << 16); }
+
+__device__ __forceinline__ void split2(float x, u16 &hi, u16 &lo) {
+    hi = bf16_bits(x);
+    lo = bf16_bits(x - bf16_val(hi));
+}
+
+__device__ __forceinline__ f32x16 mfma_bf(const f32x4 &a, const f32x4 &b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                   c, 0, 0, 0);
+}
+
+// (C,K) fp32 row-major -> hi/lo bf16 in 32x32x16 B-fragment order:
+//   out[(((cb*KS + ks)*2 + part)*64 + lane)*8 + t] = part(W[cb*32 + (lane&31)][ks*16 + (lane>>5)*8 + t])
+__global__ void split_pack_bf16_kernel(const float *__restrict__ W, int C, int K, u16 *__restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= C * K) return;
+    const int c = idx / K, k = idx - c * K;
+    u16 hi, lo;
+    split2(W[idx], hi, lo);
+    const int cb = c >> 5, j = c & 31, ks = k >> 4, h = (k >> 3) & 1, t = k & 7, KS = K >> 4;
+    const size_t base = ((size_t)(cb * KS + ks) * 2) * 64 * 8 + (size_t)(h * 32 + j) * 8 + t;
+    out[base] = hi;
+    out[base + 64 * 8] = lo;
+}
+
+template <int KS>
+__device__ __forceinline__ void load_wx(f32x4 (&wh)[KS], f32x4 (&wl)[KS], const u16 *__restrict__ wx, int cb, int lane) {
+    const f32x4 *p = (const f32x4 *)wx + (size_t)(cb * KS) * 2 * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { wh[ks] = p[(ks * 2) * 64]; wl[ks] = p[(ks * 2 + 1) * 64]; }
+}
+
+__global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
+    const float *__restrict__ x, int N, const float *__restrict__ trans,
+    const float *__restrict__ w1, const float *__restrict__ b1,
+    const u16 *__restrict__ w2x, const float *__restrict__ b2,
+    const u16 *__restrict__ w3x, const float *__restrict__ b3,
+    int relu_last, int T, int S, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u16 *h1h = (u16 *)smem_raw;                 // [XP][X1S]
+    u16 *h1l = h1h + XP * X1S;
+    u16 *h2h = h1l + XP * X1S;                  // [XP][X2S]
+    u16 *h2l = h2h + XP * X2S;
+    float *xs = (float *)(h2l + XP * X2S);      // [3][XP]
+    float *rm = xs + 3 * XP;                    // [1024]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int b = blockIdx.x / S, s = blockIdx.x - b * S;
+    const int t0 = (int)(((long)s * T) / S), t1 = (int)(((long)(s + 1) * T) / S);
+    const float *xb = x + (size_t)b * 3 * N;
+    float tm[9] = {0};
+    const bool has_t = trans != nullptr;
+    if (has_t) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) tm[i] = trans[(size_t)b * 9 + i];
+    }
+    for (int i = tid; i < 1024; i += 512) rm[i] = -INFINITY;
+
+#ifndef X3_PREFETCH
+#define X3_PREFETCH 0
+#endif
+    // layer-3 weight fragments (hi+lo of one 32-channel block = 64 VGPRs); optionally double-buffered
+    f32x4 wah[8], wal[8];
+#if X3_PREFETCH
+    f32x4 wbh[8], wbl[8];
+    load_wx<8>(wah, wal, w3x, wave, lane);
+#endif
+
+    float px0 = 0.f, px1 = 0.f, px2 = 0.f;
+    if (tid < XP) {
+        int n = t0 * XP + tid; n = n < N ? n : N - 1;
+        px0 = xb[n]; px1 = xb[N + n]; px2 = xb[2 * N + n];
+    }
+
+    for (int tile = t0; tile < t1; ++tile) {
+        if (tid < XP) {
+            float x0 = px0, x1 = px1, x2 = px2;
+            if (has_t) {
+                x0 = fmaf(px2, tm[6], fmaf(px1, tm[3], px0 * tm[0]));
+                x1 = fmaf(px2, tm[7], fmaf(px1, tm[4], px0 * tm[1]));
+                x2 = fmaf(px2, tm[8], fmaf(px1, tm[5], px0 * tm[2]));
+            }
+            xs[tid] = x0; xs[XP + tid] = x1; xs[2 * XP + tid] = x2;
+            if (tile + 1 < t1) {
+                int n = (tile + 1) * XP + tid; n = n < N ? n : N - 1;
+                px0 = xb[n]; px1 = xb[N + n]; px2 = xb[2 * N + n];
+            }
+        }
+        __syncthreads();
+        {   // layer 1 (fp32 VALU): thread = (point p = tid & 127, 16-channel group g = tid >> 7 = wave >> 1)
+            const int p = tid & 127, g = wave >> 1;
+            const float x0 = xs[p], x1 = xs[XP + p], x2 = xs[2 * XP + p];
+            u16 hv[16], lv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int c = g * 16 + e;   // wave-uniform -> scalar loads
+                const float z = fmaxf(fmaf(w1[c * 3 + 2], x2, fmaf(w1[c * 3 + 1], x1, fmaf(w1[c * 3], x0, b1[c]))), 0.f);
+                split2(z, hv[e], lv[e]);
+            }
+            uint4 *dh = (uint4 *)(h1h + p * X1S + g * 16), *dl = (uint4 *)(h1l + p * X1S + g * 16);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                uint4 vh, vl;
+                vh.x = hv[q * 8 + 0] | ((unsigned)hv[q * 8 + 1] << 16); vh.y = hv[q * 8 + 2] | ((unsigned)hv[q * 8 + 3] << 16);
+                vh.z = hv[q * 8 + 4] | ((unsigned)hv[q * 8 + 5] << 16); vh.w = hv[q * 8 + 6] | ((unsigned)hv[q * 8 + 7] << 16);
+                vl.x = lv[q * 8 + 0] | ((unsigned)lv[q * 8 + 1] << 16); vl.y = lv[q * 8 + 2] | ((unsigned)lv[q * 8 + 3] << 16);
+                vl.z = lv[q * 8 + 4] | ((unsigned)lv[q * 8 + 5] << 16); vl.w = lv[q * 8 + 6] | ((unsigned)lv[q * 8 + 7] << 16);
+                dh[q] = vh; dl[q] = vl;
+            }
+        }
+        __syncthreads();
+        {   // layer 2 (64 -> 128), bf16x3: wave owns channel block cb = wave & 3 and point blocks 2q, 2q+1
+            const int cb = wave & 3, pb0 = (wave >> 2) * 2;
+            f32x4 w2h[4], w2l[4];
+            load_wx<4>(w2h, w2l, w2x, cb, lane);
+            f32x16 a0 = {0}, a1 = {0};
+            const int r0 = (pb0 * 32 + j) * X1S + h * 8, r1 = ((pb0 + 1) * 32 + j) * X1S + h * 8;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const f32x4 ah0 = *(const f32x4 *)(h1h + r0 + ks * 16), al0 = *(const f32x4 *)(h1l + r0 + ks * 16);
+                const f32x4 ah1 = *(const f32x4 *)(h1h + r1 + ks * 16), al1 = *(const f32x4 *)(h1l + r1 + ks * 16);
+                a0 = mfma_bf(ah0, w2h[ks], a0); a1 = mfma_bf(ah1, w2h[ks], a1);
+                a0 = mfma_bf(ah0, w2l[ks], a0); a1 = mfma_bf(ah1, w2l[ks], a1);
+                a0 = mfma_bf(al0, w2h[ks], a0); a1 = mfma_bf(al1, w2h[ks], a1);
+            }
+            const float bias = b2[cb * 32 + j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mfma_row(r, lane);
+                u16 hi, lo;
+                split2(fmaxf(a0[r] + bias, 0.f), hi, lo);
+                h2h[(pb0 * 32 + row) * X2S + cb * 32 + j] = hi; h2l[(pb0 * 32 + row) * X2S + cb * 32 + j] = lo;
+                split2(fmaxf(a1[r] + bias, 0.f), hi, lo);
+                h2h[((pb0 + 1) * 32 + row) * X2S + cb * 32 + j] = hi; h2l[((pb0 + 1) * 32 + row) * X2S + cb * 32 + j] = lo;
+            }
+        }
+        __syncthreads();
+        // layer 3 (128 -> 1024), bf16x3: wave owns channel blocks wave + 8*ci, all four point blocks
+        auto block = [&](const f32x4 (&wh)[8], const f32x4 (&wl)[8], int cb) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int qp = 0; qp < 2; ++qp) {   // two point blocks at a time: 32 accumulator registers live
+                f32x16 c0 = {0}, c1 = {0};
+                const int ro0 = ((2 * qp) * 32 + j) * X2S + h * 8, ro1 = ((2 * qp + 1) * 32 + j) * X2S + h * 8;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const f32x4 ah0 = *(const f32x4 *)(h2h + ro0 + ks * 16), al0 = *(const f32x4 *)(h2l + ro0 + ks * 16);
+                    const f32x4 ah1 = *(const f32x4 *)(h2h + ro1 + ks * 16), al1 = *(const f32x4 *)(h2l + ro1 + ks * 16);
+                    c0 = mfma_bf(ah0, wh[ks], c0); c1 = mfma_bf(ah1, wh[ks], c1);
+                    c0 = mfma_bf(ah0, wl[ks], c0); c1 = mfma_bf(ah1, wl[ks], c1);
+                    c0 = mfma_bf(al0, wh[ks], c0); c1 = mfma_bf(al1, wh[ks], c1);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m = fmaxf(m, fmaxf(c0[r], c1[r]));
+            }
+            m = fmaxf(m, __shfl_xor(m, 32));
+            if (h == 0) rm[cb * 32 + j] = fmaxf(rm[cb * 32 + j], m);
+        };
+#if X3_PREFETCH
+#pragma unroll 1
+        for (int cp = 0; cp < 2; ++cp) {
+            const int cbA = wave + 16 * cp, cbB = cbA + 8, cbN = wave + ((16 * cp + 16) & 31);
+            load_wx<8>(wbh, wbl, w3x, cbB, lane);
+            block(wah, wal, cbA);
+            load_wx<8>(wah, wal, w3x, cbN, lane);
+            block(wbh, wbl, cbB);
+        }
+#else
+#pragma unroll 1
+        for (int ci = 0; ci < 4; ++ci) {
+            load_wx<8>(wah, wal, w3x, wave + 8 * ci, lane);
+            block(wah, wal, wave + 8 * ci);
+        }
+#endif
+        // the barrier after the next tile's layer 1 orders the h2 rewrite after these reads
+    }
+    if (h == 0) {
+        float *o = out + ((size_t)b * S + s) * 1024;
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci) {
+            const int c = (wave + 8 * ci) * 32 + j;
+            float v = rm[c] + b3[c];
+            if (relu_last) v = fmaxf(v, 0.f);
+            o[c] = v;
+        }
+    }
+}
+
+__global__ void pool_reduce_x3_kernel(const float *__restrict__ part, int S, float *__restrict__ out, int total) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    int b = idx >> 10, c = idx & 1023;
+    const float *p = part + (size_t)b * S * 1024 + c;
+    float m = p[0];
+    for (int s = 1; s < S; ++s) m = fmaxf(m, p[(size_t)s * 1024]);
+    out[idx] = m;
+}
+
+static int g_x3_target_blocks = 1024;
+
+extern "C" {
+
+int pngpd_split_pack_bf16(const float *W, int C, int K, void *out, void *stream) {
+    if (!W || !out || C <= 0 || K <= 0 || (C & 31) || (K & 15)) return PNGPD_ERR_INVALID_ARG;
+    const int total = C * K;
+    hipLaunchKernelGGL(split_pack_bf16_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       W, C, K, (u16 *)out);
+    return pngpd_launch_status();
+}
+
+int pngpd_trunk_fwd_infer_x3(const float *x, int B, int N, const float *trans,
+                             const float *w1, const float *b1, const void *w2x, const float *b2,
+                             const void *w3x, const float *b3, int relu_last,
+                             float *out_pool, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!x || !w1 || !b1 || !w2x || !b2 || !w3x || !b3 || !out_pool || B <= 0 || N <= 0)
+        return PNGPD_ERR_INVALID_ARG;
+    const int T = (N + XP - 1) / XP;
+    int S = (g_x3_target_blocks + B - 1) / B;
+    if (S < 1) S = 1;
+    if (S > T) S = T;
+    float *dst = out_pool;
+    if (S > 1) {
+        if (!workspace || workspace_bytes < (size_t)B * S * 1024 * sizeof(float)) return PNGPD_ERR_WORKSPACE;
+        dst = (float *)workspace;
+    }
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute((const void *)trunk_infer_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
+        attr = true;
+    }
+    hipLaunchKernelGGL(trunk_infer_x3_kernel, dim3((unsigned)B * S), dim3(512), X3_LDS_BYTES, (hipStream_t)stream,
+                       x, N, trans, w1, b1, (const u16 *)w2x, b2, (const u16 *)w3x, b3, relu_last, T, S, dst);
+    int st = pngpd_launch_status();
+    if (st != PNGPD_OK) return st;
+    if (S > 1) {
+        const int total = B * 1024;
+        hipLaunchKernelGGL(pool_reduce_x3_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                           (const float *)workspace, S, out_pool, total);
+        st = pngpd_launch_status();
+    }
+    return st;
+}
+
+}  // extern "C"

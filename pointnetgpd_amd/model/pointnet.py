@@ -28,6 +28,28 @@ from .. import ops, train
 
 _TRUNK_WIDTHS = (64, 128, 1024)
 
+# Inference arithmetic of the fused trunk: "fp32" (exact fp32 MFMA, default) or "bf16x3" (opt-in: 3-term
+# split-bf16 products on the bf16 matrix cores, ~1e-5 relative error, not bit-identical to fp32).
+_INFER_PRECISION = "fp32"
+
+
+def set_inference_precision(mode):
+    global _INFER_PRECISION
+    if mode not in ("fp32", "bf16x3"):
+        raise ValueError("precision must be 'fp32' or 'bf16x3'")
+    _INFER_PRECISION = mode
+
+
+def get_inference_precision():
+    return _INFER_PRECISION
+
+
+def _trunk_infer(mod, x, trans, relu_last):
+    """Eval-mode fused trunk of a module holding conv1..3 / bn1..3 in the selected arithmetic."""
+    if _INFER_PRECISION == "bf16x3":
+        return ops.trunk_fwd_infer_x3(x, trans, *_trunk_infer_weights_x3(mod, x.device), relu_last=relu_last)
+    return ops.trunk_fwd_infer(x, trans, *_trunk_infer_weights(mod, x.device), relu_last=relu_last)
+
 
 def _check_points(x, num_points, input_chann):
     if x.dim() != 3 or x.shape[1] != input_chann:
@@ -97,6 +119,22 @@ def _trunk_infer_weights(mod, device):
         return (w1, b1, w2, b2, w3, b3)
 
     return mod._cache().get(("trunk", device), srcs, build)
+
+
+def _trunk_infer_weights_x3(mod, device):
+    """Folded weights for pngpd_trunk_fwd_infer_x3: layer 1 fp32, layers 2/3 split into bf16 hi/lo."""
+    srcs = []
+    for i in (1, 2, 3):
+        conv, bn = getattr(mod, f"conv{i}"), getattr(mod, f"bn{i}")
+        srcs += [conv.weight, conv.bias] + _bn_tensors(bn)
+
+    def build():
+        w1, b1 = _fold(mod.conv1, mod.bn1, ops.LAYOUT_ROWMAJOR, device)
+        w2, b2 = _fold(mod.conv2, mod.bn2, ops.LAYOUT_ROWMAJOR, device)
+        w3, b3 = _fold(mod.conv3, mod.bn3, ops.LAYOUT_ROWMAJOR, device)
+        return (w1, b1, ops.split_pack_bf16(w2), b2, ops.split_pack_bf16(w3), b3)
+
+    return mod._cache().get(("trunk_x3", device), srcs, build)
 
 
 def _fc_infer_weights(mod, names, device):
@@ -171,7 +209,7 @@ class STN3d(_HipModule):
     def _forward_hip_infer(self, x):
         dev = x.device
         x = x.contiguous()
-        pooled = ops.trunk_fwd_infer(x, None, *_trunk_infer_weights(self, dev), relu_last=True)
+        pooled = _trunk_infer(self, x, None, relu_last=True)
         (w1, b1), (w2, b2), (w3, b3) = _fc_infer_weights(self, [("fc1", "bn4"), ("fc2", "bn5"), ("fc3", None)], dev)
         g = ops.fc_fwd(pooled, w1, b1, ops.EPI_RELU)
         g = ops.fc_fwd(g, w2, b2, ops.EPI_RELU)
@@ -200,9 +238,7 @@ class PointNetfeat(_HipModule):
             trans = self.stn(x)
             if self.training:
                 return train.trunk_train(self, x, trans.contiguous(), relu_last=False), trans
-            pooled = ops.trunk_fwd_infer(x, trans.contiguous(), *_trunk_infer_weights(self, x.device),
-                                         relu_last=False)
-            return pooled, trans
+            return _trunk_infer(self, x, trans.contiguous(), relu_last=False), trans
         # ATen composite: CPU plumbing path, and the (never used) global_feat=False branch.
         trans = self.stn(x)
         x = torch.bmm(x.transpose(2, 1), trans).transpose(2, 1)

@@ -84,6 +84,39 @@ def trunk_fwd_infer(x, trans, w1, b1, w2p, b2, w3p, b3, relu_last):
     return out
 
 
+def split_pack_bf16(Wf):
+    """(C,K) BN-folded fp32 row-major -> hi/lo bf16 fragments for the bf16x3 trunk (int16 tensor, 2*C*K)."""
+    lib = _lib.load()
+    Wf = _req(Wf.contiguous(), "Wf")
+    C, K = Wf.shape
+    out = torch.empty(2 * C * K, device=Wf.device, dtype=torch.int16)
+    with torch.cuda.device(Wf.device):
+        _lib.check(lib.pngpd_split_pack_bf16(_ptr(Wf), C, K, _ptr(out), _stream(Wf)), "split_pack_bf16")
+    return out
+
+
+def trunk_fwd_infer_x3(x, trans, w1, b1, w2x, b2, w3x, b3, relu_last):
+    """bf16x3 variant of trunk_fwd_infer (see include/pngpd.h)."""
+    lib = _lib.load()
+    _req(x, "x")
+    if x.dim() != 3 or x.shape[1] != 3:
+        raise RuntimeError(f"x: expected (B,3,N), got {tuple(x.shape)}")
+    B, _, N = x.shape
+    if trans is not None:
+        _req(trans, "trans", (B, 3, 3))
+    _req(w1, "w1", (64, 3)); _req(b1, "b1", (64,)); _req(b2, "b2", (128,)); _req(b3, "b3", (1024,))
+    if w2x.dtype != torch.int16 or w2x.numel() != 2 * 128 * 64 or w3x.dtype != torch.int16 or w3x.numel() != 2 * 1024 * 128:
+        raise RuntimeError("w2x/w3x: expected split_pack_bf16 outputs")
+    out = torch.empty(B, 1024, device=x.device, dtype=torch.float32)
+    nbytes = lib.pngpd_trunk_workspace_bytes(B, N)
+    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.pngpd_trunk_fwd_infer_x3(_ptr(x), B, N, _ptr(trans), _ptr(w1), _ptr(b1), _ptr(w2x), _ptr(b2),
+                                                _ptr(w3x), _ptr(b3), int(bool(relu_last)), _ptr(out), _ptr(ws),
+                                                nbytes, _stream(x)), "trunk_fwd_infer_x3")
+    return out
+
+
 def fc_fwd(inp, W, bias, epilogue):
     """out = epilogue(inp @ W^T + bias).  inp (B,K), W (Nout,K)."""
     lib = _lib.load()
