@@ -75,7 +75,7 @@ __device__ __forceinline__ void layer2_mfma(const float *h1, const float *__rest
     const float *a1p = h1 + (32 + L.j) * H1S + L.h * 4;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-#pragma unroll
+#pragma unroll 4
     for (int kb = 0; kb < 8; ++kb) {
         f32x4 wv = wp[kb * 64];
         f32x4 a0 = *(const f32x4 *)(a0p + kb * 8);

@@ -210,7 +210,8 @@ __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
-// h-moments pass: S2 = sum h2 h2^T (128x128), S1 = sum h1 h1^T (64x64), column sums.
+// h-moments pass: S2 = sum h2 h2^T (128x128) and the column sums of h2 (ps1 / psh[128:] are kept in the
+// interface for layout stability and written as zeros: dW2 is contracted directly in pass E).
 // One workgroup per cloud (all its tiles).  Contraction over points on the MFMA:
 //   D[i][j] += A[i][k=point] * B[k=point][j]  with A = B = the LDS tile read column-wise.
 //   ps2 [blk][128][128]  ps1 [blk][64][64]  psh [blk][128+64]
@@ -259,13 +260,6 @@ __global__ __launch_bounds__(256, 1) void trunk_h_moments_kernel(
             }
         }
         __syncthreads();
-        if (nbase + TP > N) {   // tail tile: zero the replicated rows of h1 (block-uniform branch)
-            for (int i = L.tid; i < TP * 64; i += 256) {
-                const int row = i >> 6, c = i & 63;
-                if (nbase + row >= N) h1[row * H1S + c] = 0.f;
-            }
-            __syncthreads();
-        }
         // S2: wave owns row block ib = wave, all four column blocks
         {
             const int ib = L.wave;
@@ -276,18 +270,10 @@ __global__ __launch_bounds__(256, 1) void trunk_h_moments_kernel(
 #pragma unroll
                 for (int q = 0; q < 4; ++q) s2a[q] = mfma32(av, rowp[q * 32], s2a[q]);
             }
-            const int i1 = L.wave >> 1, j1 = L.wave & 1;
-#pragma unroll 4
-            for (int st = 0; st < 32; ++st) {
-                const float *rowp = h1 + (2 * st + L.h) * H1S + L.j;
-                s1a = mfma32(rowp[i1 * 32], rowp[j1 * 32], s1a);
-            }
         }
         // column sums: threads 0..127 -> h2 column, 128..191 -> h1 column
         if (L.tid < 128) {
             for (int r = 0; r < TP; ++r) colsum += h2[r * H2S + L.tid];
-        } else if (L.tid < 192) {
-            for (int r = 0; r < TP; ++r) colsum += h1[r * H1S + (L.tid - 128)];
         }
         __syncthreads();
     }
@@ -386,20 +372,21 @@ struct BwdDParams {
     const int *idx;             // (B,1024)
     const float *coef;          // (B,1024)
 };
-// LDS: h2 tile + one tile that is first h1 (dead after layer 2) and then the sparse term -> 72.5 KB,
-// two workgroups per CU.
-#define BWD_D_LDS_FLOATS (2 * TP * H2S + 3 * TP + 4 * 256 + 4)
+// LDS: h2 tile + one tile that is first h1 (dead after layer 2), then the sparse term, then the g2 tile on
+// its way to HBM; the cloud's coef row; parity-split hit lists  ->  76.6 KB, two workgroups per CU.
+#define BWD_D_LDS_FLOATS (2 * TP * H2S + 3 * TP + 1024 + 1024 + 8)
 
 __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
     const float *__restrict__ x, int N, const float *__restrict__ trans, TrainChan P, BwdDParams D,
     int T, int S, float *__restrict__ g2buf, float *__restrict__ pa) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *h2 = smem;
-    float *sp = h2 + TP * H2S;            // h1 during layers 1-2, then the sparse term
+    float *sp = h2 + TP * H2S;            // h1 during layers 1-2, then the sparse term, then g2
     float *h1 = sp;
     float *xs = sp + TP * H2S;
-    int *hits = (int *)(xs + 3 * TP);     // [4][256]  (c << 8) | local point
-    int *hcnt = hits + 4 * 256;           // [4]
+    float *cfl = xs + 3 * TP;             // [1024] coef row of this cloud
+    unsigned short *hits = (unsigned short *)(cfl + 1024);   // [2 parities][4 waves][256]: (c << 6) | local point
+    int *hcnt = (int *)(hits + 2 * 4 * 256);                 // [2][4]
     const Lane L;
     const int b = blockIdx.x / S, s = blockIdx.x - b * S;
     int t0, t1; tile_range(s, S, T, t0, t1);
@@ -411,32 +398,47 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
         for (int i = 0; i < 9; ++i) tm[i] = trans[(size_t)b * 9 + i];
     }
     const int *idxb = D.idx + (size_t)b * 1024;
-    const float *coefb = D.coef + (size_t)b * 1024;
+    for (int i = L.tid; i < 1024; i += 256) cfl[i] = D.coef[(size_t)b * 1024 + i];
     float a1s = 0.f, a2s = 0.f;
     const int cb = L.wave;
     const int c2 = cb * 32 + L.j;
     const float sc2 = P.s2c[c2], sh2 = P.t2c[c2], is2 = D.is2[c2], nm2 = D.nm2[c2], cv = D.cvec[c2];
+    // coalesced hand-off of a finished g2 tile (in sp) to HBM: 8 x 16 B per thread, whole 512-B rows
+    auto flush_tile = [&](int tile) {
+        const int nb = tile * TP;
+        float *gt = g2buf + ((size_t)b * N + nb) * 128;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int q = L.tid + 256 * i, row = q >> 5, col = (q & 31) * 4;
+            if (nb + row < N) *(f32x4 *)(gt + row * 128 + col) = *(const f32x4 *)(sp + row * H2S + col);
+        }
+    };
     for (int tile = t0; tile < t1; ++tile) {
         const int nbase = tile * TP;
+        if (tile > t0) flush_tile(tile - 1);   // every wave passed the end-of-tile barrier: sp holds g2(tile-1)
         stage_points(xb, N, tile, has_t, tm, xs, nullptr, L.tid);
         __syncthreads();
         layer1_tile(xs, P.w1, P.b1, P.s1c, P.t1c, h1, L);
-        // ordered compaction of this tile's arg-extremum hits: wave w scans channels [256w, 256w+256)
+        // ordered compaction of this tile's arg-extremum hits, split by the parity of the local point so the
+        // two halves of the workgroup can accumulate without races: wave w scans channels [256w, 256w+256)
         {
-            int cnt = 0;
+            int cntE = 0, cntO = 0;
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int c = L.wave * 256 + it * 64 + L.lane;
                 const int n = idxb[c];
                 const bool hit = (n >= nbase) && (n < nbase + TP);
-                const unsigned long long mask = __ballot(hit);
+                const bool odd = (n & 1) != 0;
+                const unsigned long long mE = __ballot(hit && !odd), mO = __ballot(hit && odd);
+                const unsigned long long lt = (1ull << L.lane) - 1ull;
                 if (hit) {
-                    const int pos = cnt + __popcll(mask & ((1ull << L.lane) - 1ull));
-                    hits[L.wave * 256 + pos] = (c << 8) | (n - nbase);
+                    const unsigned short v = (unsigned short)((c << 6) | (n - nbase));
+                    if (odd) hits[(4 + L.wave) * 256 + cntO + __popcll(mO & lt)] = v;
+                    else hits[L.wave * 256 + cntE + __popcll(mE & lt)] = v;
                 }
-                cnt += __popcll(mask);
+                cntE += __popcll(mE); cntO += __popcll(mO);
             }
-            if (L.lane == 0) hcnt[L.wave] = cnt;
+            if (L.lane == 0) { hcnt[L.wave] = cntE; hcnt[4 + L.wave] = cntO; }
         }
         __syncthreads();
         f32x16 zh0, zh1;   // zhat2 for (points of this lane, channel c2)
@@ -456,18 +458,31 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
             __syncthreads();   // every wave is done reading h1: its storage becomes the sparse tile
             for (int i = L.tid; i < TP * H2S; i += 256) sp[i] = 0.f;
             __syncthreads();
-            // sparse term (deterministic order: waves' lists in order, ascending channel)
+            // sparse term, deterministic order (waves' lists in order, ascending channel).  thread = (k, parity)
+#ifndef D_SKIP_SPARSE
             {
                 const int k = L.tid & 127, half = L.tid >> 7;
                 for (int w = 0; w < 4; ++w) {
-                    const int n = hcnt[w];
-                    for (int e = 0; e < n; ++e) {
-                        const int hv = hits[w * 256 + e];
-                        const int p = hv & 255, c = hv >> 8;
-                        if ((p & 1) == half) sp[p * H2S + k] = fmaf(coefb[c], D.w3[(size_t)c * 128 + k], sp[p * H2S + k]);
+                    const unsigned short *hl = hits + (half * 4 + w) * 256;
+                    const int n = hcnt[half * 4 + w];
+                    int e = 0;
+                    for (; e + 4 <= n; e += 4) {   // four independent W3 loads in flight
+                        const int v0 = hl[e], v1 = hl[e + 1], v2 = hl[e + 2], v3 = hl[e + 3];
+                        const float w0 = D.w3[(size_t)(v0 >> 6) * 128 + k], w1_ = D.w3[(size_t)(v1 >> 6) * 128 + k];
+                        const float w2_ = D.w3[(size_t)(v2 >> 6) * 128 + k], w3_ = D.w3[(size_t)(v3 >> 6) * 128 + k];
+                        float *q0 = sp + (v0 & 63) * H2S + k; *q0 = fmaf(cfl[v0 >> 6], w0, *q0);
+                        float *q1 = sp + (v1 & 63) * H2S + k; *q1 = fmaf(cfl[v1 >> 6], w1_, *q1);
+                        float *q2 = sp + (v2 & 63) * H2S + k; *q2 = fmaf(cfl[v2 >> 6], w2_, *q2);
+                        float *q3 = sp + (v3 & 63) * H2S + k; *q3 = fmaf(cfl[v3 >> 6], w3_, *q3);
+                    }
+                    for (; e < n; ++e) {
+                        const int v0 = hl[e];
+                        float *q0 = sp + (v0 & 63) * H2S + k;
+                        *q0 = fmaf(cfl[v0 >> 6], D.w3[(size_t)(v0 >> 6) * 128 + k], *q0);
                     }
                 }
             }
+#endif
             __syncthreads();
             f32x16 d0, d1;
             k128_mfma(h2, D.Ap, cb, L, d0, d1);
@@ -481,12 +496,13 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
                 g1 = (v1 && a1[r] > 0.f) ? g1 : 0.f;
                 a1s += g0 + g1;
                 a2s = fmaf(g0, zh0[r], fmaf(g1, zh1[r], a2s));
-                if (v0) g2buf[((size_t)b * N + nbase + row) * 128 + c2] = g0;
-                if (v1) g2buf[((size_t)b * N + nbase + 32 + row) * 128 + c2] = g1;
+                sp[row * H2S + c2] = g0;            // same element this lane just read
+                sp[(32 + row) * H2S + c2] = g1;
             }
         }
-        __syncthreads();   // the next tile's layer 1 rewrites h1 (= sp)
+        __syncthreads();   // g2 tile complete in sp; flushed at the top of the next iteration
     }
+    flush_tile(t1 - 1);
     a1s += __shfl_xor(a1s, 32);
     a2s += __shfl_xor(a2s, 32);
     if (L.h == 0) {
@@ -540,9 +556,25 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
     for (int r = 0; r < 16; ++r) { pw0[r] = 0.f; pw1[r] = 0.f; }
     for (int tile = t0; tile < t1; ++tile) {
         const int nbase = tile * TP;
+        // the tile's g2 rows (64 x 512 B, contiguous in HBM) are fetched with 8 coalesced 16-B loads per thread
+        // at the top of the iteration and parked in the dz tile; each lane later picks up its own elements there
+        f32x4 gq[8];
+        {
+            const float *gt = g2buf + ((size_t)b * N + nbase) * 128;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int q = L.tid + 256 * i, row = q >> 5, col = (q & 31) * 4;
+                gq[i] = (nbase + row < N) ? *(const f32x4 *)(gt + row * 128 + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
         stage_points(xb, N, tile, has_t, tm, xs, xo, L.tid);
         __syncthreads();
         layer1_tile(xs, P.w1, P.b1, P.s1c, P.t1c, h1, L);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int q = L.tid + 256 * i, row = q >> 5, col = (q & 31) * 4;
+            *(f32x4 *)(dz + row * H2S + col) = gq[i];
+        }
         __syncthreads();
         {
             f32x16 a0, a1;
@@ -551,8 +583,7 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
             for (int r = 0; r < 16; ++r) {
                 const int row = mfma_row(r, L.lane);
                 const bool v0 = nbase + row < N, v1 = nbase + 32 + row < N;
-                const float g0 = v0 ? g2buf[((size_t)b * N + nbase + row) * 128 + c2] : 0.f;
-                const float g1 = v1 ? g2buf[((size_t)b * N + nbase + 32 + row) * 128 + c2] : 0.f;
+                const float g0 = dz[row * H2S + c2], g1 = dz[(32 + row) * H2S + c2];   // rows past N hold zeros
                 const float z0 = fmaf(a0[r], is2, nm2), z1 = fmaf(a1[r], is2, nm2);
                 dz[row * H2S + c2] = v0 ? dsc * (g0 - a1m - z0 * a2m) : 0.f;
                 dz[(32 + row) * H2S + c2] = v1 ? dsc * (g1 - a1m - z1 * a2m) : 0.f;
@@ -566,7 +597,7 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
+#pragma unroll 4
             for (int kb = 0; kb < 16; ++kb) {
                 f32x4 wv = wp[kb * 64];
                 f32x4 av = *(const f32x4 *)(ap + kb * 8);
@@ -813,6 +844,7 @@ int pngpd_trunk_bwd_d(const float *x, int B, int N, const float *trans,
     const size_t lds = BWD_D_LDS_FLOATS * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) { allow_lds((const void *)trunk_bwd_d_kernel, lds); attr_set = true; }
+    if (N > (1 << 30)) return PNGPD_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(trunk_bwd_d_kernel, dim3((unsigned)B * S), dim3(256), lds, (hipStream_t)stream,
                        x, N, trans, P, D, T, S, g2buf, pa);
     return pngpd_launch_status();
