@@ -43,21 +43,26 @@ __global__ void fold_conv_bn_kernel(const float *__restrict__ W, const float *__
 // with v_mfma_f32_32x32x2_f32; A (samples) and B (weight rows) fragments are float4 loads
 // straight from global (both operands are small and L2-resident).
 // ---------------------------------------------------------------------------------------
+// KSPLIT (small batches, latency path): the workgroup owns ONE 32-column block and its four waves each
+// contract a quarter of K (the K = 1024 MFMA chain of one wave is 14 us long); partial tiles meet in LDS.
+template <bool KSPLIT>
 __global__ __launch_bounds__(256) void fc_kernel(const float *__restrict__ in, int B, int K,
                                                  const float *__restrict__ W, const float *__restrict__ bias,
                                                  int Nout, int epi, float *__restrict__ out) {
+    __shared__ float red[KSPLIT ? 3 * 16 * 64 : 1];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
-    const int rb = blockIdx.x, cb = blockIdx.y * 4 + wave;
-    if (cb * 32 >= Nout) return;   // wave-uniform; the kernel has no barriers
+    const int rb = blockIdx.x, cb = KSPLIT ? (int)blockIdx.y : (int)blockIdx.y * 4 + wave;
+    if (!KSPLIT && cb * 32 >= Nout) return;   // wave-uniform; this variant has no barriers
     int row = rb * 32 + j; row = row < B ? row : B - 1;
     int col = cb * 32 + j; col = col < Nout ? col : Nout - 1;
     const f32x4 *ap = (const f32x4 *)(in + (size_t)row * K) + h;
     const f32x4 *wp = (const f32x4 *)(W + (size_t)col * K) + h;
     f32x16 acc = {0};
-    const int KB = K >> 3;
-    int kb = 0;
+    const int KBall = K >> 3;
+    const int KB = KSPLIT ? (wave + 1) * (KBall >> 2) : KBall;
+    int kb = KSPLIT ? wave * (KBall >> 2) : 0;
     for (; kb + 4 <= KB; kb += 4) {   // 8 loads in flight per lane
         f32x4 a[4], w[4];
 #pragma unroll
@@ -72,6 +77,17 @@ __global__ __launch_bounds__(256) void fc_kernel(const float *__restrict__ in, i
         f32x4 w = wp[kb * 2];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc = mfma32(a[t], w[t], acc);
+    }
+    if (KSPLIT) {
+        if (wave > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            acc[r] += red[r * 64 + lane] + red[(16 + r) * 64 + lane] + red[(32 + r) * 64 + lane];
     }
     const int c = cb * 32 + j;
     const bool cvalid = c < Nout;
@@ -140,8 +156,15 @@ int pngpd_fc_fwd(const float *in, int B, int K, const float *W, const float *bia
     if (epilogue < PNGPD_EPI_NONE || epilogue > PNGPD_EPI_LOG_SOFTMAX) return PNGPD_ERR_INVALID_ARG;
     if (epilogue == PNGPD_EPI_ADD_IDEN3 && Nout != 9) return PNGPD_ERR_INVALID_ARG;
     if (epilogue == PNGPD_EPI_LOG_SOFTMAX && Nout > 32) return PNGPD_ERR_INVALID_ARG;
-    dim3 grid((B + 31) / 32, (Nout + 127) / 128);
-    hipLaunchKernelGGL(fc_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, B, K, W, bias, Nout, epilogue, out);
+    if (B <= 64 && (K & 31) == 0) {   // latency path: few row blocks, split K over the workgroup's waves
+        dim3 grid((B + 31) / 32, (Nout + 31) / 32);
+        hipLaunchKernelGGL(fc_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, in, B, K, W, bias, Nout,
+                           epilogue, out);
+    } else {
+        dim3 grid((B + 31) / 32, (Nout + 127) / 128);
+        hipLaunchKernelGGL(fc_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, in, B, K, W, bias, Nout,
+                           epilogue, out);
+    }
     return pngpd_launch_status();
 }
 

@@ -46,25 +46,22 @@ __device__ __forceinline__ void swz_compute(const float *tile, const f32x4 (&wf)
     }
 }
 
-#ifndef TRUNK_PREFETCH
-#define TRUNK_PREFETCH 1
-#endif
-#ifndef TRUNK_WPS
-#define TRUNK_WPS 2
-#endif
-__global__ __launch_bounds__(256, TRUNK_WPS) void trunk_infer_kernel(
+__global__ __launch_bounds__(256, 2) void trunk_infer_kernel(
     const float *__restrict__ x, int N, const float *__restrict__ trans,
     const float *__restrict__ w1, const float *__restrict__ b1,
     const float *__restrict__ w2p, const float *__restrict__ b2,
     const float *__restrict__ w3p, const float *__restrict__ b3,
-    int relu_last, int T, int S, float *__restrict__ out) {
+    int relu_last, int T, int S, int CS, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *h1 = smem;              // [TP][I1S] swizzled
     float *h2 = h1 + TP * I1S;     // [TP][I2S] swizzled
     float *xs = h2 + TP * I2S;     // [3][TP]
     float *rm = xs + 3 * TP;       // [1024] running max of the layer-3 pre-bias output
     const Lane L;
-    const int b = blockIdx.x / S, s = blockIdx.x - b * S;
+    // small launches (latency path) additionally split the 32 channel blocks over CS in {1,2,4} workgroups
+    const int cs = blockIdx.x % CS, bs = blockIdx.x / CS;
+    const int b = bs / S, s = bs - b * S;
+    const int cp0 = cs * (4 / CS), cp1 = cp0 + 4 / CS;   // range of channel-block pairs of this workgroup
     int t0, t1; tile_range(s, S, T, t0, t1);
     const float *xb = x + (size_t)b * 3 * N;
     float tm[9] = {0};
@@ -77,11 +74,8 @@ __global__ __launch_bounds__(256, TRUNK_WPS) void trunk_infer_kernel(
     // layer-3 weight fragments are double-buffered in registers: while channel block ci is on the
     // MFMA pipe the 16 KiB of block ci+1 are in flight from L2 (the last block of a tile prefetches the
     // first block of the next tile, which also covers the tile prologue).
-    f32x4 wa[16];
-#if TRUNK_PREFETCH
-    f32x4 wb[16];
-    load_wfrag(wa, w3p, L.wave, L);
-#endif
+    f32x4 wa[16], wb[16];
+    load_wfrag(wa, w3p, L.wave + 8 * cp0, L);
     // the tile's points are fetched one tile ahead (threads 0..63 hold one point each in registers)
     float px0 = 0.f, px1 = 0.f, px2 = 0.f;
     if (L.tid < TP) {
@@ -136,23 +130,9 @@ __global__ __launch_bounds__(256, TRUNK_WPS) void trunk_infer_kernel(
             }
         }
         __syncthreads();
-#if !TRUNK_PREFETCH
 #pragma unroll 1
-        for (int ci = 0; ci < 8; ++ci) {
-            const int cb = L.wave + 4 * ci;
-            f32x16 a0, a1;
-            load_wfrag(wa, w3p, cb, L);
-            swz_compute<I2S, 16>(h2, wa, L, a0, a1);
-            float m = fmaxf(a0[0], a1[0]);
-#pragma unroll
-            for (int r = 1; r < 16; ++r) m = fmaxf(m, fmaxf(a0[r], a1[r]));
-            m = fmaxf(m, __shfl_xor(m, 32));
-            if (L.h == 0) rm[cb * 32 + L.j] = fmaxf(rm[cb * 32 + L.j], m);
-        }
-#else
-#pragma unroll 1
-        for (int cp = 0; cp < 4; ++cp) {
-            const int cbA = L.wave + 8 * cp, cbB = cbA + 4, cbN = L.wave + ((8 * cp + 8) & 31);
+        for (int cp = cp0; cp < cp1; ++cp) {
+            const int cbA = L.wave + 8 * cp, cbB = cbA + 4, cbN = L.wave + 8 * (cp + 1 < cp1 ? cp + 1 : cp0);
             f32x16 a0, a1;
             load_wfrag(wb, w3p, cbB, L);
             swz_compute<I2S, 16>(h2, wa, L, a0, a1);
@@ -169,14 +149,12 @@ __global__ __launch_bounds__(256, TRUNK_WPS) void trunk_infer_kernel(
             m = fmaxf(m, __shfl_xor(m, 32));
             if (L.h == 0) rm[cbB * 32 + L.j] = fmaxf(rm[cbB * 32 + L.j], m);
         }
-#endif
         // no barrier here: the next tile's xs/h1 writes do not alias h2, and the barrier before its
         // layer 2 orders the h2 rewrite after every wave's layer-3 reads.
     }
     if (L.h == 0) {   // each (wave, lane<32) reads back exactly the rm entries it wrote
         float *o = out + ((size_t)b * S + s) * 1024;
-#pragma unroll
-        for (int ci = 0; ci < 8; ++ci) {
+        for (int ci = 2 * cp0; ci < 2 * cp1; ++ci) {
             const int c = (L.wave + 4 * ci) * 32 + L.j;
             float v = rm[c] + b3[c];
             if (relu_last) v = fmaxf(v, 0.f);
@@ -233,8 +211,10 @@ int pngpd_trunk_fwd_infer(const float *x, int B, int N, const float *trans,
         dst = (float *)workspace;
     }
     const size_t lds = TRUNK_LDS_FLOATS * sizeof(float);
-    hipLaunchKernelGGL(trunk_infer_kernel, dim3((unsigned)B * S), dim3(256), lds, (hipStream_t)stream,
-                       x, N, trans, w1, b1, w2p, b2, w3p, b3, relu_last, T, S, dst);
+    int CS = 1;
+    if (B * S <= 128) CS = 4; else if (B * S <= 256) CS = 2;
+    hipLaunchKernelGGL(trunk_infer_kernel, dim3((unsigned)B * S * CS), dim3(256), lds, (hipStream_t)stream,
+                       x, N, trans, w1, b1, w2p, b2, w3p, b3, relu_last, T, S, CS, dst);
     int st = pngpd_launch_status();
     if (st != PNGPD_OK) return st;
     if (S > 1) {

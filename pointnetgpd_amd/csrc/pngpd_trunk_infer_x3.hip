@@ -113,6 +113,9 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
             }
         }
         __syncthreads();
+#ifdef X3_SKIP_L12
+        if (tile == t0)
+#endif
         {   // layer 1 (fp32 VALU): thread = (point p = tid & 127, 16-channel group g = tid >> 7 = wave >> 1)
             const int p = tid & 127, g = wave >> 1;
             const float x0 = xs[p], x1 = xs[XP + p], x2 = xs[2 * XP + p];
@@ -135,6 +138,9 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
             }
         }
         __syncthreads();
+#ifdef X3_SKIP_L12
+        if (tile == t0)
+#endif
         {   // layer 2 (64 -> 128), bf16x3: wave owns channel block cb = wave & 3 and point blocks 2q, 2q+1
             const int cb = wave & 3, pb0 = (wave >> 2) * 2;
             f32x4 w2h[4], w2l[4];
@@ -176,8 +182,12 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
                     c0 = mfma_bf(ah0, wl[ks], c0); c1 = mfma_bf(ah1, wl[ks], c1);
                     c0 = mfma_bf(al0, wh[ks], c0); c1 = mfma_bf(al1, wh[ks], c1);
                 }
+#ifndef X3_SKIP_EPI
 #pragma unroll
                 for (int r = 0; r < 16; ++r) m = fmaxf(m, fmaxf(c0[r], c1[r]));
+#else
+                m = fmaxf(m, c0[0] + c1[5]);
+#endif
             }
             m = fmaxf(m, __shfl_xor(m, 32));
             if (h == 0) rm[cb * 32 + j] = fmaxf(rm[cb * 32 + j], m);
