@@ -94,3 +94,35 @@ def shard_grasps(num_grasps, rank, world):
     per = (num_grasps + world - 1) // world
     s = min(num_grasps, rank * per)
     return s, min(num_grasps, s + per)
+
+
+class GraphedForward:
+    """Eval forward of a fixed (B, N) shape captured once as a HIP graph and replayed: the robot loop of
+    kinect2grasp.py scores tens of grasps per scene, where the ~10 kernel launches of a forward cost more
+    host time than the kernels themselves (B=1,N=500: 184 us eager -> 98 us replayed on MI355X).
+
+    Usage:  gf = GraphedForward(model, batch=40, num_points=500);  logp, trans = gf(x)   # x: (40,3,500) CUDA fp32
+    The returned tensors are the graph's static outputs (overwritten by the next call)."""
+
+    def __init__(self, model, batch, num_points):
+        self.model = model.eval()
+        dev = next(model.parameters()).device
+        self.x = torch.zeros(batch, 3, num_points, device=dev, dtype=torch.float32)
+        with torch.no_grad():
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self.model(self.x)          # warm-up: builds the fold cache outside the capture
+            torch.cuda.current_stream(dev).wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.logp, self.trans = self.model(self.x)
+
+    @torch.no_grad()
+    def __call__(self, x):
+        if tuple(x.shape) != tuple(self.x.shape):
+            raise RuntimeError(f"GraphedForward was captured for {tuple(self.x.shape)}, got {tuple(x.shape)}")
+        self.x.copy_(x)
+        self.graph.replay()
+        return self.logp, self.trans

@@ -163,3 +163,18 @@ def test_scorer_vote_repeat(cuda_device):
         assert int(res["pred"][g]) == int(maj)
         agree = votes[:, g] == maj
         np.testing.assert_allclose(float(res["score"][g]), probs[agree, g, 1].mean(), atol=1e-6)
+
+
+def test_graphed_forward_matches_eager(cuda_device):
+    from pointnetgpd_amd.scoring import GraphedForward
+    from tests.helpers import synth_cloud
+    m = build_model(500, 3, 35, 4702).eval().to(cuda_device)
+    gf = GraphedForward(m, batch=8, num_points=500)
+    for seed in (1, 2):
+        x = synth_cloud(8, 500, 2000 + seed, "box").to(cuda_device)
+        with torch.no_grad():
+            lp_e, tr_e = m(x)
+        lp_g, tr_g = gf(x)
+        assert torch.equal(lp_e, lp_g) and torch.equal(tr_e, tr_g)
+    with pytest.raises(RuntimeError, match="captured for"):
+        gf(torch.zeros(4, 3, 500, device=cuda_device))
