@@ -110,6 +110,13 @@ int pngpd_trunk_fwd_infer_x3(const float *x, int B, int N, const float *trans,
                              const float *w1, const float *b1, const void *w2x, const float *b2,
                              const void *w3x, const float *b3, int relu_last,
                              float *out_pool, void *workspace, size_t workspace_bytes, void *stream);
+/* OPT-IN bf16x3 variant of pass C (pngpd_trunk_fwd_train below): identical outputs/semantics, GEMM layers on
+ * split-bf16 products.  w2x = split_pack_bf16(raw W2), w3sx = split_pack_bf16(sign(gamma3)*W3).  S = number of
+ * workgroups per cloud (1 <= S <= ceil(N/128)); pmax/parg (B*S,1024), psum (B*S,2,1024).                    */
+int pngpd_trunk_fwd_train_x3(const float *x, int B, int N, const float *trans,
+                             const float *w1, const float *b1, const float *s1c, const float *t1c,
+                             const void *w2x, const float *s2c, const float *t2c, const void *w3sx, int S,
+                             float *pmax, int *parg, float *psum, void *stream);
 
 /* =======================================================================================
  * Training path (batch-statistics BatchNorm, backward).  The trunk's forward/backward is a

@@ -32,6 +32,8 @@ SIGNATURES = {
     "pngpd_split_pack_bf16": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, c_void]),
     "pngpd_trunk_fwd_infer_x3": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, c_f32p] + [c_f32p] * 6 +
                                  [ctypes.c_int, c_f32p, c_void, ctypes.c_size_t, c_void]),
+    "pngpd_trunk_fwd_train_x3": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 9 +
+                                 [ctypes.c_int, c_f32p, c_f32p, c_f32p, c_void]),
     # ---- training passes
     "pngpd_train_set_target_blocks": (ctypes.c_int, [ctypes.c_int]),
     "pngpd_trunk_train_splits": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),

@@ -222,6 +222,169 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// OPT-IN bf16x3 variant of the training main pass (pass C, see pngpd_train.hip): same outputs
+// (pmax/parg (blk,1024), psum (blk,2,1024)), per-channel affine forms instead of folded weights:
+//   h1 = relu((W1 x' + b1)*s1c + t1c),  h2 = relu((W2 h1)*s2c + t2c),  z3s = (sgn*W3) h2
+// w2x / w3x = split_pack_bf16 of the RAW (128,64) / sign-folded (1024,128) weights.
+// ---------------------------------------------------------------------------------------
+#define X3T_LDS_BYTES (X3_LDS_BYTES + 3 * 1024 * 4)
+
+__global__ __launch_bounds__(512, 2) void trunk_fwd_train_x3_kernel(
+    const float *__restrict__ x, int N, const float *__restrict__ trans,
+    const float *__restrict__ w1, const float *__restrict__ b1, const float *__restrict__ s1c,
+    const float *__restrict__ t1c, const u16 *__restrict__ w2x, const float *__restrict__ s2c,
+    const float *__restrict__ t2c, const u16 *__restrict__ w3x, int T, int S,
+    float *__restrict__ pmax, int *__restrict__ parg, float *__restrict__ psum) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u16 *h1h = (u16 *)smem_raw;
+    u16 *h1l = h1h + XP * X1S;
+    u16 *h2h = h1l + XP * X1S;
+    u16 *h2l = h2h + XP * X2S;
+    float *xs = (float *)(h2l + XP * X2S);
+    float *rm = xs + 3 * XP;
+    int *ri = (int *)(rm + 1024);
+    float *ss = (float *)(ri + 1024);
+    float *sq = ss + 1024;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int b = blockIdx.x / S, s = blockIdx.x - b * S;
+    const int t0 = (int)(((long)s * T) / S), t1 = (int)(((long)(s + 1) * T) / S);
+    const float *xb = x + (size_t)b * 3 * N;
+    float tm[9] = {0};
+    const bool has_t = trans != nullptr;
+    if (has_t) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) tm[i] = trans[(size_t)b * 9 + i];
+    }
+    for (int i = tid; i < 1024; i += 512) { rm[i] = -INFINITY; ri[i] = 0; ss[i] = 0.f; sq[i] = 0.f; }
+    f32x4 wah[8], wal[8];
+
+    for (int tile = t0; tile < t1; ++tile) {
+        const int nbase = tile * XP;
+        if (tid < XP) {
+            int n = nbase + tid; n = n < N ? n : N - 1;
+            float x0 = xb[n], x1 = xb[N + n], x2 = xb[2 * N + n];
+            if (has_t) {
+                const float y0 = fmaf(x2, tm[6], fmaf(x1, tm[3], x0 * tm[0]));
+                const float y1 = fmaf(x2, tm[7], fmaf(x1, tm[4], x0 * tm[1]));
+                const float y2 = fmaf(x2, tm[8], fmaf(x1, tm[5], x0 * tm[2]));
+                x0 = y0; x1 = y1; x2 = y2;
+            }
+            xs[tid] = x0; xs[XP + tid] = x1; xs[2 * XP + tid] = x2;
+        }
+        __syncthreads();
+        {
+            const int p = tid & 127, g = wave >> 1;
+            const float x0 = xs[p], x1 = xs[XP + p], x2 = xs[2 * XP + p];
+            u16 hv[16], lv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int c = g * 16 + e;
+                float z = fmaf(w1[c * 3 + 2], x2, fmaf(w1[c * 3 + 1], x1, fmaf(w1[c * 3], x0, b1[c])));
+                z = fmaxf(fmaf(z, s1c[c], t1c[c]), 0.f);
+                split2(z, hv[e], lv[e]);
+            }
+            uint4 *dh = (uint4 *)(h1h + p * X1S + g * 16), *dl = (uint4 *)(h1l + p * X1S + g * 16);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                uint4 vh, vl;
+                vh.x = hv[q * 8 + 0] | ((unsigned)hv[q * 8 + 1] << 16); vh.y = hv[q * 8 + 2] | ((unsigned)hv[q * 8 + 3] << 16);
+                vh.z = hv[q * 8 + 4] | ((unsigned)hv[q * 8 + 5] << 16); vh.w = hv[q * 8 + 6] | ((unsigned)hv[q * 8 + 7] << 16);
+                vl.x = lv[q * 8 + 0] | ((unsigned)lv[q * 8 + 1] << 16); vl.y = lv[q * 8 + 2] | ((unsigned)lv[q * 8 + 3] << 16);
+                vl.z = lv[q * 8 + 4] | ((unsigned)lv[q * 8 + 5] << 16); vl.w = lv[q * 8 + 6] | ((unsigned)lv[q * 8 + 7] << 16);
+                dh[q] = vh; dl[q] = vl;
+            }
+        }
+        __syncthreads();
+        {
+            const int cb = wave & 3, pb0 = (wave >> 2) * 2;
+            f32x4 w2h[4], w2l[4];
+            load_wx<4>(w2h, w2l, w2x, cb, lane);
+            f32x16 a0 = {0}, a1 = {0};
+            const int r0 = (pb0 * 32 + j) * X1S + h * 8, r1 = ((pb0 + 1) * 32 + j) * X1S + h * 8;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const f32x4 ah0 = *(const f32x4 *)(h1h + r0 + ks * 16), al0 = *(const f32x4 *)(h1l + r0 + ks * 16);
+                const f32x4 ah1 = *(const f32x4 *)(h1h + r1 + ks * 16), al1 = *(const f32x4 *)(h1l + r1 + ks * 16);
+                a0 = mfma_bf(ah0, w2h[ks], a0); a1 = mfma_bf(ah1, w2h[ks], a1);
+                a0 = mfma_bf(ah0, w2l[ks], a0); a1 = mfma_bf(ah1, w2l[ks], a1);
+                a0 = mfma_bf(al0, w2h[ks], a0); a1 = mfma_bf(al1, w2h[ks], a1);
+            }
+            const float sc = s2c[cb * 32 + j], sh = t2c[cb * 32 + j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mfma_row(r, lane);
+                u16 hi, lo;
+                split2(fmaxf(fmaf(a0[r], sc, sh), 0.f), hi, lo);
+                h2h[(pb0 * 32 + row) * X2S + cb * 32 + j] = hi; h2l[(pb0 * 32 + row) * X2S + cb * 32 + j] = lo;
+                split2(fmaxf(fmaf(a1[r], sc, sh), 0.f), hi, lo);
+                h2h[((pb0 + 1) * 32 + row) * X2S + cb * 32 + j] = hi; h2l[((pb0 + 1) * 32 + row) * X2S + cb * 32 + j] = lo;
+            }
+        }
+        __syncthreads();
+        const bool full = nbase + XP <= N;
+#pragma unroll 1
+        for (int ci = 0; ci < 4; ++ci) {
+            const int cb = wave + 8 * ci;
+            load_wx<8>(wah, wal, w3x, cb, lane);
+            float m = -INFINITY, su = 0.f, qu = 0.f;
+            int am = 0;
+#pragma unroll
+            for (int qp = 0; qp < 2; ++qp) {
+                f32x16 c0 = {0}, c1 = {0};
+                const int ro0 = ((2 * qp) * 32 + j) * X2S + h * 8, ro1 = ((2 * qp + 1) * 32 + j) * X2S + h * 8;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const f32x4 ah0 = *(const f32x4 *)(h2h + ro0 + ks * 16), al0 = *(const f32x4 *)(h2l + ro0 + ks * 16);
+                    const f32x4 ah1 = *(const f32x4 *)(h2h + ro1 + ks * 16), al1 = *(const f32x4 *)(h2l + ro1 + ks * 16);
+                    c0 = mfma_bf(ah0, wah[ks], c0); c1 = mfma_bf(ah1, wah[ks], c1);
+                    c0 = mfma_bf(ah0, wal[ks], c0); c1 = mfma_bf(ah1, wal[ks], c1);
+                    c0 = mfma_bf(al0, wah[ks], c0); c1 = mfma_bf(al1, wah[ks], c1);
+                }
+                // ascending local-row order with strict >: the first maximum wins
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { if (c0[r] > m) { m = c0[r]; am = (2 * qp) * 32 + mfma_row(r, lane); } }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { if (c1[r] > m) { m = c1[r]; am = (2 * qp + 1) * 32 + mfma_row(r, lane); } }
+                if (full) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { su += c0[r] + c1[r]; qu = fmaf(c0[r], c0[r], fmaf(c1[r], c1[r], qu)); }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = mfma_row(r, lane);
+                        const float v0 = (nbase + (2 * qp) * 32 + row < N) ? c0[r] : 0.f;
+                        const float v1 = (nbase + (2 * qp + 1) * 32 + row < N) ? c1[r] : 0.f;
+                        su += v0 + v1; qu = fmaf(v0, v0, fmaf(v1, v1, qu));
+                    }
+                }
+            }
+            const float om = __shfl_xor(m, 32); const int oa = __shfl_xor(am, 32);
+            if (om > m || (om == m && oa < am)) { m = om; am = oa; }
+            su += __shfl_xor(su, 32); qu += __shfl_xor(qu, 32);
+            if (h == 0) {
+                const int c = cb * 32 + j;
+                if (m > rm[c]) { rm[c] = m; const int n = nbase + am; ri[c] = n < N ? n : N - 1; }
+                ss[c] += su; sq[c] += qu;
+            }
+        }
+    }
+    if (h == 0) {
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci) {
+            const int c = (wave + 8 * ci) * 32 + j;
+            pmax[(size_t)blockIdx.x * 1024 + c] = rm[c];
+            parg[(size_t)blockIdx.x * 1024 + c] = ri[c];
+            psum[((size_t)blockIdx.x * 2) * 1024 + c] = ss[c];
+            psum[((size_t)blockIdx.x * 2 + 1) * 1024 + c] = sq[c];
+        }
+    }
+}
+
 __global__ void pool_reduce_x3_kernel(const float *__restrict__ part, int S, float *__restrict__ out, int total) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
@@ -275,6 +438,26 @@ int pngpd_trunk_fwd_infer_x3(const float *x, int B, int N, const float *trans,
         st = pngpd_launch_status();
     }
     return st;
+}
+
+int pngpd_trunk_fwd_train_x3(const float *x, int B, int N, const float *trans,
+                             const float *w1, const float *b1, const float *s1c, const float *t1c,
+                             const void *w2x, const float *s2c, const float *t2c, const void *w3sx, int S,
+                             float *pmax, int *parg, float *psum, void *stream) {
+    if (!x || !w1 || !b1 || !s1c || !t1c || !w2x || !s2c || !t2c || !w3sx || !pmax || !parg || !psum ||
+        B <= 0 || N <= 0)
+        return PNGPD_ERR_INVALID_ARG;
+    const int T = (N + XP - 1) / XP;
+    if (S < 1 || S > T) return PNGPD_ERR_INVALID_ARG;   // S: the split count the caller sized pmax/parg/psum for
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute((const void *)trunk_fwd_train_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, X3T_LDS_BYTES);
+        attr = true;
+    }
+    hipLaunchKernelGGL(trunk_fwd_train_x3_kernel, dim3((unsigned)B * S), dim3(512), X3T_LDS_BYTES, (hipStream_t)stream,
+                       x, N, trans, w1, b1, s1c, t1c, (const u16 *)w2x, s2c, t2c, (const u16 *)w3sx, T, S,
+                       pmax, parg, psum);
+    return pngpd_launch_status();
 }
 
 }  // extern "C"

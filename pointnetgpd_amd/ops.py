@@ -211,6 +211,18 @@ def trunk_fwd_train(x, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, w3sp):
     return pmax, parg, psum
 
 
+def trunk_fwd_train_x3(x, trans, w1, b1, s1c, t1c, w2x, s2c, t2c, w3sx):
+    """bf16x3 variant of trunk_fwd_train; returns (pmax (B,S,1024), parg, psum (B*S,2,1024), S)."""
+    B, _, N = x.shape
+    S = max(1, min(train_splits(B, N), (N + 127) // 128))
+    pmax = torch.empty(B, S, 1024, device=x.device, dtype=torch.float32)
+    parg = torch.empty(B, S, 1024, device=x.device, dtype=torch.int32)
+    psum = torch.empty(B * S, 2, 1024, device=x.device, dtype=torch.float32)
+    _call("pngpd_trunk_fwd_train_x3", x, x, B, N, trans, w1, b1, s1c, t1c, w2x, s2c, t2c, w3sx, int(S), pmax, parg,
+          psum)
+    return pmax, parg, psum, S
+
+
 def trunk_h_moments(x, trans, w1, b1, s1c, t1c, w2p, s2c, t2c):
     B, _, N = x.shape
     ps2 = torch.empty(B, 128, 128, device=x.device, dtype=torch.float32)

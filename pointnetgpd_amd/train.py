@@ -18,6 +18,14 @@ from . import ops
 from .ops import _call
 
 F64 = torch.float64
+_TRAIN_PRECISION = "fp32"   # "bf16x3": opt-in split-bf16 products for the main forward pass (pass C)
+
+
+def set_train_precision(mode):
+    global _TRAIN_PRECISION
+    if mode not in ("fp32", "bf16x3"):
+        raise ValueError("precision must be 'fp32' or 'bf16x3'")
+    _TRAIN_PRECISION = mode
 DEBUG_STASH = None   # set to a dict to capture backward intermediates (tests / tools/diag_train2.py)
 
 
@@ -84,15 +92,21 @@ class TrunkTrainFn(torch.autograd.Function):
         s2c, t2c, is2, nm2 = chan2[0], chan2[1], chan2[2], chan2[3]
         # ---- pass C + BN3 + pool
         sgn = torch.where(g3c >= 0, 1.0, -1.0).to(torch.float32)
-        w3sp = ops.pack_mfma_b(w3, scale=sgn)
-        pmax, parg, psum = ops.trunk_fwd_train(x, T, w1, b1c, s1c, t1c, w2p, s2c, t2c, w3sp)
+        Sc = S
+        if _TRAIN_PRECISION == "bf16x3":
+            w3s = (w3 * sgn[:, None]).contiguous()
+            pmax, parg, psum, Sc = ops.trunk_fwd_train_x3(x, T, w1, b1c, s1c, t1c, ops.split_pack_bf16(w2), s2c, t2c,
+                                                          ops.split_pack_bf16(w3s))
+        else:
+            w3sp = ops.pack_mfma_b(w3, scale=sgn)
+            pmax, parg, psum = ops.trunk_fwd_train(x, T, w1, b1c, s1c, t1c, w2p, s2c, t2c, w3sp)
         stats3 = _e(dev, 2048, dtype=F64)
         rm, rv, nbt = _bufs3(bufs3)
-        tot3 = _reduce(psum, 1, blk, 2048)
+        tot3 = _reduce(psum, 1, B * Sc, 2048)
         _call("pngpd_bn3_finalize", x, tot3, B, N, b3c, g3c, float(momentum), rm, rv, nbt, stats3)
         _bump(bufs3)
         pooled, idx, zhat = _e(dev, B, 1024), _e(dev, B, 1024, dtype=torch.int32), _e(dev, B, 1024)
-        _call("pngpd_pool_finalize", x, pmax, parg, B, S, stats3, g3c, be3c, float(eps), int(relu_last), pooled,
+        _call("pngpd_pool_finalize", x, pmax, parg, B, Sc, stats3, g3c, be3c, float(eps), int(relu_last), pooled,
               idx, zhat)
         ctx.relu_last, ctx.eps, ctx.has_t, ctx.S = relu_last, eps, T is not None, S
         ctx.save_for_backward(x, T if T is not None else x.new_empty(0), w1, b1c, g1c, w2, g2c, w3, g3c, mom,

@@ -231,3 +231,34 @@ def test_trunk_backward_intermediates(cuda_device):
         assert _rel(feat[kx].cpu(), dbg[kx]) < tol, (kx, _rel(feat[kx].cpu(), dbg[kx]))
     for kx, ky in [("dW1", "W1"), ("dW2", "W2"), ("dW3", "W3"), ("dT", "T")]:
         assert _rel(feat[kx].cpu(), g[ky]) < 1e-3, (kx, _rel(feat[kx].cpu(), g[ky]))
+
+
+@pytest.mark.parametrize("B,N,k", [(16, 750, 2), (5, 100, 3)])
+def test_train_step_bf16x3_main_pass(B, N, k, cuda_device):
+    """Opt-in bf16x3 arithmetic for the forward main pass: same parity bars as the fp32 path."""
+    from pointnetgpd_amd import train
+    m = build_model(N, k, 80 + B, 4500 + B).train()
+    sd = state_dict_cpu(m)
+    x = synth_cloud(B, N, 900 + B, "box")
+    y = (torch.arange(B) * 7 % k).long()
+    loss_ref, logp_ref, trans_ref, grads_ref, stats_ref = po.train_step_torch(sd, x, y, dtype=torch.float64)
+    _, _, _, grads32, _ = po.train_step_torch(sd, x, y, dtype=torch.float32)
+    m = m.to(cuda_device)
+    train.set_train_precision("bf16x3")
+    try:
+        logp, trans = m(x.to(cuda_device))
+        loss = F.nll_loss(logp, y.to(cuda_device))
+        loss.backward()
+    finally:
+        train.set_train_precision("fp32")
+    assert abs(loss.item() - loss_ref.item()) < 1e-3
+    np.testing.assert_allclose(logp.detach().cpu().numpy(), logp_ref.numpy(), atol=1e-3, rtol=0)
+    np.testing.assert_allclose(trans.detach().cpu().numpy(), trans_ref.numpy(), atol=1e-3, rtol=0)
+    for n, p in m.named_parameters():
+        ref = grads_ref[n]
+        if ref.double().norm().item() < 1e-9:
+            continue
+        assert _rel(p.grad.cpu(), ref) < grad_tol(B, _rel(grads32[n], ref)), n
+    cur = m.state_dict()
+    for n, v in stats_ref.items():
+        np.testing.assert_allclose(cur[n].cpu().numpy(), v.float().numpy(), atol=5e-5, rtol=5e-4, err_msg=n)
