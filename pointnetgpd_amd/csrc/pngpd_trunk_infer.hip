@@ -33,16 +33,24 @@ __device__ __forceinline__ void swz_compute(const float *tile, const f32x4 (&wf)
     const int sx = L.j & 15;   // (32 + j) & 15 == j & 15
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    // A fragments double-buffered in registers: the two ds_read_b128 of k-block kb+1 are in flight while the
+    // eight MFMAs of k-block kb issue (hipcc otherwise re-uses the registers and waits lgkmcnt(0) every block)
+    f32x4 a0 = *(const f32x4 *)(r0 + (((0 * 2 + L.h) ^ sx) << 2));
+    f32x4 a1 = *(const f32x4 *)(r1 + (((0 * 2 + L.h) ^ sx) << 2));
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-        const int c4 = ((kb * 2 + L.h) ^ sx) << 2;
-        f32x4 a0 = *(const f32x4 *)(r0 + c4);
-        f32x4 a1 = *(const f32x4 *)(r1 + c4);
+        f32x4 n0 = a0, n1 = a1;
+        if (kb + 1 < NKB) {
+            const int c4 = (((kb + 1) * 2 + L.h) ^ sx) << 2;
+            n0 = *(const f32x4 *)(r0 + c4);
+            n1 = *(const f32x4 *)(r1 + c4);
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             acc0 = mfma32(a0[t], wf[kb][t], acc0);
             acc1 = mfma32(a1[t], wf[kb][t], acc1);
         }
+        a0 = n0; a1 = n1;
     }
 }
 

@@ -173,14 +173,22 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
 #pragma unroll
             for (int qp = 0; qp < 2; ++qp) {   // two point blocks at a time: 32 accumulator registers live
                 f32x16 c0 = {0}, c1 = {0};
-                const int ro0 = ((2 * qp) * 32 + j) * X2S + h * 8, ro1 = ((2 * qp + 1) * 32 + j) * X2S + h * 8;
+                const u16 *p0h = h2h + ((2 * qp) * 32 + j) * X2S + h * 8, *p0l = h2l + ((2 * qp) * 32 + j) * X2S + h * 8;
+                const u16 *p1h = h2h + ((2 * qp + 1) * 32 + j) * X2S + h * 8, *p1l = h2l + ((2 * qp + 1) * 32 + j) * X2S + h * 8;
+                // A fragments are double-buffered in registers: the reads of k-step ks+1 are in flight while the
+                // six MFMAs of k-step ks issue (otherwise every k-step pays a full LDS latency)
+                f32x4 ah0 = *(const f32x4 *)p0h, al0 = *(const f32x4 *)p0l, ah1 = *(const f32x4 *)p1h, al1 = *(const f32x4 *)p1l;
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
-                    const f32x4 ah0 = *(const f32x4 *)(h2h + ro0 + ks * 16), al0 = *(const f32x4 *)(h2l + ro0 + ks * 16);
-                    const f32x4 ah1 = *(const f32x4 *)(h2h + ro1 + ks * 16), al1 = *(const f32x4 *)(h2l + ro1 + ks * 16);
+                    f32x4 nh0 = ah0, nl0 = al0, nh1 = ah1, nl1 = al1;
+                    if (ks < 7) {
+                        nh0 = *(const f32x4 *)(p0h + (ks + 1) * 16); nl0 = *(const f32x4 *)(p0l + (ks + 1) * 16);
+                        nh1 = *(const f32x4 *)(p1h + (ks + 1) * 16); nl1 = *(const f32x4 *)(p1l + (ks + 1) * 16);
+                    }
                     c0 = mfma_bf(ah0, wh[ks], c0); c1 = mfma_bf(ah1, wh[ks], c1);
                     c0 = mfma_bf(ah0, wl[ks], c0); c1 = mfma_bf(ah1, wl[ks], c1);
                     c0 = mfma_bf(al0, wh[ks], c0); c1 = mfma_bf(al1, wh[ks], c1);
+                    ah0 = nh0; al0 = nl0; ah1 = nh1; al1 = nl1;
                 }
 #ifndef X3_SKIP_EPI
 #pragma unroll
