@@ -82,15 +82,8 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
     }
     for (int i = tid; i < 1024; i += 512) rm[i] = -INFINITY;
 
-#ifndef X3_PREFETCH
-#define X3_PREFETCH 0
-#endif
-    // layer-3 weight fragments (hi+lo of one 32-channel block = 64 VGPRs); optionally double-buffered
+    // layer-3 weight fragments (hi+lo of one 32-channel block = 64 VGPRs)
     f32x4 wah[8], wal[8];
-#if X3_PREFETCH
-    f32x4 wbh[8], wbl[8];
-    load_wx<8>(wah, wal, w3x, wave, lane);
-#endif
 
     float px0 = 0.f, px1 = 0.f, px2 = 0.f;
     if (tid < XP) {
@@ -168,54 +161,43 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
         }
         __syncthreads();
         // layer 3 (128 -> 1024), bf16x3: wave owns channel blocks wave + 8*ci, all four point blocks
-        auto block = [&](const f32x4 (&wh)[8], const f32x4 (&wl)[8], int cb) {
+        // One channel block x all four point blocks per step: 4 independent accumulator chains (an accumulator is
+        // re-used every 4th MFMA) and the A fragments of k-step ks+1 in flight while k-step ks issues.
+        auto block4 = [&](int cb) {
+            load_wx<8>(wah, wal, w3x, cb, lane);
+            f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+            const int ro = j * X2S + h * 8;
+            f32x4 ah[4], al[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { ah[q] = *(const f32x4 *)(h2h + ro + q * 32 * X2S); al[q] = *(const f32x4 *)(h2l + ro + q * 32 * X2S); }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                f32x4 nh[4], nl[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    nh[q] = ah[q]; nl[q] = al[q];
+                    if (ks < 7) {
+                        nh[q] = *(const f32x4 *)(h2h + ro + q * 32 * X2S + (ks + 1) * 16);
+                        nl[q] = *(const f32x4 *)(h2l + ro + q * 32 * X2S + (ks + 1) * 16);
+                    }
+                }
+                c0 = mfma_bf(ah[0], wah[ks], c0); c1 = mfma_bf(ah[1], wah[ks], c1);
+                c2 = mfma_bf(ah[2], wah[ks], c2); c3 = mfma_bf(ah[3], wah[ks], c3);
+                c0 = mfma_bf(ah[0], wal[ks], c0); c1 = mfma_bf(ah[1], wal[ks], c1);
+                c2 = mfma_bf(ah[2], wal[ks], c2); c3 = mfma_bf(ah[3], wal[ks], c3);
+                c0 = mfma_bf(al[0], wah[ks], c0); c1 = mfma_bf(al[1], wah[ks], c1);
+                c2 = mfma_bf(al[2], wah[ks], c2); c3 = mfma_bf(al[3], wah[ks], c3);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { ah[q] = nh[q]; al[q] = nl[q]; }
+            }
             float m = -INFINITY;
 #pragma unroll
-            for (int qp = 0; qp < 2; ++qp) {   // two point blocks at a time: 32 accumulator registers live
-                f32x16 c0 = {0}, c1 = {0};
-                const u16 *p0h = h2h + ((2 * qp) * 32 + j) * X2S + h * 8, *p0l = h2l + ((2 * qp) * 32 + j) * X2S + h * 8;
-                const u16 *p1h = h2h + ((2 * qp + 1) * 32 + j) * X2S + h * 8, *p1l = h2l + ((2 * qp + 1) * 32 + j) * X2S + h * 8;
-                // A fragments are double-buffered in registers: the reads of k-step ks+1 are in flight while the
-                // six MFMAs of k-step ks issue (otherwise every k-step pays a full LDS latency)
-                f32x4 ah0 = *(const f32x4 *)p0h, al0 = *(const f32x4 *)p0l, ah1 = *(const f32x4 *)p1h, al1 = *(const f32x4 *)p1l;
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
-                    f32x4 nh0 = ah0, nl0 = al0, nh1 = ah1, nl1 = al1;
-                    if (ks < 7) {
-                        nh0 = *(const f32x4 *)(p0h + (ks + 1) * 16); nl0 = *(const f32x4 *)(p0l + (ks + 1) * 16);
-                        nh1 = *(const f32x4 *)(p1h + (ks + 1) * 16); nl1 = *(const f32x4 *)(p1l + (ks + 1) * 16);
-                    }
-                    c0 = mfma_bf(ah0, wh[ks], c0); c1 = mfma_bf(ah1, wh[ks], c1);
-                    c0 = mfma_bf(ah0, wl[ks], c0); c1 = mfma_bf(ah1, wl[ks], c1);
-                    c0 = mfma_bf(al0, wh[ks], c0); c1 = mfma_bf(al1, wh[ks], c1);
-                    ah0 = nh0; al0 = nl0; ah1 = nh1; al1 = nl1;
-                }
-#ifndef X3_SKIP_EPI
-#pragma unroll
-                for (int r = 0; r < 16; ++r) m = fmaxf(m, fmaxf(c0[r], c1[r]));
-#else
-                m = fmaxf(m, c0[0] + c1[5]);
-#endif
-            }
+            for (int r = 0; r < 16; ++r) m = fmaxf(m, fmaxf(fmaxf(c0[r], c1[r]), fmaxf(c2[r], c3[r])));
             m = fmaxf(m, __shfl_xor(m, 32));
             if (h == 0) rm[cb * 32 + j] = fmaxf(rm[cb * 32 + j], m);
         };
-#if X3_PREFETCH
 #pragma unroll 1
-        for (int cp = 0; cp < 2; ++cp) {
-            const int cbA = wave + 16 * cp, cbB = cbA + 8, cbN = wave + ((16 * cp + 16) & 31);
-            load_wx<8>(wbh, wbl, w3x, cbB, lane);
-            block(wah, wal, cbA);
-            load_wx<8>(wah, wal, w3x, cbN, lane);
-            block(wbh, wbl, cbB);
-        }
-#else
-#pragma unroll 1
-        for (int ci = 0; ci < 4; ++ci) {
-            load_wx<8>(wah, wal, w3x, wave + 8 * ci, lane);
-            block(wah, wal, wave + 8 * ci);
-        }
-#endif
+        for (int ci = 0; ci < 4; ++ci) block4(wave + 8 * ci);
         // the barrier after the next tile's layer 1 orders the h2 rewrite after these reads
     }
     if (h == 0) {
