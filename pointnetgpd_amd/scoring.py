@@ -126,3 +126,41 @@ class GraphedForward:
         self.x.copy_(x)
         self.graph.replay()
         return self.logp, self.trans
+
+
+def score_scene_distributed(score_fn, scene_cloud, grasps, group=None):
+    """BASELINE config 5 across the GPUs of a node: every rank holds the scene cloud, scores its contiguous
+    slice of the candidates with ``score_fn(cloud, grasps_slice) -> dict(pred, score, counts, valid)`` (e.g.
+    ``GraspScorer.score``) and the per-candidate results are concatenated on every rank with ONE
+    ``all_gather`` of a packed (per_rank, 4) tensor — there is no collective inside the scoring path itself.
+    Returns dict(pred, score, counts, valid, order) over ALL candidates (order: good-first is left to the caller's
+    best-class rule; here: all valid candidates sorted by score, descending)."""
+    import torch.distributed as dist
+    grasps = np.asarray(grasps).reshape(-1, 5, 3)
+    G = grasps.shape[0]
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    s, e = shard_grasps(G, rank, world)
+    per = (G + world - 1) // world
+    if e > s:
+        res = score_fn(scene_cloud, grasps[s:e])
+        dev = res["score"].device
+        local = torch.stack([res["pred"].float(), res["score"].float(), res["counts"].float(),
+                             res["valid"].float()], dim=1)
+    else:
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        local = torch.zeros(0, 4, device=dev)
+    packed = torch.zeros(per, 4, device=dev)
+    packed[:e - s] = local
+    if world > 1:
+        out = [torch.empty_like(packed) for _ in range(world)]
+        dist.all_gather(out, packed, group=group)
+        # ranks hold contiguous slices of length `per` (only the tail ranks are shorter), so the concatenation
+        # is already in candidate order and the padding sits at the end
+        allr = torch.cat(out, 0)[:G]
+    else:
+        allr = packed[:G]
+    pred, score, counts, valid = allr[:, 0].long(), allr[:, 1], allr[:, 2].int(), allr[:, 3] > 0.5
+    vi = torch.nonzero(valid).squeeze(1)
+    order = vi[torch.argsort(score[vi], descending=True, stable=True)]
+    return dict(pred=pred, score=score, counts=counts, valid=valid, order=order)

@@ -178,3 +178,17 @@ def test_graphed_forward_matches_eager(cuda_device):
         assert torch.equal(lp_e, lp_g) and torch.equal(tr_e, tr_g)
     with pytest.raises(RuntimeError, match="captured for"):
         gf(torch.zeros(4, 3, 500, device=cuda_device))
+
+
+def test_score_scene_distributed_single_rank(cuda_device):
+    """world_size 1 (no process group): the sharded entry returns exactly what GraspScorer.score returns."""
+    from pointnetgpd_amd.scoring import GraspScorer, score_scene_distributed
+    m = build_model(48, 2, 36, 4703).eval().to(cuda_device)
+    pc, grasps = _scene(33, 30000, 23)
+    scorer = GraspScorer(m, num_points=48, repeat=1, batch=16, seed=3)
+    ref = scorer.score(pc.astype(np.float32), grasps)
+    res = score_scene_distributed(scorer.score, pc.astype(np.float32), grasps)
+    assert torch.equal(res["pred"], ref["pred"]) and torch.equal(res["valid"], ref["valid"])
+    assert torch.equal(res["counts"], ref["counts"]) and torch.equal(res["score"], ref["score"])
+    sc = res["score"][res["order"]]
+    assert (sc[:-1] >= sc[1:]).all()
