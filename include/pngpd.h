@@ -249,6 +249,26 @@ int pngpd_crop_resample(const void *cloud, int cloud_is_f64, const double *frame
                         const int *idx, int max_keep, int N, int mode, int min_points,
                         unsigned long long seed, const int *sel, float *out, unsigned char *valid, void *stream);
 
+/* =======================================================================================
+ * GPG grasp-candidate sampler, device half (upstream of the crop at inference) —
+ * dex-net/src/dexnet/grasping/grasp_sampler.py :: GpgGraspSamplerPcl.sample_grasps :1383-1656.
+ * Same cloud convention as the crop entries.  The host half (3x3 eigen-decomposition, pose
+ * enumeration, selection logic) is pointnetgpd_amd/gpg.py.
+ * ======================================================================================= */
+/* :1471-1485  For each of K sample points (queries (K,3) f64): the <= max_nn nearest cloud points with
+ * squared distance < radius^2 (ties at the cut -> lower index) and M_out (K,9) f64 = sum over the selected
+ * points with non-zero distance of n n^T, n = normals[p] / |normals[p]| (normals (P,3) f64);
+ * nsel_out (K) = number of selected points (including a zero-distance one).                     */
+int pngpd_gpg_normal_moments(const void *cloud, int cloud_is_f64, const double *normals, int P,
+                             const double *queries, int K, double radius, int max_nn, double *M_out,
+                             int *nsel_out, void *stream);
+/* :336-393 / :405-421  For each of Q hand poses (poses (Q,12) f64 = centre, approach, binormal, minor; unit
+ * axes) count the cloud points strictly inside each of num_boxes (1 or 4) boxes of the hand model, boxes
+ * (num_boxes,6) f64 = x_lo, x_hi, y_lo, y_hi, z_lo, z_hi in the grasp frame -> counts (Q,num_boxes) int32.
+ * check_collision_square's has_p is counts > 0, its points_in_area length is counts.             */
+int pngpd_hand_box_counts(const void *cloud, int cloud_is_f64, int P, const double *poses, int Q,
+                          const double *boxes, int num_boxes, int *counts, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

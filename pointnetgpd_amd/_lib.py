@@ -74,6 +74,11 @@ SIGNATURES = {
     "pngpd_crop_resample": (ctypes.c_int, [c_void, ctypes.c_int, c_void, ctypes.c_int, c_void, c_void,
                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_ulonglong, c_void, c_void, c_void, c_void]),
+    # ---- GPG sampler (device half)
+    "pngpd_gpg_normal_moments": (ctypes.c_int, [c_void, ctypes.c_int, c_void, ctypes.c_int, c_void, ctypes.c_int,
+                                                ctypes.c_double, ctypes.c_int, c_void, c_void, c_void]),
+    "pngpd_hand_box_counts": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, ctypes.c_int, c_void,
+                                             ctypes.c_int, c_void, c_void]),
 }
 
 

@@ -1,0 +1,327 @@
+"""GPG grasp-candidate sampler, batched on the GPU — the upstream of the in-gripper crop.
+
+Mirror of ``GpgGraspSamplerPcl.sample_grasps`` (dex-net/src/dexnet/grasping/grasp_sampler.py:1383-1656), the
+sampler ``kinect2grasp.py:150`` calls.  The reference walks the sample points one at a time and, for each, runs
+19 rotations x 21 lateral offsets x 2-4 ``check_collision_square`` numpy passes over the whole cloud, then up to
+25 push-in steps x 7 passes per surviving pose.  Here all sample points of a call are processed together:
+
+1. ``pngpd_gpg_normal_moments``   one workgroup per sample point: r-ball / 100-NN selection and M = sum n n^T
+2. host (numpy, a few 3x3 ops per sample point): ``np.linalg.eig`` — the same LAPACK call as the reference, so the
+   arbitrary eigenvector SIGNS that decide the enumeration order agree — local frame, pose enumeration
+3. ``pngpd_hand_box_counts``      one thread per pose, four hand boxes per transformed point, whole sweep in ONE launch
+4. host: middle-offset rule per rotation, table check, push-in poses + table back-off
+5. ``pngpd_hand_box_counts``      collision at every push-in step and the final check at every backed-off pose
+6. host: first accepted step per pose, reference output order, ``num_grasps`` / ``max_num_samples`` stop rule
+
+Three launches and three small device->host copies per scene instead of ~10^5 numpy calls.
+
+Reference quirks reproduced on purpose (see oracle/gpg_oracle.py for the executed-reference pin):
+* the "rotation by dtheta" is ``rotation_from_quaternion([dtheta_rad, minor])`` on an un-normalised quaternion;
+* ``all_normal[ind]`` indexes the FULL-cloud normals with an index into ``points_for_sample`` (:1510);
+* the table back-off distance is the Frobenius norm of the stacked (lowest corner, table point) pair (:1605);
+* a sample point whose M is all-zero consumes a draw but does not count towards ``max_num_samples`` (:1486-1489)
+  — the reference can loop forever there; this implementation gives up after 10 x max_num_samples draws.
+
+The reference reseeds numpy from the OS before every draw (:1455) and so has no reproducible stream; here the
+draws come from ``sample_indices`` (explicit), else ``numpy.random.default_rng(seed)``.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .crop import ROBOTIQ_85 as _CROP_GRIPPER
+
+# dex-net/data/grippers/robotiq_85/params.json
+ROBOTIQ_85 = dict(_CROP_GRIPPER, init_bite=0.01)
+
+NUM_DY, DTHETA, RANGE_DTHETA = 10, 10, 90      # grasp_sampler.py:1413-1415
+APPROACH_STEP = 0.005                          # :1418
+MAX_NN = 100                                   # :1475
+TABLE_CLEARANCE = 0.01                         # :1599 safety_dis_above_table
+MIN_OPEN_POINTS = 10                           # :1614
+BOX_OPEN, BOX_LEFT, BOX_RIGHT, BOX_BOTTOM = 0, 1, 2, 3
+
+
+def _gripper_dict(gripper):
+    keys = ("hand_outer_diameter", "finger_width", "hand_depth", "hand_height", "init_bite")
+    if isinstance(gripper, dict):
+        return {k: float(gripper[k]) for k in keys}
+    return {k: float(getattr(gripper, k)) for k in keys}     # RobotGripper-like object
+
+
+# The hand model (:287-321) as a construction table: corner = parent + axis * scale.  Axes: a = approach,
+# b = binormal, m = unit(a x b).  Built in this order so that every corner sees the same sequence of roundings
+# as the reference's p1..p20 (negations and the factor 0.5 are exact).
+def _hand_table(g):
+    hh, fw, hd = g["hand_height"], g["finger_width"], g["hand_depth"]
+    ow = g["hand_outer_diameter"] - fw * 2
+    t = [("u", "c", "m", hh * 0.5), ("d", "c", "m", -(hh * 0.5)),
+         (5, "u", "b", -(ow * 0.5)), (6, "u", "b", ow * 0.5), (7, "d", "b", ow * 0.5), (8, "d", "b", -(ow * 0.5)),
+         (1, 5, "a", hd), (2, 6, "a", hd), (3, 7, "a", hd), (4, 8, "a", hd),
+         (9, 1, "b", -fw), (10, 4, "b", -fw), (11, 5, "b", -fw), (12, 8, "b", -fw),
+         (13, 2, "b", fw), (14, 3, "b", fw), (15, 6, "b", fw), (16, 7, "b", fw),
+         (17, 11, "a", -hh), (18, 15, "a", -hh), (19, 16, "a", -hh), (20, 12, "a", -hh)]
+    return t
+
+
+def hand_corners(g, center, approach, binormal):
+    """(..., 3) arrays -> (..., 20, 3): corners p1..p20 of the hand model in the world frame."""
+    center, approach, binormal = (np.asarray(v, dtype=np.float64) for v in (center, approach, binormal))
+    m = np.cross(approach, binormal)
+    m = m / np.linalg.norm(m, axis=-1, keepdims=True)
+    axes = {"a": approach, "b": binormal, "m": m}
+    pts = {"c": center}
+    for name, parent, ax, scale in _hand_table(g):
+        pts[name] = axes[ax] * scale + pts[parent]
+    return np.stack([pts[i] for i in range(1, 21)], axis=-2)
+
+
+def hand_boxes(g):
+    """(4,6) strict bounds [x_lo, x_hi, y_lo, y_hi, z_lo, z_hi] of p_open, p_left, p_right, p_bottom (:361-377)."""
+    c = hand_corners(g, np.zeros(3), np.array([1.0, 0, 0]), np.array([0, 1.0, 0]))
+    p = {i + 1: c[i] for i in range(20)}
+    sel = [(p[1], p[2], p[4], p[8]), (p[9], p[1], p[10], p[12]), (p[2], p[13], p[3], p[7]), (p[11], p[15], p[12], p[20])]
+    return np.array([[s8[0], s4[0], s1[1], s2[1], s4[2], s1[2]] for s1, s2, s4, s8 in sel])
+
+
+def _rotations(minor):
+    """(K,3) minor axes -> (K,R,3,3): rotation_from_quaternion([dtheta_rad, minor]) for the dtheta sweep (:1524-1529)."""
+    dth = np.arange(-RANGE_DTHETA, RANGE_DTHETA + 1, DTHETA).astype(np.float64) / 180 * np.pi
+    K, R = minor.shape[0], dth.shape[0]
+    q = np.empty((K, R, 4))                      # xyzw
+    q[:, :, :3] = minor[:, None, :]
+    q[:, :, 3] = dth[None, :]
+    nq = (q * q).sum(-1, keepdims=True)
+    q = q * np.sqrt(2.0 / nq)
+    o = q[..., :, None] * q[..., None, :]
+    rot = np.empty((K, R, 3, 3))
+    rot[..., 0, 0] = 1.0 - o[..., 1, 1] - o[..., 2, 2]; rot[..., 0, 1] = o[..., 0, 1] - o[..., 2, 3]; rot[..., 0, 2] = o[..., 0, 2] + o[..., 1, 3]
+    rot[..., 1, 0] = o[..., 0, 1] + o[..., 2, 3]; rot[..., 1, 1] = 1.0 - o[..., 0, 0] - o[..., 2, 2]; rot[..., 1, 2] = o[..., 1, 2] - o[..., 0, 3]
+    rot[..., 2, 0] = o[..., 0, 2] - o[..., 1, 3]; rot[..., 2, 1] = o[..., 1, 2] + o[..., 0, 3]; rot[..., 2, 2] = 1.0 - o[..., 0, 0] - o[..., 1, 1]
+    tiny = nq[..., 0] < np.finfo(float).eps * 4.0
+    rot[tiny] = np.identity(3)
+    return rot
+
+
+def _unit(v):
+    return v / np.linalg.norm(v, axis=-1, keepdims=True)
+
+
+# ------------------------------------------------------------------------------------------------
+# device entry points
+# ------------------------------------------------------------------------------------------------
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _check_cloud(cloud):
+    if not cloud.is_cuda or cloud.dim() != 2 or cloud.shape[1] != 3 or cloud.dtype not in (torch.float32, torch.float64):
+        raise RuntimeError("cloud: expected a CUDA (P,3) float32/float64 tensor")
+    return cloud.contiguous()
+
+
+def normal_moments(cloud, normals, queries, radius, max_nn=MAX_NN):
+    """cloud (P,3) CUDA f32|f64, normals (P,3) CUDA f64, queries (K,3) CUDA f64 -> M (K,3,3) f64, nsel (K) int32."""
+    lib = _lib.load()
+    cloud = _check_cloud(cloud)
+    if not normals.is_cuda or normals.dtype != torch.float64 or tuple(normals.shape) != tuple(cloud.shape):
+        raise RuntimeError("normals: expected a CUDA (P,3) float64 tensor")
+    if not queries.is_cuda or queries.dtype != torch.float64 or queries.dim() != 2 or queries.shape[1] != 3:
+        raise RuntimeError("queries: expected a CUDA (K,3) float64 tensor")
+    normals, queries = normals.contiguous(), queries.contiguous()
+    K = queries.shape[0]
+    M = torch.empty(K, 3, 3, device=cloud.device, dtype=torch.float64)
+    nsel = torch.empty(K, device=cloud.device, dtype=torch.int32)
+    with torch.cuda.device(cloud.device):
+        _lib.check(lib.pngpd_gpg_normal_moments(_p(cloud), int(cloud.dtype == torch.float64), _p(normals),
+                                                cloud.shape[0], _p(queries), K, float(radius), int(max_nn), _p(M),
+                                                _p(nsel), _stream(cloud)), "gpg_normal_moments")
+    return M, nsel
+
+
+def hand_box_counts(cloud, poses, boxes):
+    """cloud (P,3) CUDA; poses (Q,12) CUDA f64 [centre, approach, binormal, minor] (unit axes); boxes (NB,6) CUDA f64,
+    NB in {1,4} -> counts (Q,NB) int32: cloud points strictly inside each box of each pose."""
+    lib = _lib.load()
+    cloud = _check_cloud(cloud)
+    if not poses.is_cuda or poses.dtype != torch.float64 or poses.dim() != 2 or poses.shape[1] != 12:
+        raise RuntimeError("poses: expected a CUDA (Q,12) float64 tensor")
+    if not boxes.is_cuda or boxes.dtype != torch.float64 or boxes.dim() != 2 or boxes.shape[1] != 6:
+        raise RuntimeError("boxes: expected a CUDA (NB,6) float64 tensor")
+    poses, boxes = poses.contiguous(), boxes.contiguous()
+    Q, NB = poses.shape[0], boxes.shape[0]
+    counts = torch.empty(Q, NB, device=cloud.device, dtype=torch.int32)
+    if Q == 0:
+        return counts
+    with torch.cuda.device(cloud.device):
+        _lib.check(lib.pngpd_hand_box_counts(_p(cloud), int(cloud.dtype == torch.float64), cloud.shape[0], _p(poses),
+                                             Q, _p(boxes), NB, _p(counts), _stream(cloud)), "hand_box_counts")
+    return counts
+
+
+# ------------------------------------------------------------------------------------------------
+# the sampler
+# ------------------------------------------------------------------------------------------------
+class GpgGraspSamplerPcl:
+    """Drop-in for ``dexnet.grasping.GpgGraspSamplerPcl``: ``sample_grasps(point_cloud, points_for_sample,
+    all_normal, num_grasps, max_num_samples)`` -> list of ``[bottom_center, approach, binormal, minor,
+    bottom_center_modified]`` (five (3,) float64 arrays per grasp; :1616-1618) in the reference's order.
+
+    gripper: dict or RobotGripper-like object with hand_outer_diameter, finger_width, hand_depth, hand_height,
+    init_bite (default: robotiq_85).  ``config`` is accepted for signature compatibility and unused, as in the
+    Pcl sampler."""
+
+    def __init__(self, gripper=None, config=None, device=None):
+        self.gripper = gripper if gripper is not None else ROBOTIQ_85
+        self.config = config
+        self.device = torch.device(device) if device is not None else None
+        self.last_stats = {}
+
+    # -- device work for one batch of draws --------------------------------------------------
+    def _run_batch(self, g, cloud_d, normals_d, boxes_d, sel_pts, normals_at_ind):
+        """sel_pts (K,3) sample points, normals_at_ind (K,3) -> (m_zero (K,) bool, per-draw list of (n,5,3) arrays)."""
+        dev = cloud_d.device
+        K = sel_pts.shape[0]
+        fw, hd = g["finger_width"], g["hand_depth"]
+        r_ball = max(g["hand_outer_diameter"] - fw, hd, g["hand_height"] / 2.0)                  # :1464
+        M, _ = normal_moments(cloud_d, normals_d, torch.from_numpy(sel_pts).to(dev), r_ball, MAX_NN)
+        M = M.cpu().numpy()
+        m_zero = M.sum((1, 2)) == 0                                                             # :1486
+        empty = np.zeros((0, 5, 3))
+        res = [empty] * K
+        live = np.nonzero(~m_zero)[0]
+        if live.size == 0:
+            return m_zero, res
+        # local frames (:1493-1512) — np.linalg.eig exactly as the reference calls it
+        eigval, eigvec = np.linalg.eig(M[live])
+        eigval, eigvec = np.real(eigval), np.real(eigvec)
+        ar = np.arange(live.size)
+        minor = _unit(eigvec[ar, :, np.argmin(eigval, 1)])
+        normal = _unit(eigvec[ar, :, np.argmax(eigval, 1)])
+        major = np.cross(minor, normal)
+        nm = np.linalg.norm(major, axis=1, keepdims=True)
+        major = np.where(nm != 0, major / np.where(nm != 0, nm, 1.0), major)
+        flip = (normals_at_ind[live] * normal).sum(1) < 0
+        normal = np.where(flip[:, None], -normal, normal)
+        minor = np.where(flip[:, None], -minor, minor)
+        # pose sweep (:1524-1541): (L, R, D) poses
+        rot = _rotations(minor)                                                                 # (L,R,3,3)
+        dys = np.arange(-NUM_DY * fw, (NUM_DY + 1) * fw, fw)                                    # :1531
+        binormal = np.einsum("lrij,lj->lri", rot, major)
+        approach = np.einsum("lrij,lj->lri", rot, normal)
+        L, R, D = live.size, rot.shape[1], dys.shape[0]
+        bottom = sel_pts[live][:, None, None, :] + binormal[:, :, None, :] * dys[None, None, :, None]
+        bottom = g["init_bite"] * (-approach[:, :, None, :]) + bottom                           # (L,R,D,3)
+        poses = np.empty((L, R, D, 12))
+        poses[..., 0:3] = bottom
+        poses[..., 3:6] = _unit(approach)[:, :, None, :]
+        poses[..., 6:9] = _unit(binormal)[:, :, None, :]
+        poses[..., 9:12] = _unit(minor)[:, None, None, :]
+        cnt = hand_box_counts(cloud_d, torch.from_numpy(poses.reshape(-1, 12)).to(dev), boxes_d)
+        cnt = cnt.cpu().numpy().reshape(L, R, D, 4)
+        ok = (cnt[..., BOX_OPEN] > 0) & (cnt[..., BOX_BOTTOM] == 0) & (cnt[..., BOX_LEFT] == 0) & (cnt[..., BOX_RIGHT] == 0)
+        # the middle admissible offset per rotation (:1565-1567) ...
+        n_ok = ok.sum(-1)
+        target = np.ceil(n_ok / 2).astype(np.int64) - 1
+        rank = np.cumsum(ok, -1) - 1
+        pick = ok & (rank == target[..., None])
+        li, ri, di = np.nonzero(pick)                                                           # ordered by (l, r)
+        p0 = bottom[li, ri, di]
+        pa, pb, pm = approach[li, ri], binormal[li, ri], minor[li]
+        # ... kept if the fingers point down by more than 30 degrees (:1570-1573)
+        keep = (p0 + pa * hd)[:, 2] < p0[:, 2] - hd * 0.5
+        li, p0, pa, pb, pm = li[keep], p0[keep], pa[keep], pb[keep], pm[keep]
+        self.last_stats["potential"] = self.last_stats.get("potential", 0) + int(keep.sum())
+        if li.size == 0:
+            return m_zero, res
+        # push-in (:1575-1612): every step and its backed-off, table-corrected twin
+        S = int(hd / APPROACH_STEP)
+        steps = np.arange(S, dtype=np.float64)
+        c_s = pa[:, None, :] * steps[None, :, None] * APPROACH_STEP + p0[:, None, :]            # (Np,S,3)
+        back = c_s + (-pa[:, None, :]) * APPROACH_STEP * 3
+        A = np.broadcast_to(pa[:, None, :], back.shape)
+        Bn = np.broadcast_to(pb[:, None, :], back.shape)
+        corners = hand_corners(g, back, A, Bn)                                                  # (Np,S,20,3)
+        zmin = corners[..., 2].min(-1)
+        low = np.take_along_axis(corners, np.argmin(corners[..., 2], -1)[..., None, None], axis=-2)[..., 0, :]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            tx = -low[..., 2] * A[..., 0] / A[..., 2] + low[..., 0]
+            ty = -low[..., 2] * A[..., 1] / A[..., 2] + low[..., 1]
+            dist = np.sqrt((low * low).sum(-1) + tx * tx + ty * ty) + TABLE_CLEARANCE             # :1605
+            mod = np.where((zmin < TABLE_CLEARANCE)[..., None], back - A * dist[..., None], back)
+        Np = li.size
+        ax = np.concatenate([_unit(pa), _unit(pb), _unit(pm)], 1)                               # (Np,9)
+        poses2 = np.empty((2, Np, S, 12))
+        poses2[0, :, :, 0:3] = c_s
+        poses2[1, :, :, 0:3] = np.where(np.isfinite(mod), mod, 1e30)                            # non-finite -> empty boxes
+        poses2[:, :, :, 3:12] = ax[None, :, None, :]
+        cnt2 = hand_box_counts(cloud_d, torch.from_numpy(poses2.reshape(-1, 12)).to(dev), boxes_d)
+        cnt2 = cnt2.cpu().numpy().reshape(2, Np, S, 4)
+        hit = (cnt2[..., BOX_BOTTOM] > 0) | (cnt2[..., BOX_LEFT] > 0) | (cnt2[..., BOX_RIGHT] > 0)   # check_collide
+        accept = hit[0] & (cnt2[1, ..., BOX_OPEN] > MIN_OPEN_POINTS) & ~hit[1]                  # :1614
+        found = accept.any(1)
+        s_first = np.argmax(accept, 1)                                                          # first accepted step (:1625 break)
+        sel = np.nonzero(found)[0]
+        grasps = np.stack([back[sel, s_first[sel]], pa[sel], pb[sel], pm[sel], mod[sel, s_first[sel]]], 1)   # (n,5,3)
+        owner = live[li[sel]]
+        for k in np.unique(owner):
+            res[k] = grasps[owner == k]
+        return m_zero, res
+
+    def sample_grasps(self, point_cloud, points_for_sample, all_normal, num_grasps=20, max_num_samples=200,
+                      show_final_grasp=False, sample_indices=None, seed=None, as_array=False, **kwargs):
+        g = _gripper_dict(self.gripper)
+        self.last_stats = {"draws": 0, "sampled": 0, "potential": 0}
+        if isinstance(point_cloud, torch.Tensor):
+            cloud_d = point_cloud if self.device is None else point_cloud.to(self.device)
+        else:
+            pc = point_cloud.to_array() if hasattr(point_cloud, "to_array") else np.asarray(point_cloud)
+            if pc.dtype not in (np.float32, np.float64):
+                pc = pc.astype(np.float64)
+            dev = self.device or torch.device("cuda", torch.cuda.current_device())
+            cloud_d = torch.from_numpy(np.ascontiguousarray(pc)).to(dev)
+        if not cloud_d.is_cuda:
+            raise RuntimeError("GpgGraspSamplerPcl runs on the GPU: pass a CUDA cloud or construct with device='cuda'")
+        dev = cloud_d.device
+        all_normal = np.asarray(all_normal.cpu() if isinstance(all_normal, torch.Tensor) else all_normal, dtype=np.float64)
+        pfs = np.asarray(points_for_sample.cpu() if isinstance(points_for_sample, torch.Tensor) else points_for_sample,
+                         dtype=np.float64).reshape(-1, 3)
+        normals_d = torch.from_numpy(np.ascontiguousarray(all_normal)).to(dev)
+        boxes_d = torch.from_numpy(hand_boxes(g)).to(dev)
+        out = []
+        if num_grasps <= 0 or max_num_samples <= 0 or pfs.shape[0] == 0:                       # :1432 loop never entered
+            return np.zeros((0, 5, 3)) if as_array else out
+        rng = np.random.default_rng(seed)
+        explicit = None if sample_indices is None else np.asarray(sample_indices, dtype=np.int64).reshape(-1)
+        pos, sampled, done = 0, 0, False
+        while not done:
+            want = max_num_samples - sampled
+            if explicit is not None:
+                draws = explicit[pos:pos + want]
+                if draws.size == 0:
+                    break
+            else:
+                if self.last_stats["draws"] >= 10 * max_num_samples:
+                    break                                            # degenerate cloud: the reference would spin here
+                draws = rng.integers(0, pfs.shape[0], size=want)
+            pos += draws.size
+            m_zero, res = self._run_batch(g, cloud_d, normals_d, boxes_d, pfs[draws], all_normal[draws])
+            for k in range(draws.size):
+                self.last_stats["draws"] += 1
+                if m_zero[k]:
+                    continue                                         # :1486-1489 — not counted
+                out.extend(res[k])
+                sampled += 1
+                if len(out) >= num_grasps or sampled >= max_num_samples:                      # :1639
+                    done = True
+                    break
+        self.last_stats["sampled"] = sampled
+        if as_array:
+            return np.stack(out, 0) if out else np.zeros((0, 5, 3))
+        return [[v.copy() for v in gr] for gr in out]

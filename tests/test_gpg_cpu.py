@@ -1,0 +1,68 @@
+"""CPU: the GPG-sampler oracle against the goldens recorded from the EXECUTED reference
+(oracle/make_golden_gpg.py), and the host half of the product sampler (hand model, rotation sweep)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import gpg_oracle as go
+from tests.helpers import GOLDEN
+
+CASES = sorted(os.path.basename(p)[4:-4] for p in glob.glob(os.path.join(GOLDEN, "gpg_*.npz")))
+
+
+def load_case(tag):
+    fx = np.load(os.path.join(GOLDEN, f"gpg_{tag}.npz"))
+    pts, nrm = go.synth_scene(str(fx["kind"]), int(fx["P"]), int(fx["seed_scene"]))
+    assert pts.sum() == fx["pts_sum"] and nrm.sum() == fx["nrm_sum"]       # the scene generator is reproducible
+    return fx, pts, pts[pts[:, 2] > 0.010], nrm
+
+
+def test_golden_inventory():
+    assert set(CASES) >= {"cyl", "box", "ell", "cyl_stop", "box_big"}
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_oracle_matches_executed_reference(tag):
+    fx, pts, pfs, nrm = load_case(tag)
+    got = go.sample_grasps(pts, pfs, nrm, fx["draws"], int(fx["num_grasps"]), int(fx["max_num_samples"]))
+    got = np.array(got).reshape(-1, 5, 3)
+    assert got.shape == fx["grasps"].shape and got.shape[0] > 0
+    np.testing.assert_allclose(got, fx["grasps"], rtol=0, atol=1e-13)
+
+
+def test_host_half_matches_oracle():
+    from pointnetgpd_amd import gpg
+    g = gpg._gripper_dict(gpg.ROBOTIQ_85)
+    assert g == {k: go.ROBOTIQ_85[k] for k in g}
+    rng = np.random.default_rng(0)
+    hp = go.hand_points(go.ROBOTIQ_85, np.zeros(3), np.array([1.0, 0, 0]), np.array([0, 1.0, 0]))
+    boxes = gpg.hand_boxes(g)
+    for i, w in enumerate(go.WAYS):                       # product order: open, left, right, bottom
+        assert np.array_equal(boxes[i], go.way_box(hp, w))
+    for _ in range(20):
+        a = rng.normal(size=3); a /= np.linalg.norm(a)
+        b = np.cross(a, rng.normal(size=3)); b /= np.linalg.norm(b)
+        c = rng.normal(size=3) * 0.1
+        np.testing.assert_allclose(gpg.hand_corners(g, c, a, b), go.hand_points(go.ROBOTIQ_85, c, a, b)[1:], atol=1e-16)
+    minor = rng.normal(size=(5, 3)); minor /= np.linalg.norm(minor, axis=1, keepdims=True)
+    rot = gpg._rotations(minor)
+    assert rot.shape == (5, 19, 3, 3)
+    for k in range(5):
+        for r, dth in enumerate(np.arange(-90, 91, 10)):
+            ref = go.rotation_from_quaternion(np.array([np.float64(dth) / 180 * np.pi, *minor[k]]))
+            np.testing.assert_allclose(rot[k, r], ref, atol=1e-15)
+    # the quirk: dtheta = 0 is a half turn about the minor axis, not the identity
+    np.testing.assert_allclose(rot[0, 9] @ minor[0], minor[0], atol=1e-15)
+    assert abs(np.trace(rot[0, 9]) + 1.0) < 1e-14
+
+
+def test_sampler_needs_the_gpu():
+    from pointnetgpd_amd import gpg
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    pts, nrm = go.synth_scene("box", 200, 1)
+    with pytest.raises((RuntimeError, AssertionError)):
+        gpg.GpgGraspSamplerPcl().sample_grasps(pts, pts, nrm, 5, 5)
