@@ -13,10 +13,11 @@ Restates (citations relative to /root/reference/):
 Parity pin: ``collect_pc`` of the unmodified reference is importable in the
 build container (open3d stubbed); ``oracle/make_golden.py`` runs it on seeded
 synthetic clouds and commits inputs+outputs under ``tests/golden/``.
-``kinect2grasp.py`` cannot be imported anywhere (rospy, pcl …): the
-inference-style restatement is therefore *unpinned by execution* and anchored
-only on a line-by-line reading of kinect2grasp.py:178-258 — stated as such in
-DESIGN.md.
+``kinect2grasp.py`` cannot be imported (rospy, pcl, node start-up at module level), but its
+two crop functions only need numpy and a sampler object: ``oracle/make_golden_gpg.py`` cuts their
+unmodified source segments out of the reference file with ``ast`` and executes them; the record
+(102 grasps on 3 scenes: index sets, hand-frame points) is ``tests/golden/crop_infer.npz`` and pins
+``collect_pc_infer`` below (``tests/test_gpg_cpu.py``).
 """
 from __future__ import annotations
 

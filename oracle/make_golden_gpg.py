@@ -113,6 +113,60 @@ CASES = [  # tag, kind, P, seed_scene, seed_draws, num_grasps, max_num_samples
 ]
 
 
+KINECT_FILE = "/root/reference/dex-net/apps/kinect2grasp.py"
+
+
+def load_kinect2grasp_crop(mod):
+    """kinect2grasp.py cannot be imported (rospy, pcl, argparse + node start-up at module level), but its two crop
+    functions (check_collision_square :178-235, collect_pc :238-258) only touch numpy and the module-global sampler
+    ``ags``.  Their UNMODIFIED source segments are cut out of the reference file with ``ast`` at run time and
+    executed in a namespace holding numpy and a reference sampler object — nothing is copied into the repo."""
+    import ast
+    src = open(KINECT_FILE).read()
+    tree = ast.parse(src)
+    want = {"check_collision_square", "collect_pc"}
+    segs = [ast.get_source_segment(src, n) for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in want]
+    assert len(segs) == 2
+    ags = object.__new__(mod.GpgGraspSamplerPcl)
+    ags.gripper = types.SimpleNamespace(**go.ROBOTIQ_85)
+    ns = {"np": np, "ags": ags}
+    for seg in segs:
+        exec(compile(seg, KINECT_FILE, "exec"), ns)
+    return ns["collect_pc"]
+
+
+def infer_crop_cases(mod):
+    """Inference-style crop record: scenes x grasp rows (the sampler's own output + random frames) ->
+    per-grasp in-box index sets and hand-frame points, from the executed reference functions."""
+    collect_pc = load_kinect2grasp_crop(mod)
+    rec = {}
+    rng = np.random.default_rng(99)
+    for c, (tag, kind, P, ss) in enumerate([("cyl", "cylinder", 1500, 11), ("box", "box", 2000, 12),
+                                            ("ell", "ellipsoid", 1200, 13)]):
+        pts, _ = go.synth_scene(kind, P, ss)
+        pts32 = pts.astype(np.float32)                                         # kinect2grasp.py:112
+        sampled = np.load(os.path.join(OUT, f"gpg_{tag}.npz"))["grasps"]
+        G2 = 12
+        a = rng.normal(size=(G2, 3)); a /= np.linalg.norm(a, axis=1, keepdims=True)
+        b = np.cross(a, rng.normal(size=(G2, 3))); b /= np.linalg.norm(b, axis=1, keepdims=True)
+        b *= rng.uniform(0.5, 2.0, (G2, 1))                                    # un-normalised axes are normalised (:180-185)
+        m = np.cross(a, b)
+        bottom = pts[rng.integers(0, P, G2)] - 0.05 * a
+        rand = np.stack([bottom, a, b, m, bottom], 1)
+        grasps = np.concatenate([sampled, rand], 0)
+        ind, inpts = collect_pc([list(g) for g in grasps], pts32)
+        rec[f"kind_{c}"] = kind; rec[f"P_{c}"] = P; rec[f"seed_{c}"] = ss
+        rec[f"grasps_{c}"] = grasps
+        rec[f"counts_{c}"] = np.array([len(i) for i in ind])
+        rec[f"ind_{c}"] = np.concatenate(ind).astype(np.int16)              # P < 32768
+        # hand-frame coordinates: first 3 rows per grasp + per-grasp column sums (the full record would be 2 MB)
+        rec[f"pts_head_{c}"] = np.stack([np.concatenate([p_[:3], np.zeros((3 - min(3, len(p_)), 3))]) for p_ in inpts])
+        rec[f"pts_sum_{c}"] = np.stack([p_.sum(0) for p_ in inpts])
+        print(f"crop_infer {tag}: {len(grasps)} grasps, counts {rec[f'counts_{c}'].tolist()}")
+    rec["n_cases"] = 3
+    np.savez_compressed(os.path.join(OUT, "crop_infer.npz"), **rec)
+
+
 def main():
     mod = load_reference()
     os.makedirs(OUT, exist_ok=True)
@@ -124,6 +178,7 @@ def main():
                             num_grasps=ng, max_num_samples=mx, grasps=grasps,
                             pts_sum=pts.sum(), nrm_sum=nrm.sum())
         print(f"{tag}: {len(draws)} draws -> {len(grasps)} grasps")
+    infer_crop_cases(mod)
 
 
 if __name__ == "__main__":

@@ -66,3 +66,32 @@ def test_sampler_needs_the_gpu():
     pts, nrm = go.synth_scene("box", 200, 1)
     with pytest.raises((RuntimeError, AssertionError)):
         gpg.GpgGraspSamplerPcl().sample_grasps(pts, pts, nrm, 5, 5)
+
+
+def _crop_infer_cases():
+    fx = np.load(os.path.join(GOLDEN, "crop_infer.npz"))
+    for c in range(int(fx["n_cases"])):
+        pts, _ = go.synth_scene(str(fx[f"kind_{c}"]), int(fx[f"P_{c}"]), int(fx[f"seed_{c}"]))
+        counts = fx[f"counts_{c}"]
+        ind = np.split(fx[f"ind_{c}"].astype(np.int64), np.cumsum(counts)[:-1])
+        yield pts.astype(np.float32), fx[f"grasps_{c}"], counts, ind, fx[f"pts_head_{c}"], fx[f"pts_sum_{c}"]
+
+
+def test_infer_crop_oracle_matches_executed_reference():
+    """kinect2grasp.py:178-258, cut out of the reference file and executed by oracle/make_golden_gpg.py — the pin
+    of the inference-style crop (oracle and host mirror)."""
+    from oracle import crop_oracle as co
+    from pointnetgpd_amd import crop
+    n = 0
+    for pc, grasps, counts, ind, head, psum in _crop_infer_cases():
+        ind_o, pts_o = co.collect_pc_infer(grasps, pc)
+        frames = crop.frames_from_grasps_infer(grasps)
+        for g in range(len(grasps)):
+            assert np.array_equal(ind_o[g], ind[g])
+            k = min(3, counts[g])
+            np.testing.assert_allclose(pts_o[g][:k], head[g][:k], rtol=0, atol=1e-15)
+            np.testing.assert_allclose(pts_o[g].sum(0), psum[g], rtol=0, atol=1e-12)
+            ih, ph = crop.collect_pc_numpy(frames[g], pc)            # the product's host-side mirror
+            assert np.array_equal(ih, ind[g])
+            n += 1
+    assert n == 102

@@ -192,3 +192,24 @@ def test_score_scene_distributed_single_rank(cuda_device):
     assert torch.equal(res["counts"], ref["counts"]) and torch.equal(res["score"], ref["score"])
     sc = res["score"][res["order"]]
     assert (sc[:-1] >= sc[1:]).all()
+
+
+def test_infer_crop_kernel_vs_executed_reference(cuda_device):
+    """Crop kernel vs the record of kinect2grasp.py:178-258 executed by oracle/make_golden_gpg.py: index sets exact."""
+    from pointnetgpd_amd import crop
+    from tests.test_gpg_cpu import _crop_infer_cases
+    for pc, grasps, counts_ref, ind_ref, head, _ in _crop_infer_cases():
+        frames = torch.from_numpy(crop.frames_from_grasps_infer(grasps)).to(cuda_device)
+        cloud = torch.from_numpy(pc).to(cuda_device)
+        counts, idx = crop.crop_count_compact(cloud, frames, max_keep=2048)
+        np.testing.assert_array_equal(counts.cpu().numpy(), counts_ref)
+        idx = idx.cpu().numpy()
+        for g in range(len(grasps)):
+            np.testing.assert_array_equal(idx[g, :counts_ref[g]], ind_ref[g])
+        # hand-frame coordinates of the first in-box points (fp32-rounded by the resample kernel)
+        N = 3
+        sel = torch.arange(N, dtype=torch.int32, device=cuda_device).repeat(len(grasps), 1)
+        out, valid = crop.crop_resample(cloud, frames, counts, torch.from_numpy(idx).to(cuda_device), N,
+                                        crop.MODE_INFER, 3, sel=sel)
+        for g in np.nonzero(counts_ref >= 3)[0]:
+            np.testing.assert_allclose(out[g].cpu().numpy().T, head[g].astype(np.float32), rtol=0, atol=1e-8)
