@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Every BASELINE.json config shape on ONE MI355X (per-GPU share where the config names 8 GPUs):
+eval forward and full training step (fwd + nll_loss + bwd + Adam), events on the current stream."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn.functional as F
+
+import bench
+from pointnetgpd_amd import train as pt
+from pointnetgpd_amd.model import pointnet as pn
+
+dev = torch.device("cuda:0")
+CONFIGS = [("C1 shape on GPU: B=64 N=750 k=2", 64, 750, 2),
+           ("C2: B=1024 N=1024 k=2", 1024, 1024, 2),
+           ("C3 per-GPU share: B=512 N=1024 k=3", 512, 1024, 3),
+           ("C4: B=512 N=4096 k=2", 512, 4096, 2)]
+
+
+def timeit(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    rows = []
+    for name, B, N, k in CONFIGS:
+        torch.manual_seed(0)
+        m = pn.PointNetCls(N, 3, k).to(dev)
+        x = bench.synth_clouds(B, N, 1, dev)
+        y = torch.randint(0, k, (B,), device=dev)
+        flops = B * (N * 557842 + 2627072)
+        row = dict(config=name)
+        for prec in ("fp32", "bf16x3"):
+            pn.set_inference_precision(prec)
+            m.eval()
+            with torch.no_grad():
+                ms = timeit(lambda: m(x), 20)
+            row[f"infer_{prec}_ms"] = round(ms, 3)
+            row[f"infer_{prec}_grasps_s"] = round(B / ms * 1e3)
+            if prec == "fp32":
+                row["infer_fp32_tflops"] = round(flops / ms / 1e9, 1)
+        pn.set_inference_precision("fp32")
+        for prec in ("fp32", "bf16x3"):
+            pt.set_train_precision(prec)
+            m.train()
+            opt = torch.optim.Adam(m.parameters(), lr=0.005)
+
+            def step():
+                opt.zero_grad(set_to_none=True)
+                logp, _ = m(x)
+                F.nll_loss(logp, y).backward()
+                opt.step()
+            ms = timeit(step, 8)
+            row[f"train_{prec}_ms"] = round(ms, 3)
+            row[f"train_{prec}_grasps_s"] = round(B / ms * 1e3)
+        pt.set_train_precision("fp32")
+        rows.append(row)
+        print(json.dumps(row))
+    return rows
+
+
+if __name__ == "__main__":
+    main()

@@ -9,11 +9,13 @@ in full; everything else is folded into one 'other' line.
 import sqlite3
 import sys
 
-OURS = ("trunk_", "fc_", "pool_reduce", "fold_conv_bn", "crop_", "resample", "bn_", "pngpd")
+OURS = ("trunk_", "fc_", "pool_", "fold_conv_bn", "crop_", "resample", "bn", "pngpd", "gpg_", "hand_box", "split_pack",
+        "cloud_moments", "a_cvec", "bwd_e_prep", "dtrans", "dw1_", "dw3_", "log_softmax_bwd", "reduce_partials")
 
 
 def short(name):
-    return name.split("(")[0]
+    n = name.split("(")[0]
+    return n[5:] if n.startswith("void ") else n
 
 
 def main():
