@@ -164,3 +164,33 @@ def score_scene_distributed(score_fn, scene_cloud, grasps, group=None):
     vi = torch.nonzero(valid).squeeze(1)
     order = vi[torch.argsort(score[vi], descending=True, stable=True)]
     return dict(pred=pred, score=score, counts=counts, valid=valid, order=order)
+
+
+def detect_grasps(scene_cloud, surface_normal, scorer, sampler=None, num_grasps=40, max_num_samples=150,
+                  select_point_above_table=0.010, sample_indices=None, seed=None):
+    """One scene through the whole inference chain of ``kinect2grasp.py`` (minus ROS I/O, voxelisation and pcl's
+    normal estimation, which stay upstream): ``cal_grasp`` :141-150 (sample points above the table -> GPG
+    sampler) -> ``collect_pc`` :443 (in-gripper crop) -> the scoring loop :454-514 (PointNet, vote, sort).
+
+    scene_cloud (P,3) numpy/tensor, surface_normal (P,3) outward normals, scorer: GraspScorer.
+    Returns dict(grasps (G,5,3) float64 — all sampled candidates —, plus GraspScorer.score's fields; ``order``
+    indexes the good grasps by descending score, i.e. ``grasps[order]`` is the reference's ``real_good_grasp``)."""
+    from . import gpg
+    pts = scene_cloud.cpu().numpy() if isinstance(scene_cloud, torch.Tensor) else np.asarray(scene_cloud)
+    dev = next(scorer.model.parameters()).device
+    if sampler is None:
+        sampler = gpg.GpgGraspSamplerPcl(gripper=dict(scorer.gripper, init_bite=gpg.ROBOTIQ_85["init_bite"]), device=dev)
+    pfs = pts[np.where(pts[:, 2] > select_point_above_table)[0]]                      # :141
+    cloud_d = torch.as_tensor(pts).to(dev)
+    if len(pfs) == 0:                                                                 # :142-144
+        grasps = np.zeros((0, 5, 3))
+    else:
+        grasps = sampler.sample_grasps(cloud_d, pfs, surface_normal, num_grasps, max_num_samples,
+                                       sample_indices=sample_indices, seed=seed, as_array=True)
+    if len(grasps) == 0:
+        e = torch.zeros(0, device=dev)
+        return dict(grasps=grasps, pred=e.long(), score=e, counts=e.int(), valid=e.bool(), good=e.bool(),
+                    order=e.long(), probs=torch.zeros(scorer.repeat, 0, scorer.model.fc3.out_features, device=dev))
+    res = scorer.score(cloud_d, grasps)
+    res["grasps"] = grasps
+    return res

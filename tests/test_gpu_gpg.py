@@ -132,3 +132,28 @@ def test_sampler_edge_cases(cuda_device):
     assert a.shape[1:] == (5, 3) and np.array_equal(a, b)
     with pytest.raises(RuntimeError, match="CUDA"):
         gpg.hand_box_counts(torch.zeros(4, 3), torch.zeros(1, 12, dtype=torch.float64), torch.zeros(4, 6, dtype=torch.float64))
+
+
+def test_detect_grasps_chain(cuda_device):
+    """sampler -> crop -> scorer in one call == the three stages composed by hand."""
+    from pointnetgpd_amd import gpg
+    from pointnetgpd_amd.scoring import GraspScorer, detect_grasps
+    from tests.helpers import build_model
+    pts, nrm = go.synth_scene("ellipsoid", 3000, 44)
+    pts32 = pts.astype(np.float32)
+    m = build_model(64, 3, 37, 4704).eval().to(cuda_device)
+    scorer = GraspScorer(m, num_points=64, repeat=1, batch=32, seed=9)
+    res = detect_grasps(pts32, nrm, scorer, num_grasps=30, max_num_samples=20, seed=5)
+    pfs = pts32[pts32[:, 2] > 0.010]
+    grasps = gpg.GpgGraspSamplerPcl(device=cuda_device).sample_grasps(pts32, pfs, nrm, 30, 20, seed=5, as_array=True)
+    assert len(grasps) > 0 and np.array_equal(res["grasps"], grasps)
+    ref = scorer.score(pts32, grasps)
+    for k_ in ("pred", "score", "counts", "valid", "good", "order"):
+        assert torch.equal(res[k_], ref[k_]), k_
+    # every sampled grasp passed the sampler's own > 10-points-between-the-fingers check, and the (larger) crop
+    # box of the scorer contains that region -> the crop counts are at least 11
+    assert int(res["counts"].min()) > 10
+    # empty scene above the table -> empty result, no launch
+    low = pts32.copy(); low[:, 2] = 0.0
+    res0 = detect_grasps(low, nrm, scorer)
+    assert res0["grasps"].shape == (0, 5, 3) and res0["order"].numel() == 0
