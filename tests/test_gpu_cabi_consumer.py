@@ -1,0 +1,81 @@
+"""GPU: the torch-free C++ consumer of the C ABI (examples/cabi_consumer.cpp, built by `make example` / build())
+against the same calls made through the ctypes binding AND a plain fp64 numpy evaluation of the same layers."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "examples", "cabi_consumer")
+
+
+class Lcg:
+    """The generator of examples/cabi_consumer.cpp."""
+
+    def __init__(self, s):
+        self.s = s
+
+    def fill(self, n, scale, shift=0.0):
+        out = np.empty(n, dtype=np.float32)
+        s = self.s
+        for i in range(n):
+            s = (s * 1664525 + 1013904223) & 0xFFFFFFFF
+            out[i] = s >> 8
+        self.s = s
+        u = out * np.float32(1.0 / 16777216.0) - np.float32(0.5)
+        return u * np.float32(scale) + np.float32(shift)
+
+
+@pytest.mark.parametrize("B,N", [(5, 200), (3, 1000)])
+def test_cabi_consumer_matches_binding(B, N, cuda_device):
+    from pointnetgpd_amd import ops
+    if not os.path.exists(EXE):          # normally built by __graft_entry__.build(); same toolchain on the GPU box
+        subprocess.run(["make", "-C", os.path.join(ROOT, "pointnetgpd_amd", "csrc"), "example"], check=True)
+    res = subprocess.run([EXE, str(B), str(N)], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    lines = res.stdout.strip().splitlines()
+    pool_cs = np.array([[float(v) for v in ln.split()[2:]] for ln in lines if ln.startswith("pool")])
+    fc = np.array([[float(v) for v in ln.split()[2:]] for ln in lines if ln.startswith("fc")])
+    assert pool_cs.shape == (B, 2) and fc.shape == (B, 9)
+
+    g = Lcg(12345)
+    x = g.fill(B * 3 * N, 0.1).reshape(B, 3, N)
+    T = g.fill(B * 9, 0.2).reshape(B, 3, 3)
+    T[:, np.arange(3), np.arange(3)] += np.float32(1.0)
+    C = [3, 64, 128, 1024]
+    layers = []
+    for l in range(3):
+        W = g.fill(C[l + 1] * C[l], 2.0 / C[l]).reshape(C[l + 1], C[l])
+        layers.append(dict(W=W, b=g.fill(C[l + 1], 0.1), g=g.fill(C[l + 1], 1.0, 1.0), be=g.fill(C[l + 1], 0.2),
+                           mu=g.fill(C[l + 1], 0.2), var=g.fill(C[l + 1], 1.0, 1.0)))
+    layers[2]["g"][::7] *= -1
+    Wfc = g.fill(9 * 1024, 0.05).reshape(9, 1024)
+    bfc = g.fill(9, 0.1)
+
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda_device)
+    folded = []
+    for l, L in enumerate(layers):
+        folded += list(ops.fold_conv_bn(t(L["W"]), t(L["b"]), t(L["g"]), t(L["be"]), t(L["mu"]), t(L["var"]), 1e-5,
+                                        ops.LAYOUT_ROWMAJOR if l == 0 else ops.LAYOUT_MFMA_B))
+    pool = ops.trunk_fwd_infer(t(x), t(T), *folded, False)
+    out = ops.fc_fwd(pool, t(Wfc), t(bfc), ops.EPI_ADD_IDEN3)
+    pool_np, out_np = pool.cpu().numpy().astype(np.float64), out.cpu().numpy()
+    # same library, same inputs -> same bits; the printed 10 significant digits bound the comparison
+    np.testing.assert_allclose(fc, out_np, rtol=2e-9, atol=0)
+    np.testing.assert_allclose(pool_cs[:, 0], pool_np.sum(1), rtol=1e-9)
+    np.testing.assert_allclose(pool_cs[:, 1], np.abs(pool_np).sum(1), rtol=1e-9)
+
+    # and both agree with a straight fp64 evaluation of conv+BN(eval)+ReLU, max over points, FC + identity
+    h = np.einsum("bji,bjn->bin", T.astype(np.float64), x.astype(np.float64))           # x' = x^T T  (pointnet.py:140-143)
+    for l, L in enumerate(layers):
+        z = np.einsum("ck,bkn->bcn", L["W"].astype(np.float64), h) + L["b"].astype(np.float64)[None, :, None]
+        s = L["g"].astype(np.float64) / np.sqrt(L["var"].astype(np.float64) + 1e-5)
+        z = (z - L["mu"].astype(np.float64)[None, :, None]) * s[None, :, None] + L["be"].astype(np.float64)[None, :, None]
+        h = np.maximum(z, 0) if l < 2 else z
+    ref_pool = h.max(2)
+    ref_fc = ref_pool @ Wfc.astype(np.float64).T + bfc + np.eye(3).reshape(1, 9)
+    np.testing.assert_allclose(pool_np, ref_pool, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(fc, ref_fc, rtol=0, atol=2e-4)
