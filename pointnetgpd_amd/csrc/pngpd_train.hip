@@ -459,7 +459,6 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
             for (int i = L.tid; i < TP * H2S; i += 256) sp[i] = 0.f;
             __syncthreads();
             // sparse term, deterministic order (waves' lists in order, ascending channel).  thread = (k, parity)
-#ifndef D_SKIP_SPARSE
             {
                 const int k = L.tid & 127, half = L.tid >> 7;
                 for (int w = 0; w < 4; ++w) {
@@ -482,7 +481,6 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
                     }
                 }
             }
-#endif
             __syncthreads();
             f32x16 d0, d1;
             k128_mfma(h2, D.Ap, cb, L, d0, d1);

@@ -106,9 +106,6 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
             }
         }
         __syncthreads();
-#ifdef X3_SKIP_L12
-        if (tile == t0)
-#endif
         {   // layer 1 (fp32 VALU): thread = (point p = tid & 127, 16-channel group g = tid >> 7 = wave >> 1)
             const int p = tid & 127, g = wave >> 1;
             const float x0 = xs[p], x1 = xs[XP + p], x2 = xs[2 * XP + p];
@@ -131,9 +128,6 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
             }
         }
         __syncthreads();
-#ifdef X3_SKIP_L12
-        if (tile == t0)
-#endif
         {   // layer 2 (64 -> 128), bf16x3: wave owns channel block cb = wave & 3 and point blocks 2q, 2q+1
             const int cb = wave & 3, pb0 = (wave >> 2) * 2;
             f32x4 w2h[4], w2l[4];
