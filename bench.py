@@ -168,7 +168,7 @@ def main():
     if not args.no_train:
         import torch.nn.functional as F
         tmodel = build_model(N, k, dev).train()
-        opt = torch.optim.Adam(tmodel.parameters(), lr=0.005)
+        opt = torch.optim.Adam(tmodel.parameters(), lr=0.005, fused=True)
         y = (torch.arange(B, device=dev) % k).long()
         params = [p for p in tmodel.parameters()]
         tsteps = max(3, args.steps // 4)
@@ -208,7 +208,7 @@ def main():
             # ~600 small kernels of the parameter-sized fp64 algebra between the passes
             del loss                       # no autograd state of the eager leg may stay alive
             gmodel = build_model(N, k, dev).train()
-            gopt = torch.optim.Adam(gmodel.parameters(), lr=0.005, capturable=True)
+            gopt = torch.optim.Adam(gmodel.parameters(), lr=0.005, capturable=True, fused=True)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -260,7 +260,7 @@ def main():
                           "value": round(world * B * tsteps / ftdt, 1), "ms_per_step": round(ftdt / tsteps * 1e3, 3)}
         train_res = {"value": round(world * B * tsteps / tdt, 1), "unit": "grasps/s", "steps": tsteps,
                      "ms_per_step": round(tdt / tsteps * 1e3, 3),
-                     "step": "fwd(batch-stat BN)+nll_loss+bwd+Adam" + ("+RCCL grad all-reduce" if dist else ""),
+                     "step": "fwd(batch-stat BN)+nll_loss+bwd+Adam(fused)" + ("+RCCL grad all-reduce" if dist else ""),
                      "tflops_effective_3x_fwd": round(world * B * tsteps / tdt * 3 * flops_per_grasp(N, k) / 1e12, 2)}
         if graph_res is not None:
             train_res["hip_graph_replay"] = graph_res

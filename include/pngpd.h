@@ -148,11 +148,12 @@ int pngpd_trunk_fwd_train(const float *x, int B, int N, const float *trans,
                           const float *w2p, const float *s2c, const float *t2c, const float *w3sp,
                           float *pmax, int *parg, float *psum, void *stream);
 
-/* second moments of the hidden activations (needed by the closed-form dW3 / dW2):
- *   ps2 (B,128,128) = sum_n h2 h2^T, ps1 (B,64,64) = sum_n h1 h1^T, psh (B,192) = [sum h2 | sum h1] */
+/* second moments of the hidden activations (needed by the closed-form dW3 / dW2), per workgroup; S workgroups
+ * share a cloud's tiles (1 <= S <= ceil(N/64); S > 1 fills the chip at small B):
+ *   ps2 (B*S,128,128) = sum_n h2 h2^T, ps1 (B*S,64,64) (reserved, zeros), psh (B*S,192) = [sum h2 | 0] */
 int pngpd_trunk_h_moments(const float *x, int B, int N, const float *trans,
                           const float *w1, const float *b1, const float *s1c, const float *t1c,
-                          const float *w2p, const float *s2c, const float *t2c,
+                          const float *w2p, const float *s2c, const float *t2c, int S,
                           float *ps2, float *ps1, float *psh, void *stream);
 
 /* sparse (arg-extremum) term of dW3:  Gp (ceil(B/clouds_per_range),1024,128),

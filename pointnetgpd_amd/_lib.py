@@ -40,7 +40,8 @@ SIGNATURES = {
     "pngpd_cloud_moments": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, c_f32p, c_void]),
     "pngpd_trunk_bn2_stats": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 7 + [c_void]),
     "pngpd_trunk_fwd_train": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 12 + [c_void]),
-    "pngpd_trunk_h_moments": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 11 + [c_void]),
+    "pngpd_trunk_h_moments": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 8 + [ctypes.c_int] +
+                              [c_f32p] * 3 + [c_void]),
     "pngpd_trunk_bwd_gather": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 10 +
                                [ctypes.c_int, c_f32p, c_void]),
     "pngpd_trunk_bwd_d": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 17 + [c_void]),

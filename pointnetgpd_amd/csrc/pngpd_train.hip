@@ -217,14 +217,16 @@ __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
 //   ps2 [blk][128][128]  ps1 [blk][64][64]  psh [blk][128+64]
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 1) void trunk_h_moments_kernel(
-    const float *__restrict__ x, int N, const float *__restrict__ trans, TrainChan P, int T,
+    const float *__restrict__ x, int N, const float *__restrict__ trans, TrainChan P, int T, int S,
     float *__restrict__ ps2, float *__restrict__ ps1, float *__restrict__ psh) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *h1 = smem;
     float *h2 = h1 + TP * H1S;
     float *xs = h2 + TP * H2S;
     const Lane L;
-    const int b = blockIdx.x;
+    const int blk = blockIdx.x, b = blk / S;   // S workgroups per cloud (small batches), each a range of tiles
+    int t0, t1;
+    tile_range(blk - b * S, S, T, t0, t1);
     const float *xb = x + (size_t)b * 3 * N;
     float tm[9] = {0};
     const bool has_t = trans != nullptr;
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(256, 1) void trunk_h_moments_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) s1a[r] = 0.f;
     float colsum = 0.f;
-    for (int tile = 0; tile < T; ++tile) {
+    for (int tile = t0; tile < t1; ++tile) {
         stage_points(xb, N, tile, has_t, tm, xs, nullptr, L.tid);
         __syncthreads();
         layer1_tile(xs, P.w1, P.b1, P.s1c, P.t1c, h1, L);
@@ -278,18 +280,18 @@ __global__ __launch_bounds__(256, 1) void trunk_h_moments_kernel(
         __syncthreads();
     }
     {
-        float *o2 = ps2 + (size_t)b * 128 * 128;
+        float *o2 = ps2 + (size_t)blk * 128 * 128;
         const int ib = L.wave;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 o2[(ib * 32 + mfma_row(r, L.lane)) * 128 + q * 32 + L.j] = s2a[q][r];
-        float *o1 = ps1 + (size_t)b * 64 * 64;
+        float *o1 = ps1 + (size_t)blk * 64 * 64;
         const int i1 = L.wave >> 1, j1 = L.wave & 1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) o1[(i1 * 32 + mfma_row(r, L.lane)) * 64 + j1 * 32 + L.j] = s1a[r];
-        if (L.tid < 192) psh[(size_t)b * 192 + L.tid] = colsum;
+        if (L.tid < 192) psh[(size_t)blk * 192 + L.tid] = colsum;
     }
 }
 
@@ -800,15 +802,16 @@ int pngpd_trunk_fwd_train(const float *x, int B, int N, const float *trans,
 
 int pngpd_trunk_h_moments(const float *x, int B, int N, const float *trans,
                           const float *w1, const float *b1, const float *s1c, const float *t1c,
-                          const float *w2p, const float *s2c, const float *t2c,
+                          const float *w2p, const float *s2c, const float *t2c, int S,
                           float *ps2, float *ps1, float *psh, void *stream) {
     if (!x || !w1 || !b1 || !s1c || !t1c || !w2p || !s2c || !t2c || !ps2 || !ps1 || !psh || B <= 0 || N <= 0)
         return PNGPD_ERR_INVALID_ARG;
     const int T = (N + TP - 1) / TP;
+    if (S < 1 || S > T) return PNGPD_ERR_INVALID_ARG;
     TrainChan P = make_chan(w1, b1, s1c, t1c, w2p, s2c, t2c);
     const size_t lds = (TP * H1S + TP * H2S + 3 * TP) * sizeof(float);
-    hipLaunchKernelGGL(trunk_h_moments_kernel, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream,
-                       x, N, trans, P, T, ps2, ps1, psh);
+    hipLaunchKernelGGL(trunk_h_moments_kernel, dim3((unsigned)B * S), dim3(256), lds, (hipStream_t)stream,
+                       x, N, trans, P, T, S, ps2, ps1, psh);
     return pngpd_launch_status();
 }
 

@@ -67,6 +67,9 @@ def build_parser():
     p.add_argument("--max-batches", type=int, default=0, help="stop every epoch after this many batches")
     p.add_argument("--persistent-optimizer", action="store_true",
                    help="main_1v only: keep one optimizer/scheduler (fixes main_1v.py:60-62)")
+    p.add_argument("--hip-graph", action="store_true",
+                   help="single-GPU --cuda training: replay full-size batches from a captured HIP graph "
+                        "(train.GraphedTrainStep); ragged batches (my_collate dropped samples) run eagerly")
     p.add_argument("--log-dir", type=str, default="./assets/log/")
     return p
 
@@ -181,11 +184,20 @@ def run(variant, argv=None):
     model = model.to(device)
     averager = ddp.GradAverager(model) if world > 1 else None
 
-    state = {"optimizer": None, "scheduler": None}
+    state = {"optimizer": None, "scheduler": None, "graph": None}
+    use_graph = bool(args.hip_graph and args.cuda and averager is None)
+    if args.hip_graph and not use_graph and rank == 0:
+        print("--hip-graph ignored (needs --cuda and a single process)")
 
     def new_optimizer():
-        state["optimizer"] = optim.Adam(model.parameters(), lr=args.lr)
+        if use_graph:      # capturable Adam with the lr in a device tensor: StepLR fills it in place
+            state["optimizer"] = optim.Adam(model.parameters(), lr=torch.tensor(float(args.lr), device=device),
+                                            capturable=True, fused=True)
+        else:
+            # same Adam (main_1v.py:61); on the GPU the fused implementation: 2 launches instead of ~45
+            state["optimizer"] = optim.Adam(model.parameters(), lr=args.lr, fused=bool(args.cuda))
         state["scheduler"] = StepLR(state["optimizer"], step_size=30, gamma=0.5)
+        state["graph"] = None
 
     recreate = cfg["recreate_optimizer"] and not args.persistent_optimizer
     if not recreate:
@@ -210,15 +222,21 @@ def run(variant, argv=None):
             dataset_size += data.shape[0]
             data, target = data.float(), target.long().squeeze()
             data, target = data.to(device), target.to(device)
-            if averager is not None:
-                averager.sync_buffers()
-            optimizer.zero_grad()
-            output, _ = model(data)
-            loss = F.nll_loss(output, target)
-            loss.backward()
-            if averager is not None:
-                averager.average_gradients()
-            optimizer.step()
+            if use_graph and data.shape[0] == args.batch_size and target.dim() == 1:
+                if state["graph"] is None:
+                    from .train import GraphedTrainStep
+                    state["graph"] = GraphedTrainStep(model, data.shape[0], data.shape[2], optimizer=optimizer)
+                loss, output = state["graph"](data, target)
+            else:
+                if averager is not None:
+                    averager.sync_buffers()
+                optimizer.zero_grad()
+                output, _ = model(data)
+                loss = F.nll_loss(output, target)
+                loss.backward()
+                if averager is not None:
+                    averager.average_gradients()
+                optimizer.step()
             pred = output.data.max(1, keepdim=True)[1]
             correct += pred.eq(target.view_as(pred)).long().cpu().sum()
             if batch_idx % args.log_interval == 0 and rank == 0:

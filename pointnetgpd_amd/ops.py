@@ -223,17 +223,27 @@ def trunk_fwd_train_x3(x, trans, w1, b1, s1c, t1c, w2x, s2c, t2c, w3sx):
     return pmax, parg, psum, S
 
 
+def h_moments_splits(B, N):
+    """Workgroups per cloud for the h-moments pass: 1 once B alone fills the 256 CUs, else enough to reach them."""
+    T = (N + 63) // 64
+    return 1 if B >= 256 else max(1, min(T, (256 + B - 1) // B))
+
+
 def trunk_h_moments(x, trans, w1, b1, s1c, t1c, w2p, s2c, t2c):
+    """-> per-workgroup partials ps2 (B*S,128,128), ps1 (B*S,64,64), psh (B*S,192); reduce over dim 0."""
     B, _, N = x.shape
-    ps2 = torch.empty(B, 128, 128, device=x.device, dtype=torch.float32)
-    ps1 = torch.empty(B, 64, 64, device=x.device, dtype=torch.float32)
-    psh = torch.empty(B, 192, device=x.device, dtype=torch.float32)
-    _call("pngpd_trunk_h_moments", x, x, B, N, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, ps2, ps1, psh)
+    S = h_moments_splits(B, N)
+    ps2 = torch.empty(B * S, 128, 128, device=x.device, dtype=torch.float32)
+    ps1 = torch.empty(B * S, 64, 64, device=x.device, dtype=torch.float32)
+    psh = torch.empty(B * S, 192, device=x.device, dtype=torch.float32)
+    _call("pngpd_trunk_h_moments", x, x, B, N, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, int(S), ps2, ps1, psh)
     return ps2, ps1, psh
 
 
-def trunk_bwd_gather(x, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, idx, coef, clouds_per_range=16):
+def trunk_bwd_gather(x, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, idx, coef, clouds_per_range=None):
     B, _, N = x.shape
+    if clouds_per_range is None:      # 16 workgroups per range: ~256 workgroups at small B, 16 clouds per range at large B
+        clouds_per_range = max(1, min(16, B // 16))
     R = (B + clouds_per_range - 1) // clouds_per_range
     Gp = torch.empty(R, 1024, 128, device=x.device, dtype=torch.float32)
     _call("pngpd_trunk_bwd_gather", x, x, B, N, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, idx, coef,

@@ -131,8 +131,8 @@ class TrunkTrainFn(torch.autograd.Function):
               dbe3, m12)
         # ---- hidden-activation moments + arg-extremum gather, reduced in fp64
         ps2, ps1, psh = ops.trunk_h_moments(x, T, w1, b1c, s1c, t1c, w2p, s2c, t2c)
-        S2 = _reduce(ps2, 1, B, 128 * 128)[0]
-        sh = _reduce(psh, 1, B, 192)[0][:128]
+        S2 = _reduce(ps2, 1, ps2.shape[0], 128 * 128)[0]
+        sh = _reduce(psh, 1, psh.shape[0], 192)[0][:128]
         Gp = ops.trunk_bwd_gather(x, T, w1, b1c, s1c, t1c, w2p, s2c, t2c, idx, coef)
         G = _reduce(Gp, 1, Gp.shape[0], 1024 * 128)[0]
         dW3, Ap, cvec = _e(dev, 1024, 128), _e(dev, 128 * 128), _e(dev, 128)
@@ -269,3 +269,93 @@ def fc_bn_relu_train(lin, bn, inp):
 
 def fc_epilogue_train(lin, inp, epilogue):
     return LinearEpiFn.apply(inp, lin.weight, lin.bias, epilogue)
+
+
+class GraphedTrainStep:
+    """One training step (``main_1v.py:72-76``: zero_grad, forward, ``nll_loss``, backward, Adam step) of a fixed
+    (batch, num_points) shape captured ONCE as a HIP graph and replayed.  A step is ≈190 kernel launches whose
+    host cost (Python autograd Functions + ctypes + the foreach optimizer) exceeds the device time at the
+    reference's own batch sizes (B = 64, N = 750: 2.8 ms eager for ≈0.8 ms of kernels); the replay has no host
+    work beyond two input copies.
+
+        step = GraphedTrainStep(model, batch=64, num_points=750, lr=0.005)
+        loss, logp = step(x, y)          # x (64,3,750) fp32 CUDA, y (64,) int64 CUDA; static output tensors
+        step.optimizer                   # torch.optim.Adam(capturable=True, lr as a device tensor -> StepLR works)
+
+    The three warm-up steps the capture needs run on zero data and are UNDONE (parameters, BatchNorm buffers and
+    Adam state restored in place), so the first replay is the first real step.  Single process only: gradient
+    all-reduce is not captured (use the eager loop + ``ddp.GradAverager`` under torchrun)."""
+
+    def __init__(self, model, batch, num_points, lr=0.005, optimizer=None, warmup=3):
+        import torch.nn.functional as F
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            raise RuntimeError("GraphedTrainStep captures no collective: use the eager loop under torchrun")
+        self.model = model.train()
+        p0 = next(model.parameters())
+        dev = p0.device
+        if dev.type != "cuda":
+            raise RuntimeError("GraphedTrainStep needs the model on a CUDA device")
+        k = model.fc3.out_features
+        self.x = torch.zeros(batch, 3, num_points, device=dev)
+        self.y = (torch.arange(batch, device=dev) % k).long()
+        if optimizer is None:
+            optimizer = torch.optim.Adam(model.parameters(), lr=torch.tensor(float(lr), device=dev), capturable=True,
+                                         fused=True)
+        elif not all(g.get("capturable", False) for g in optimizer.param_groups):
+            raise RuntimeError("the optimizer must be constructed with capturable=True")
+        self.optimizer = optimizer
+        had_state = len(optimizer.state) > 0
+        saved_model = {n: t.detach().clone() for n, t in model.state_dict().items()}
+        saved_opt = [(st, {n: v.detach().clone() for n, v in st.items() if torch.is_tensor(v)})
+                     for st in optimizer.state.values()] if had_state else None
+
+        def one_step():
+            optimizer.zero_grad(set_to_none=True)
+            logp, _ = self.model(self.x)
+            loss = F.nll_loss(logp, self.y)
+            loss.backward()
+            optimizer.step()
+            return loss, logp
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            self.x.normal_(std=0.02)                 # any finite cloud; the effect of these steps is undone below
+            for _ in range(max(1, warmup)):
+                loss, logp = one_step()
+            del loss, logp
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        optimizer.zero_grad(set_to_none=True)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss, self.logp = one_step()
+        # undo warm-up + capture-time side effects, in place (the graph holds these addresses)
+        with torch.no_grad():
+            for n, t in model.state_dict().items():
+                t.copy_(saved_model[n])
+            if had_state:
+                for st, sv in saved_opt:
+                    for n, v in sv.items():
+                        st[n].copy_(v)
+            else:
+                for st in optimizer.state.values():
+                    for v in st.values():
+                        if torch.is_tensor(v):
+                            v.zero_()
+        self.x.zero_()
+        self._state = [t for t in list(model.parameters()) + list(model.buffers())]
+
+    def __call__(self, x, y):
+        if tuple(x.shape) != tuple(self.x.shape) or tuple(y.shape) != tuple(self.y.shape):
+            raise RuntimeError(f"GraphedTrainStep was captured for x {tuple(self.x.shape)}, y {tuple(self.y.shape)}; "
+                               f"got {tuple(x.shape)}, {tuple(y.shape)}")
+        self.x.copy_(x)
+        self.y.copy_(y)
+        self.graph.replay()
+        # a replay rewrites parameters and BatchNorm buffers without any Python-side in-place op: tell the
+        # version-keyed caches (eval-mode fold cache) that they changed
+        for t in self._state:
+            torch.autograd.graph.increment_version(t)
+        return self.loss, self.logp

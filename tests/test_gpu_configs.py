@@ -92,3 +92,27 @@ def test_config5_candidate_scoring(cuda_device):
     order = res["order"].cpu().numpy()
     score = res["score"].cpu().numpy()
     assert (np.diff(score[order]) <= 1e-7).all()
+
+
+def test_cli_on_gpu_eager_and_graph(tmp_path, cuda_device):
+    """main_1v-style CLI with --cuda on the HIP path: train 2 epochs on synthetic clouds, checkpoint, eval from the
+    whole-module pickle — eagerly and with --hip-graph (full batches replayed from a captured HIP graph, the ragged
+    last batch eager).  The two modes use different Adam code paths, and Adam turns the numerically-zero gradients
+    of the pre-BatchNorm biases into +-lr steps, so their trajectories are not comparable step by step
+    (tests/test_gpu_train.py::test_graphed_train_step_equals_eager holds the bitwise comparison); here each mode
+    must be deterministic, finite and consistent with its own checkpoint."""
+    from pointnetgpd_amd import mains
+    out = {}
+    for tag, extra in (("eager", []), ("graph", ["--hip-graph"]), ("graph2", ["--hip-graph"])):
+        common = ["--cuda", "--gpu", "0", "--batch-size", "16", "--num-workers", "0", "--synthetic", "72",
+                  "--model-path", str(tmp_path / tag), "--log-dir", str(tmp_path / "log"), "--seed", "3", "--tag", tag,
+                  "--persistent-optimizer"]
+        out[tag] = mains.run("1v", ["--mode", "train", "--epoch", "2"] + common + extra)   # 72 = 4 x 16 + 8: ragged tail
+        ckpt = tmp_path / tag / f"{tag}_1.model"
+        assert ckpt.exists()
+        r2 = mains.run("1v", ["--mode", "test", "--load-model", str(ckpt)] + common)
+        assert np.isfinite(r2["test_loss"]) and abs(r2["test_loss"] - out[tag]["test_loss"]) < 1e-5
+        m = torch.load(ckpt, map_location="cuda:0", weights_only=False)
+        assert next(m.parameters()).is_cuda and int(m.feat.bn3.num_batches_tracked) == 10
+        assert 0.0 <= out[tag]["train_acc"] <= 1.0 and out[tag]["test_loss"] < 10.0
+    assert out["graph"]["test_loss"] == out["graph2"]["test_loss"]          # replays are deterministic

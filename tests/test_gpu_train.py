@@ -262,3 +262,56 @@ def test_train_step_bf16x3_main_pass(B, N, k, cuda_device):
     cur = m.state_dict()
     for n, v in stats_ref.items():
         np.testing.assert_allclose(cur[n].cpu().numpy(), v.float().numpy(), atol=5e-5, rtol=5e-4, err_msg=n)
+
+
+def test_graphed_train_step_equals_eager(cuda_device):
+    """Three replays of the captured step == three eager steps with the same (capturable) Adam from the same state:
+    parameters, BatchNorm running statistics and losses, and the capture's warm-up leaves no trace."""
+    import torch.nn.functional as F
+    from pointnetgpd_amd import train as pt
+    from tests.helpers import build_model, synth_cloud
+    B, N, k = 16, 300, 3
+    m_g = build_model(N, k, 51, 4801).to(cuda_device)
+    m_e = build_model(N, k, 51, 4801).to(cuda_device).train()
+    init = {n: t.clone() for n, t in m_g.state_dict().items()}
+    xe = synth_cloud(4, N, 7000, "box").to(cuda_device)
+    with torch.no_grad():
+        m_g.eval()(xe)                                         # populate the eval-mode fold cache BEFORE training
+    step = pt.GraphedTrainStep(m_g, batch=B, num_points=N, lr=0.005)
+    for n, t in m_g.state_dict().items():                      # warm-up undone
+        assert torch.equal(t, init[n]), n
+    opt_e = torch.optim.Adam(m_e.parameters(), lr=torch.tensor(0.005, device=cuda_device), capturable=True, fused=True)
+    for i in range(3):
+        x = synth_cloud(B, N, 6000 + i, "box").to(cuda_device)
+        y = torch.randint(0, k, (B,), generator=torch.Generator().manual_seed(i)).to(cuda_device)
+        loss_g, logp_g = step(x, y)
+        loss_g, logp_g = loss_g.clone(), logp_g.clone()
+        opt_e.zero_grad(set_to_none=True)
+        logp_e, _ = m_e(x)
+        loss_e = F.nll_loss(logp_e, y)
+        loss_e.backward()
+        opt_e.step()
+        assert torch.equal(logp_g, logp_e.detach()) and torch.equal(loss_g, loss_e.detach()), i
+    # the CLI's mixture (mains.py --hip-graph): a ragged batch runs eagerly on the SAME optimizer, then replays go on
+    xr = synth_cloud(B - 5, N, 6100, "box").to(cuda_device)
+    yr = torch.randint(0, k, (B - 5,), generator=torch.Generator().manual_seed(9)).to(cuda_device)
+    for mm, oo in ((m_g, step.optimizer), (m_e, opt_e)):
+        oo.zero_grad()
+        F.nll_loss(mm(xr)[0], yr).backward()
+        oo.step()
+    x = synth_cloud(B, N, 6200, "box").to(cuda_device)
+    y = torch.randint(0, k, (B,), generator=torch.Generator().manual_seed(10)).to(cuda_device)
+    loss_g, _ = step(x, y)
+    opt_e.zero_grad(set_to_none=True)
+    loss_e = F.nll_loss(m_e(x)[0], y); loss_e.backward(); opt_e.step()
+    assert torch.equal(loss_g, loss_e.detach())
+    sd_g, sd_e = m_g.state_dict(), m_e.state_dict()
+    for n in sd_g:
+        assert torch.equal(sd_g[n], sd_e[n]), n
+    assert int(sd_g["feat.bn3.num_batches_tracked"]) == 5
+    # the eval-mode fold cache sees the graph's in-place weight updates
+    m_g.eval(); m_e.eval()
+    with torch.no_grad():
+        assert torch.equal(m_g(xe)[0], m_e(xe)[0])
+    with pytest.raises(RuntimeError, match="captured for"):
+        step(torch.zeros(B + 1, 3, N, device=cuda_device), torch.zeros(B + 1, dtype=torch.long, device=cuda_device))

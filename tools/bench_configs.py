@@ -55,7 +55,7 @@ def main():
         for prec in ("fp32", "bf16x3"):
             pt.set_train_precision(prec)
             m.train()
-            opt = torch.optim.Adam(m.parameters(), lr=0.005)
+            opt = torch.optim.Adam(m.parameters(), lr=0.005, fused=True)
 
             def step():
                 opt.zero_grad(set_to_none=True)
@@ -66,6 +66,13 @@ def main():
             row[f"train_{prec}_ms"] = round(ms, 3)
             row[f"train_{prec}_grasps_s"] = round(B / ms * 1e3)
         pt.set_train_precision("fp32")
+        torch.manual_seed(0)
+        mg = pn.PointNetCls(N, 3, k).to(dev)
+        gstep = pt.GraphedTrainStep(mg, B, N, lr=0.005)
+        ms = timeit(lambda: gstep(x, y), 8)
+        row["train_fp32_hipgraph_ms"] = round(ms, 3)
+        row["train_fp32_hipgraph_grasps_s"] = round(B / ms * 1e3)
+        del gstep, mg
         rows.append(row)
         print(json.dumps(row))
     return rows

@@ -1,0 +1,16 @@
+"""10 eager training steps at the reference's own batch shape (B=64, N=750) — for a rocprofv3 kernel trace."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, torch.nn.functional as F
+import bench
+from pointnetgpd_amd.model import pointnet as pn
+dev = torch.device("cuda:0")
+B, N, k = int(os.environ.get("B", 64)), int(os.environ.get("N", 750)), 2
+torch.manual_seed(0)
+m = pn.PointNetCls(N, 3, k).to(dev).train()
+x = bench.synth_clouds(B, N, 1, dev); y = torch.randint(0, k, (B,), device=dev)
+opt = torch.optim.Adam(m.parameters(), lr=0.005, fused=True)
+for i in range(12):
+    opt.zero_grad(set_to_none=True)
+    lp, _ = m(x); F.nll_loss(lp, y).backward(); opt.step()
+torch.cuda.synchronize()
