@@ -61,6 +61,10 @@ class GraspScorer:
         frames = torch.from_numpy(crop.frames_from_grasps_infer(grasps, self.gripper)).to(dev)
         G = frames.shape[0]
         k = self.model.fc3.out_features
+        if G == 0:                                                   # no candidates: nothing to launch
+            e = torch.zeros(0, device=dev)
+            return dict(pred=e.long(), score=e, counts=e.int(), valid=e.bool(), good=e.bool(), order=e.long(),
+                        probs=torch.zeros(self.repeat, 0, k, device=dev))
         counts, idx = crop.crop_count_compact(cloud, frames, self.max_keep)
         probs = torch.zeros(self.repeat, G, k, device=dev)
         valid = None
@@ -187,10 +191,6 @@ def detect_grasps(scene_cloud, surface_normal, scorer, sampler=None, num_grasps=
     else:
         grasps = sampler.sample_grasps(cloud_d, pfs, surface_normal, num_grasps, max_num_samples,
                                        sample_indices=sample_indices, seed=seed, as_array=True)
-    if len(grasps) == 0:
-        e = torch.zeros(0, device=dev)
-        return dict(grasps=grasps, pred=e.long(), score=e, counts=e.int(), valid=e.bool(), good=e.bool(),
-                    order=e.long(), probs=torch.zeros(scorer.repeat, 0, scorer.model.fc3.out_features, device=dev))
     res = scorer.score(cloud_d, grasps)
     res["grasps"] = grasps
     return res
