@@ -115,6 +115,24 @@ def load():
     return lib
 
 
+class _NullCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NULL = _NullCtx()
+
+
+def device_guard(device):
+    """``torch.cuda.device(device)`` only when ``device`` is not already current: the context manager costs two
+    hipSetDevice round trips per kernel launch, which is most of a launch's host time at B = 1."""
+    import torch
+    return _NULL if torch.cuda.current_device() == device.index else torch.cuda.device(device)
+
+
 def check(code, what):
     if code != 0:
         msg = load().pngpd_strerror(code).decode()

@@ -98,7 +98,7 @@ def crop_count_compact(cloud, frames, max_keep=4096):
     P, G = cloud.shape[0], frames.shape[0]
     counts = torch.empty(G, device=cloud.device, dtype=torch.int32)
     idx = torch.empty(G, max_keep, device=cloud.device, dtype=torch.int32)
-    with torch.cuda.device(cloud.device):
+    with _lib.device_guard(cloud.device):
         _lib.check(lib.pngpd_crop_count_compact(_p(cloud), int(cloud.dtype == torch.float64), P, _p(frames), G,
                                                 int(max_keep), _p(counts), _p(idx), _stream(cloud)),
                    "crop_count_compact")
@@ -117,7 +117,7 @@ def crop_resample(cloud, frames, counts, idx, num_points, mode=MODE_INFER, min_p
         if not sel.is_cuda or sel.dtype != torch.int32 or tuple(sel.shape) != (G, num_points):
             raise RuntimeError("sel: expected a CUDA (G,N) int32 tensor")
         sel = sel.contiguous()
-    with torch.cuda.device(cloud.device):
+    with _lib.device_guard(cloud.device):
         _lib.check(lib.pngpd_crop_resample(_p(cloud), int(cloud.dtype == torch.float64), _p(frames), G, _p(counts),
                                            _p(idx), int(max_keep), int(num_points), int(mode), int(min_points),
                                            ctypes.c_ulonglong(int(seed) & (2 ** 64 - 1)), _p(sel), _p(out),

@@ -138,7 +138,7 @@ def normal_moments(cloud, normals, queries, radius, max_nn=MAX_NN):
     K = queries.shape[0]
     M = torch.empty(K, 3, 3, device=cloud.device, dtype=torch.float64)
     nsel = torch.empty(K, device=cloud.device, dtype=torch.int32)
-    with torch.cuda.device(cloud.device):
+    with _lib.device_guard(cloud.device):
         _lib.check(lib.pngpd_gpg_normal_moments(_p(cloud), int(cloud.dtype == torch.float64), _p(normals),
                                                 cloud.shape[0], _p(queries), K, float(radius), int(max_nn), _p(M),
                                                 _p(nsel), _stream(cloud)), "gpg_normal_moments")
@@ -159,7 +159,7 @@ def hand_box_counts(cloud, poses, boxes):
     counts = torch.empty(Q, NB, device=cloud.device, dtype=torch.int32)
     if Q == 0:
         return counts
-    with torch.cuda.device(cloud.device):
+    with _lib.device_guard(cloud.device):
         _lib.check(lib.pngpd_hand_box_counts(_p(cloud), int(cloud.dtype == torch.float64), cloud.shape[0], _p(poses),
                                              Q, _p(boxes), NB, _p(counts), _stream(cloud)), "hand_box_counts")
     return counts

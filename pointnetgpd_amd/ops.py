@@ -55,7 +55,7 @@ def fold_conv_bn(weight, bias, bn_weight=None, bn_bias=None, running_mean=None, 
         args = [_req(a.detach().contiguous(), "bn", (C,)) for a in args]
     wf = torch.empty(C * K, device=w.device, dtype=torch.float32)
     bf = torch.empty(C, device=w.device, dtype=torch.float32)
-    with torch.cuda.device(w.device):
+    with _lib.device_guard(w.device):
         _lib.check(lib.pngpd_fold_conv_bn(_ptr(w), _ptr(b), _ptr(args[0]), _ptr(args[1]), _ptr(args[2]),
                                           _ptr(args[3]), float(eps), C, K, layout, _ptr(wf), _ptr(bf),
                                           _stream(w)), "fold_conv_bn")
@@ -77,7 +77,7 @@ def trunk_fwd_infer(x, trans, w1, b1, w2p, b2, w3p, b3, relu_last):
     out = torch.empty(B, 1024, device=x.device, dtype=torch.float32)
     nbytes = lib.pngpd_trunk_workspace_bytes(B, N)
     ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
-    with torch.cuda.device(x.device):
+    with _lib.device_guard(x.device):
         _lib.check(lib.pngpd_trunk_fwd_infer(_ptr(x), B, N, _ptr(trans), _ptr(w1), _ptr(b1), _ptr(w2p), _ptr(b2),
                                              _ptr(w3p), _ptr(b3), int(bool(relu_last)), _ptr(out), _ptr(ws),
                                              nbytes, _stream(x)), "trunk_fwd_infer")
@@ -90,7 +90,7 @@ def split_pack_bf16(Wf):
     Wf = _req(Wf.contiguous(), "Wf")
     C, K = Wf.shape
     out = torch.empty(2 * C * K, device=Wf.device, dtype=torch.int16)
-    with torch.cuda.device(Wf.device):
+    with _lib.device_guard(Wf.device):
         _lib.check(lib.pngpd_split_pack_bf16(_ptr(Wf), C, K, _ptr(out), _stream(Wf)), "split_pack_bf16")
     return out
 
@@ -110,7 +110,7 @@ def trunk_fwd_infer_x3(x, trans, w1, b1, w2x, b2, w3x, b3, relu_last):
     out = torch.empty(B, 1024, device=x.device, dtype=torch.float32)
     nbytes = lib.pngpd_trunk_workspace_bytes(B, N)
     ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
-    with torch.cuda.device(x.device):
+    with _lib.device_guard(x.device):
         _lib.check(lib.pngpd_trunk_fwd_infer_x3(_ptr(x), B, N, _ptr(trans), _ptr(w1), _ptr(b1), _ptr(w2x), _ptr(b2),
                                                 _ptr(w3x), _ptr(b3), int(bool(relu_last)), _ptr(out), _ptr(ws),
                                                 nbytes, _stream(x)), "trunk_fwd_infer_x3")
@@ -125,7 +125,7 @@ def fc_fwd(inp, W, bias, epilogue):
     Nout = W.shape[0]
     _req(W, "W", (Nout, K)); _req(bias, "bias", (Nout,))
     out = torch.empty(B, Nout, device=inp.device, dtype=torch.float32)
-    with torch.cuda.device(inp.device):
+    with _lib.device_guard(inp.device):
         _lib.check(lib.pngpd_fc_fwd(_ptr(inp), B, K, _ptr(W), _ptr(bias), Nout, int(epilogue), _ptr(out),
                                     _stream(inp)), "fc_fwd")
     return out
@@ -149,7 +149,7 @@ def _call(name, ref, *args):
             conv.append(ctypes.c_void_p(0))
         else:
             conv.append(a)
-    with torch.cuda.device(ref.device):
+    with _lib.device_guard(ref.device):
         _lib.check(getattr(lib, name)(*conv, _stream(ref)), name)
 
 
@@ -180,7 +180,7 @@ def _fold_scale(W, b, scale):
     scale = _req(scale.detach().contiguous(), "scale", (C,))
     wf = torch.empty(C * K, device=W.device, dtype=torch.float32)
     bf = torch.empty(C, device=W.device, dtype=torch.float32)
-    with torch.cuda.device(W.device):
+    with _lib.device_guard(W.device):
         _lib.check(lib.pngpd_fold_conv_bn(_ptr(W), _ptr(b), _ptr(scale), None, None, None, 0.0, C, K,
                                           LAYOUT_MFMA_B, _ptr(wf), _ptr(bf), _stream(W)), "fold(scale)")
     return wf, bf
