@@ -134,23 +134,33 @@ def fc_fwd(inp, W, bias, epilogue):
 # ---------------------------------------------------------------------------------------------
 # training passes (include/pngpd.h "Training path")
 # ---------------------------------------------------------------------------------------------
+_FN = {}
+
+
 def _call(name, ref, *args):
     """Generic C-ABI call: tensors -> device pointers, None -> NULL, scalars as is; the stream of
     ``ref``'s device is appended.  Every tensor must be CUDA + contiguous (dtype is the callee's
-    contract and is checked by the typed wrappers below)."""
-    lib = _lib.load()
+    contract and is checked by the typed wrappers below).  Kept lean: a training step makes ~150 of these."""
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(_lib.load(), name)
     conv = []
     for a in args:
         if isinstance(a, torch.Tensor):
             if not a.is_cuda or not a.is_contiguous():
                 raise RuntimeError(f"{name}: expected contiguous CUDA tensors")
-            conv.append(ctypes.c_void_p(a.data_ptr()))
-        elif a is None:
-            conv.append(ctypes.c_void_p(0))
+            conv.append(a.data_ptr())           # argtypes are c_void_p: plain ints / None convert directly
         else:
             conv.append(a)
-    with _lib.device_guard(ref.device):
-        _lib.check(getattr(lib, name)(*conv, _stream(ref)), name)
+    dev = ref.device
+    conv.append(torch.cuda.current_stream(dev).cuda_stream)
+    if torch.cuda.current_device() == dev.index:
+        code = fn(*conv)
+    else:
+        with torch.cuda.device(dev):
+            code = fn(*conv)
+    if code != 0:
+        _lib.check(code, name)
 
 
 def _f32(t, name, shape=None):

@@ -11,4 +11,3 @@ GP=$(find /tmp/prof_gpg -name "*.db" | head -1)
 [ -n "$GP" ] && python tools/rocprof_summary.py gpurun_out/r01_final2_gpg_trace.md "tools/bench_gpg.py kernel trace, P 20000, 150 sample points=$GP" > /dev/null
 tail -n 3 /tmp/gpg.log
 ls -la gpurun_out/
-timeout 300 python tools/bench_configs.py > gpurun_out/r01_bench_configs.jsonl 2> /tmp/cfg.err; echo "cfg rc=$?"; tail -n 3 /tmp/cfg.err; cat gpurun_out/r01_bench_configs.jsonl
