@@ -25,7 +25,6 @@ class GradAverager:
         self.world = dist.get_world_size(process_group)
         self.broadcast_buffers = broadcast_buffers
         self.params = [p for p in model.parameters() if p.requires_grad]
-        self._flat = None
         self.sync_parameters()
 
     def sync_parameters(self):
@@ -35,14 +34,21 @@ class GradAverager:
                 dist.broadcast(t.data, src=0, group=self.group)
 
     def sync_buffers(self):
-        if not self.broadcast_buffers:
+        """Rank 0's BatchNorm buffers become everyone's: ONE broadcast of the 7,936 running statistics (flattened)
+        and one of the 10 ``num_batches_tracked`` counters — not 30 small collectives per forward."""
+        if not self.broadcast_buffers or self.world == 1:
             return
         with torch.no_grad():
-            for b in self.model.buffers():
-                dist.broadcast(b.data, src=0, group=self.group)
+            bufs = list(self.model.buffers())
+            for dt in sorted({b.dtype for b in bufs}, key=str):      # same order on every rank
+                group = [b for b in bufs if b.dtype == dt]
+                flat = torch.cat([b.reshape(-1) for b in group])
+                dist.broadcast(flat, src=0, group=self.group)
+                torch._foreach_copy_(group, [c.view_as(b) for c, b in zip(flat.split([b.numel() for b in group]), group)])
 
     def average_gradients(self):
-        """All-reduce(sum)/world of every parameter gradient through one flat bucket."""
+        """All-reduce(sum)/world of every parameter gradient through one flat bucket: one gather kernel, one
+        collective, one scale, one multi-tensor scatter."""
         if self.world == 1:
             return
         grads = []
@@ -50,21 +56,10 @@ class GradAverager:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
             grads.append(p.grad)
-        total = sum(g.numel() for g in grads)
-        if self._flat is None or self._flat.numel() != total or self._flat.device != grads[0].device:
-            self._flat = torch.empty(total, device=grads[0].device, dtype=grads[0].dtype)
-        off = 0
-        for g in grads:
-            n = g.numel()
-            self._flat[off:off + n].copy_(g.reshape(-1))
-            off += n
-        dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.group)
-        self._flat.div_(self.world)
-        off = 0
-        for g in grads:
-            n = g.numel()
-            g.copy_(self._flat[off:off + n].view_as(g))
-            off += n
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        flat.div_(self.world)
+        torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
 
 
 def init_from_env(backend=None):
