@@ -104,8 +104,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # Debug hook (not used by the driver): PNGPD_BENCH_DEBUG_ONE_GPU=1 runs every rank on cuda:0 over gloo so
+        # that the N>1 control flow can be exercised on a 1-GPU box.  Numbers from such a run are meaningless.
+        one_gpu = os.environ.get("PNGPD_BENCH_DEBUG_ONE_GPU") == "1"
+        if one_gpu:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
