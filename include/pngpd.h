@@ -245,7 +245,8 @@ int pngpd_crop_count_compact(const void *cloud, int cloud_is_f64, int P, const d
  * dataset.py:440-444); valid (G) = count >= min_points (dataset.py:71, kinect2grasp.py:462).
  * mode 0: without replacement iff m > N (dataset.py:439); mode 1: iff m >= N (kinect2grasp.py:474),
  * m = min(count, max_keep).  sel (G,N) int32 ranks in [0,m) injects the draw (else device RNG
- * keyed by seed).  Invalid grasps are zero-filled.                                              */
+ * keyed by seed; a without-replacement draw is a uniform random N-subset written in ascending
+ * point-index order — the scorer is invariant to the column order).  Invalid grasps are zero-filled. */
 int pngpd_crop_resample(const void *cloud, int cloud_is_f64, const double *frames, int G, const int *counts,
                         const int *idx, int max_keep, int N, int mode, int min_points,
                         unsigned long long seed, const int *sel, float *out, unsigned char *valid, void *stream);

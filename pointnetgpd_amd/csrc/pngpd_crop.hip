@@ -90,17 +90,36 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
     return z ^ (z >> 31);
 }
 
+// Block-wide sum over 256 threads (every thread gets the total).
+__device__ __forceinline__ int crop_block_sum(int v, int *sh) {
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) v += __shfl_xor(v, k);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
 // One workgroup per grasp: pick N of the m = min(count, max_keep) kept points and write them in the
 // hand frame as (3,N) fp32.  Rule of the reference: WITHOUT replacement iff m > N (mode 0, dataset.py:439)
 // or m >= N (mode 1, kinect2grasp.py:474); otherwise WITH replacement.  sel != NULL injects the draw:
 // sel[g][n] in [0, m) is the rank of the kept point to take (tests / bit-reproducible pipelines).
+//
+// Without replacement = a uniform random N-subset: every kept point gets an iid 32-bit key (counter hash of
+// (seed, grasp, rank)); the N smallest keys win, exact ties at the cut resolved towards the lower rank.  The N-th
+// smallest key is found by bisection over the key space with block-wide counts (32 rounds over keys parked in
+// LDS), and the winners leave in ascending rank by ballot-ordered compaction — fully parallel, where a
+// Fisher-Yates draw is a serial chain of N dependent swaps.  The column ORDER of the output is therefore the
+// index order, not a random permutation; the scorer is invariant to it (per-point MLP + max-pool).
 template <bool F64>
 __global__ __launch_bounds__(256) void crop_resample_kernel(
     const void *__restrict__ cloud, const double *__restrict__ frames, const int *__restrict__ counts,
     const int *__restrict__ idx, int max_keep, int N, int mode, int min_points, unsigned long long seed,
     const int *__restrict__ sel, float *__restrict__ out, unsigned char *__restrict__ valid) {
-    extern __shared__ int perm[];   // [max_keep] only used for the without-replacement draw
-    const int g = blockIdx.x, tid = threadIdx.x;
+    extern __shared__ unsigned keys[];   // [max_keep] only used for the without-replacement draw
+    __shared__ int shi[4];
+    __shared__ int wsel[4], wtie[4];
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cnt = counts[g];
     const int m = cnt < max_keep ? cnt : max_keep;
     float *o = out + (size_t)g * 3 * N;
@@ -115,24 +134,57 @@ __global__ __launch_bounds__(256) void crop_resample_kernel(
     const int *gi = idx + (size_t)g * max_keep;
     const bool without = (mode == 0) ? (m > N) : (m >= N);
     if (!sel && without) {
-        for (int i = tid; i < m; i += 256) perm[i] = i;
+        for (int i = tid; i < m; i += 256)
+            keys[i] = (unsigned)(mix64(seed ^ mix64(((unsigned long long)g << 32) | (unsigned)i)) >> 32);
         __syncthreads();
-        if (tid == 0) {   // partial Fisher-Yates: the first N entries become a uniform N-subset
-            for (int i = 0; i < N; ++i) {
-                const unsigned long long r = mix64(seed ^ mix64(((unsigned long long)g << 32) | (unsigned)i));
-                const int j = i + (int)(r % (unsigned long long)(m - i));
-                const int t = perm[i]; perm[i] = perm[j]; perm[j] = t;
-            }
+        auto count_le = [&](unsigned T) {
+            int c = 0;
+            for (int i = tid; i < m; i += 256) c += keys[i] <= T ? 1 : 0;
+            return crop_block_sum(c, shi);
+        };
+        unsigned lo = 0u, hi = 0xFFFFFFFFu;            // smallest T with #(key <= T) >= N   (m >= N here)
+        while (lo < hi) {
+            const unsigned mid = lo + ((hi - lo) >> 1);
+            if (count_le(mid) >= N) hi = mid; else lo = mid + 1u;
         }
-        __syncthreads();
+        const unsigned T = lo;
+        const int need = N - (T ? count_le(T - 1u) : 0);   // how many of the key == T ties are taken (lowest ranks)
+        int run_sel = 0, run_tie = 0;
+        for (int base = 0; base < m; base += 256) {
+            const int i = base + tid;
+            const unsigned k = i < m ? keys[i] : 0xFFFFFFFFu;
+            const bool tie = i < m && k == T;
+            const unsigned long long tmask = __ballot(tie);
+            if (lane == 0) wtie[wave] = __popcll(tmask);
+            __syncthreads();
+            int toff = 0, ttot = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { const int c = wtie[w]; if (w < wave) toff += c; ttot += c; }
+            const int tie_rank = run_tie + toff + __popcll(tmask & ((1ull << lane) - 1ull));
+            const bool take = i < m && (k < T || (tie && tie_rank < need));
+            const unsigned long long smask = __ballot(take);
+            if (lane == 0) wsel[wave] = __popcll(smask);
+            __syncthreads();
+            int soff = 0, stot = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { const int c = wsel[w]; if (w < wave) soff += c; stot += c; }
+            if (take) {
+                const int n = run_sel + soff + __popcll(smask & ((1ull << lane) - 1ull));
+                double x, y, z, a, b, c;
+                load_point<F64>(cloud, gi[i], x, y, z);
+                to_frame(F, x, y, z, a, b, c);
+                o[n] = (float)a; o[N + n] = (float)b; o[2 * N + n] = (float)c;
+            }
+            run_sel += stot; run_tie += ttot;
+            __syncthreads();
+        }
+        return;
     }
     for (int n = tid; n < N; n += 256) {
         int r;
         if (sel) {
             r = sel[(size_t)g * N + n];
             r = r < 0 ? 0 : (r >= m ? m - 1 : r);
-        } else if (without) {
-            r = perm[n];
         } else {
             r = (int)(mix64(seed ^ mix64(((unsigned long long)g << 32) | (unsigned)n)) % (unsigned long long)m);
         }

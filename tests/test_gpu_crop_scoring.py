@@ -213,3 +213,30 @@ def test_infer_crop_kernel_vs_executed_reference(cuda_device):
                                         crop.MODE_INFER, 3, sel=sel)
         for g in np.nonzero(counts_ref >= 3)[0]:
             np.testing.assert_allclose(out[g].cpu().numpy().T, head[g].astype(np.float32), rtol=0, atol=1e-8)
+
+
+def test_resample_without_replacement_is_a_uniform_subset(cuda_device):
+    """4,000 identical grasps (the draw is keyed by the grasp index): every draw is N DISTINCT in-box points in
+    ascending index order, and each in-box point is chosen with frequency N/m (5 sigma)."""
+    from pointnetgpd_amd import crop
+    pc, grasps = _scene(1, 3000, 51)
+    pc32 = pc.astype(np.float32)
+    G, N = 4000, 16
+    frames1 = crop.frames_from_grasps_infer(grasps)
+    frames = torch.from_numpy(np.repeat(frames1, G, 0)).to(cuda_device)
+    cloud = torch.from_numpy(pc32).to(cuda_device)
+    counts, idx = crop.crop_count_compact(cloud, frames, max_keep=512)
+    m = int(counts[0])
+    assert N < m <= 512 and bool((counts == m).all())
+    out, valid = crop.crop_resample(cloud, frames, counts, idx, N, crop.MODE_INFER, 1, seed=123)
+    assert bool(valid.all())
+    ind_ref, pts_ref = co.collect_pc_infer(grasps, pc32)
+    ref32 = torch.from_numpy(pts_ref[0].astype(np.float32)).to(cuda_device)          # (m,3)
+    # map every output column back to its in-box rank (exact fp32 match up to 1e-8, see test_infer_crop_vs_oracle)
+    d = (out.permute(0, 2, 1).unsqueeze(2) - ref32.view(1, 1, m, 3)).abs().amax(3)  # (G,N,m)
+    rank = d.argmin(2)
+    assert float(d.amin(2).max()) <= 1e-8
+    assert bool((rank[:, 1:] > rank[:, :-1]).all())                                  # distinct + ascending
+    freq = torch.bincount(rank.reshape(-1), minlength=m).double() / G
+    p = N / m
+    assert float((freq - p).abs().max()) < 5 * np.sqrt(p * (1 - p) / G)
