@@ -270,6 +270,13 @@ int pngpd_gpg_normal_moments(const void *cloud, int cloud_is_f64, const double *
  * check_collision_square's has_p is counts > 0, its points_in_area length is counts.             */
 int pngpd_hand_box_counts(const void *cloud, int cloud_is_f64, int P, const double *poses, int Q,
                           const double *boxes, int num_boxes, int *counts, void *stream);
+/* Same result (identical counts) through a spatial index, for large clouds / many poses: cloud_sorted is the
+ * cloud re-ordered so that consecutive points are close (Morton order), spheres (C,4) f64 = bounding sphere
+ * (centre xyz, radius) of every 64-point chunk, C = ceil(P/64).  One wave per pose rejects chunks by their sphere
+ * before testing points.                                                                          */
+int pngpd_hand_box_counts_indexed(const void *cloud_sorted, int cloud_is_f64, int P, const double *spheres, int C,
+                                  const double *poses, int Q, const double *boxes, int num_boxes, int *counts,
+                                  void *stream);
 
 #ifdef __cplusplus
 }

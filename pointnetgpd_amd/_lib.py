@@ -80,6 +80,8 @@ SIGNATURES = {
                                                 ctypes.c_double, ctypes.c_int, c_void, c_void, c_void]),
     "pngpd_hand_box_counts": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, ctypes.c_int, c_void,
                                              ctypes.c_int, c_void, c_void]),
+    "pngpd_hand_box_counts_indexed": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, ctypes.c_int, c_void,
+                                                     ctypes.c_int, c_void, ctypes.c_int, c_void, c_void]),
 }
 
 

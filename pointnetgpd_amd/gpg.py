@@ -145,10 +145,63 @@ def normal_moments(cloud, normals, queries, radius, max_nn=MAX_NN):
     return M, nsel
 
 
-def hand_box_counts(cloud, poses, boxes):
+def _spread3(v):
+    """10-bit integers -> bits spread to every third position (Morton interleave helper), int64 tensors."""
+    v = v & 0x3FF
+    v = (v | (v << 16)) & 0x30000FF
+    v = (v | (v << 8)) & 0x300F00F
+    v = (v | (v << 4)) & 0x30C30C3
+    v = (v | (v << 2)) & 0x9249249
+    return v
+
+
+class CloudIndex:
+    """Spatial index of a scene cloud for ``hand_box_counts``: the points re-ordered along a 30-bit Morton curve
+    (consecutive points are neighbours) and the bounding sphere of every 64-point chunk.  Built once per scene from a
+    handful of torch ops on the device; point VALUES are untouched, so counts are identical to the un-indexed path."""
+
+    def __init__(self, cloud):
+        cloud = _check_cloud(cloud)
+        P = cloud.shape[0]
+        pts = cloud.double()
+        lo = pts.min(0).values
+        ext = (pts.max(0).values - lo).clamp_min(1e-30)
+        q = ((pts - lo) / ext * 1023.0).long().clamp_(0, 1023)
+        code = _spread3(q[:, 0]) | (_spread3(q[:, 1]) << 1) | (_spread3(q[:, 2]) << 2)
+        order = torch.argsort(code)
+        self.cloud = cloud[order].contiguous()
+        C = (P + 63) // 64
+        sp = pts[order]
+        if C * 64 != P:                                   # pad the last chunk with its own last point
+            sp = torch.cat([sp, sp[-1:].expand(C * 64 - P, 3)], 0)
+        sp = sp.view(C, 64, 3)
+        centre = (sp.min(1).values + sp.max(1).values) * 0.5
+        radius = (sp - centre[:, None, :]).norm(dim=2).max(1).values
+        self.spheres = torch.cat([centre, radius[:, None]], 1).contiguous()      # (C,4) f64
+        self.P, self.C = P, C
+
+
+def hand_box_counts(cloud, poses, boxes, index=None):
     """cloud (P,3) CUDA; poses (Q,12) CUDA f64 [centre, approach, binormal, minor] (unit axes); boxes (NB,6) CUDA f64,
-    NB in {1,4} -> counts (Q,NB) int32: cloud points strictly inside each box of each pose."""
+    NB in {1,4} -> counts (Q,NB) int32: cloud points strictly inside each box of each pose.
+    ``index`` (a ``CloudIndex`` of the same cloud) selects the sphere-culling kernel: same counts, less work."""
     lib = _lib.load()
+    if index is not None:
+        if not poses.is_cuda or poses.dtype != torch.float64 or poses.dim() != 2 or poses.shape[1] != 12:
+            raise RuntimeError("poses: expected a CUDA (Q,12) float64 tensor")
+        if not boxes.is_cuda or boxes.dtype != torch.float64 or boxes.dim() != 2 or boxes.shape[1] != 6:
+            raise RuntimeError("boxes: expected a CUDA (NB,6) float64 tensor")
+        poses, boxes = poses.contiguous(), boxes.contiguous()
+        Q, NB = poses.shape[0], boxes.shape[0]
+        counts = torch.empty(Q, NB, device=poses.device, dtype=torch.int32)
+        if Q == 0:
+            return counts
+        c = index.cloud
+        with _lib.device_guard(c.device):
+            _lib.check(lib.pngpd_hand_box_counts_indexed(_p(c), int(c.dtype == torch.float64), index.P,
+                                                         _p(index.spheres), index.C, _p(poses), Q, _p(boxes), NB,
+                                                         _p(counts), _stream(c)), "hand_box_counts_indexed")
+        return counts
     cloud = _check_cloud(cloud)
     if not poses.is_cuda or poses.dtype != torch.float64 or poses.dim() != 2 or poses.shape[1] != 12:
         raise RuntimeError("poses: expected a CUDA (Q,12) float64 tensor")
@@ -177,14 +230,15 @@ class GpgGraspSamplerPcl:
     init_bite (default: robotiq_85).  ``config`` is accepted for signature compatibility and unused, as in the
     Pcl sampler."""
 
-    def __init__(self, gripper=None, config=None, device=None):
+    def __init__(self, gripper=None, config=None, device=None, use_index=True):
+        self.use_index = bool(use_index)     # sphere-culled collision kernel (identical counts); False: brute force
         self.gripper = gripper if gripper is not None else ROBOTIQ_85
         self.config = config
         self.device = torch.device(device) if device is not None else None
         self.last_stats = {}
 
     # -- device work for one batch of draws --------------------------------------------------
-    def _run_batch(self, g, cloud_d, normals_d, boxes_d, sel_pts, normals_at_ind):
+    def _run_batch(self, g, cloud_d, normals_d, boxes_d, sel_pts, normals_at_ind, index=None):
         """sel_pts (K,3) sample points, normals_at_ind (K,3) -> (m_zero (K,) bool, per-draw list of (n,5,3) arrays)."""
         dev = cloud_d.device
         K = sel_pts.shape[0]
@@ -223,7 +277,7 @@ class GpgGraspSamplerPcl:
         poses[..., 3:6] = _unit(approach)[:, :, None, :]
         poses[..., 6:9] = _unit(binormal)[:, :, None, :]
         poses[..., 9:12] = _unit(minor)[:, None, None, :]
-        cnt = hand_box_counts(cloud_d, torch.from_numpy(poses.reshape(-1, 12)).to(dev), boxes_d)
+        cnt = hand_box_counts(cloud_d, torch.from_numpy(poses.reshape(-1, 12)).to(dev), boxes_d, index=index)
         cnt = cnt.cpu().numpy().reshape(L, R, D, 4)
         ok = (cnt[..., BOX_OPEN] > 0) & (cnt[..., BOX_BOTTOM] == 0) & (cnt[..., BOX_LEFT] == 0) & (cnt[..., BOX_RIGHT] == 0)
         # the middle admissible offset per rotation (:1565-1567) ...
@@ -261,7 +315,7 @@ class GpgGraspSamplerPcl:
         poses2[0, :, :, 0:3] = c_s
         poses2[1, :, :, 0:3] = np.where(np.isfinite(mod), mod, 1e30)                            # non-finite -> empty boxes
         poses2[:, :, :, 3:12] = ax[None, :, None, :]
-        cnt2 = hand_box_counts(cloud_d, torch.from_numpy(poses2.reshape(-1, 12)).to(dev), boxes_d)
+        cnt2 = hand_box_counts(cloud_d, torch.from_numpy(poses2.reshape(-1, 12)).to(dev), boxes_d, index=index)
         cnt2 = cnt2.cpu().numpy().reshape(2, Np, S, 4)
         hit = (cnt2[..., BOX_BOTTOM] > 0) | (cnt2[..., BOX_LEFT] > 0) | (cnt2[..., BOX_RIGHT] > 0)   # check_collide
         accept = hit[0] & (cnt2[1, ..., BOX_OPEN] > MIN_OPEN_POINTS) & ~hit[1]                  # :1614
@@ -294,6 +348,7 @@ class GpgGraspSamplerPcl:
                          dtype=np.float64).reshape(-1, 3)
         normals_d = torch.from_numpy(np.ascontiguousarray(all_normal)).to(dev)
         boxes_d = torch.from_numpy(hand_boxes(g)).to(dev)
+        index = CloudIndex(cloud_d) if self.use_index else None      # once per scene, shared by both launches
         out = []
         if num_grasps <= 0 or max_num_samples <= 0 or pfs.shape[0] == 0:                       # :1432 loop never entered
             return np.zeros((0, 5, 3)) if as_array else out
@@ -311,7 +366,7 @@ class GpgGraspSamplerPcl:
                     break                                            # degenerate cloud: the reference would spin here
                 draws = rng.integers(0, pfs.shape[0], size=want)
             pos += draws.size
-            m_zero, res = self._run_batch(g, cloud_d, normals_d, boxes_d, pfs[draws], all_normal[draws])
+            m_zero, res = self._run_batch(g, cloud_d, normals_d, boxes_d, pfs[draws], all_normal[draws], index)
             for k in range(draws.size):
                 self.last_stats["draws"] += 1
                 if m_zero[k]:

@@ -111,7 +111,7 @@ def test_sampler_host_half_against_goldens(monkeypatch):
         M = np.stack([go.normal_moment(pts, nrm, q[k], radius) for k in range(len(q))])
         return torch.from_numpy(M), torch.zeros(len(q), dtype=torch.int32)
 
-    def fake_counts(cloud, poses, boxes):
+    def fake_counts(cloud, poses, boxes, index=None):
         pts, P = cloud.numpy().astype(np.float64), poses.numpy()
         out = np.zeros((len(P), 4), dtype=np.int32)
         for qi, p in enumerate(P):

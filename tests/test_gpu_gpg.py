@@ -159,3 +159,38 @@ def test_detect_grasps_chain(cuda_device):
     low = pts32.copy(); low[:, 2] = 0.0
     res0 = detect_grasps(low, nrm, scorer)
     assert res0["grasps"].shape == (0, 5, 3) and res0["order"].numel() == 0
+
+
+@pytest.mark.parametrize("dtype,P,Q,kind", [(np.float32, 5000, 900, "box"), (np.float64, 1025, 37, "cylinder"),
+                                            (np.float32, 64, 5, "box"), (np.float64, 20000, 2000, "ellipsoid")])
+def test_indexed_counts_identical_to_brute_force(dtype, P, Q, kind, cuda_device):
+    """The sphere-culled kernel returns exactly the counts of the brute-force kernel (same per-point arithmetic; the
+    broad phase may only discard chunks that cannot hold an in-box point), for 1 and 4 boxes."""
+    from pointnetgpd_amd import gpg
+    pts, _ = go.synth_scene(kind, P, 8)
+    pts = pts.astype(dtype)
+    rng = np.random.default_rng(P * 7 + Q)
+    poses = _poses(rng, pts.astype(np.float64), Q)
+    poses[::5, 0:3] += rng.normal(scale=0.2, size=(len(poses[::5]), 3))          # some poses far from the object
+    boxes = gpg.hand_boxes(gpg._gripper_dict(gpg.ROBOTIQ_85))
+    cloud = torch.from_numpy(pts).to(cuda_device)
+    index = gpg.CloudIndex(cloud)
+    assert index.C == (P + 63) // 64 and index.spheres.shape == (index.C, 4)
+    # the index holds the same multiset of points
+    assert torch.equal(torch.sort(index.cloud.double().sum(1)).values, torch.sort(cloud.double().sum(1)).values)
+    pd, bd = torch.from_numpy(poses).to(cuda_device), torch.from_numpy(boxes).to(cuda_device)
+    for nb in (4, 1):
+        ref = gpg.hand_box_counts(cloud, pd, bd[:nb])
+        got = gpg.hand_box_counts(cloud, pd, bd[:nb], index=index)
+        assert torch.equal(ref, got)
+    assert int(ref.sum()) > 0
+
+
+def test_sampler_same_result_with_and_without_index(cuda_device):
+    from pointnetgpd_amd import gpg
+    pts, nrm = go.synth_scene("box", 6000, 14)
+    pfs = pts[pts[:, 2] > 0.010]
+    draws = np.random.default_rng(4).integers(0, len(pfs), 40)
+    a = gpg.GpgGraspSamplerPcl(device=cuda_device, use_index=True).sample_grasps(pts, pfs, nrm, 1000, 40, sample_indices=draws, as_array=True)
+    b = gpg.GpgGraspSamplerPcl(device=cuda_device, use_index=False).sample_grasps(pts, pfs, nrm, 1000, 40, sample_indices=draws, as_array=True)
+    assert len(a) > 0 and np.array_equal(a, b)

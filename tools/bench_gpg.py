@@ -52,6 +52,18 @@ def main():
             gpg.hand_box_counts(cloud_d, poses, boxes)
         ev1.record(); torch.cuda.synchronize()
         sweep_ms = ev0.elapsed_time(ev1) / 5
+        index = gpg.CloudIndex(cloud_d)
+        ev0.record()
+        for _ in range(5):
+            gpg.CloudIndex(cloud_d)
+        ev1.record(); torch.cuda.synchronize()
+        index_ms = ev0.elapsed_time(ev1) / 5
+        gpg.hand_box_counts(cloud_d, poses, boxes, index=index)
+        ev0.record()
+        for _ in range(5):
+            gpg.hand_box_counts(cloud_d, poses, boxes, index=index)
+        ev1.record(); torch.cuda.synchronize()
+        sweep_idx_ms = ev0.elapsed_time(ev1) / 5
         q_d = torch.from_numpy(pfs[draws].astype(np.float64)).to(dev)
         n_d = torch.from_numpy(nrm).to(dev)
         gpg.normal_moments(cloud_d, n_d, q_d, 0.1925)
@@ -66,7 +78,8 @@ def main():
         out.append(dict(P=P, samples=a.samples, grasps=int(len(res)), gpu_s_per_scene=gpu_s,
                         gpu_ms_per_draw=gpu_s / a.samples * 1e3, cpu_oracle_s_per_draw=cpu_per_draw,
                         speedup_per_draw=cpu_per_draw / (gpu_s / a.samples),
-                        sweep_kernel_ms=sweep_ms, sweep_pairs_per_s=Q * P / (sweep_ms * 1e-3),
+                        sweep_kernel_brute_ms=sweep_ms, sweep_kernel_indexed_ms=sweep_idx_ms, index_build_ms=index_ms,
+                        sweep_pairs_per_s_brute=Q * P / (sweep_ms * 1e-3),
                         moments_kernel_ms=mom_ms, potential=s.last_stats["potential"]))
         print(json.dumps(out[-1]))
     return out
