@@ -230,8 +230,9 @@ class GpgGraspSamplerPcl:
     init_bite (default: robotiq_85).  ``config`` is accepted for signature compatibility and unused, as in the
     Pcl sampler."""
 
-    def __init__(self, gripper=None, config=None, device=None, use_index=True):
+    def __init__(self, gripper=None, config=None, device=None, use_index=True, batch_samples=2048):
         self.use_index = bool(use_index)     # sphere-culled collision kernel (identical counts); False: brute force
+        self.batch_samples = int(batch_samples)   # sample points per device round (399 poses each; bounds host memory)
         self.gripper = gripper if gripper is not None else ROBOTIQ_85
         self.config = config
         self.device = torch.device(device) if device is not None else None
@@ -356,7 +357,7 @@ class GpgGraspSamplerPcl:
         explicit = None if sample_indices is None else np.asarray(sample_indices, dtype=np.int64).reshape(-1)
         pos, sampled, done = 0, 0, False
         while not done:
-            want = max_num_samples - sampled
+            want = min(self.batch_samples, max_num_samples - sampled)
             if explicit is not None:
                 draws = explicit[pos:pos + want]
                 if draws.size == 0:
