@@ -26,7 +26,7 @@ def set_train_precision(mode):
     if mode not in ("fp32", "bf16x3"):
         raise ValueError("precision must be 'fp32' or 'bf16x3'")
     _TRAIN_PRECISION = mode
-DEBUG_STASH = None   # set to a dict to capture backward intermediates (tests / tools/diag_train2.py)
+DEBUG_STASH = None   # set to a dict to capture backward intermediates (tests/test_gpu_train.py::test_trunk_backward_intermediates)
 
 
 def _e(dev, *shape, dtype=torch.float32):
