@@ -317,36 +317,56 @@ __global__ __launch_bounds__(512, 2) void trunk_fwd_train_x3_kernel(
             load_wx<8>(wah, wal, w3x, cb, lane);
             float m = -INFINITY, su = 0.f, qu = 0.f;
             int am = 0;
+            // all four point blocks at once: 4 independent accumulator chains, A fragments of k-step ks+1 in flight
+            // while k-step ks issues (same schedule as trunk_infer_x3_kernel)
+            f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+            {
+                const int ro = j * X2S + h * 8;
+                f32x4 ah[4], al[4];
 #pragma unroll
-            for (int qp = 0; qp < 2; ++qp) {
-                f32x16 c0 = {0}, c1 = {0};
-                const int ro0 = ((2 * qp) * 32 + j) * X2S + h * 8, ro1 = ((2 * qp + 1) * 32 + j) * X2S + h * 8;
+                for (int q = 0; q < 4; ++q) { ah[q] = *(const f32x4 *)(h2h + ro + q * 32 * X2S); al[q] = *(const f32x4 *)(h2l + ro + q * 32 * X2S); }
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
-                    const f32x4 ah0 = *(const f32x4 *)(h2h + ro0 + ks * 16), al0 = *(const f32x4 *)(h2l + ro0 + ks * 16);
-                    const f32x4 ah1 = *(const f32x4 *)(h2h + ro1 + ks * 16), al1 = *(const f32x4 *)(h2l + ro1 + ks * 16);
-                    c0 = mfma_bf(ah0, wah[ks], c0); c1 = mfma_bf(ah1, wah[ks], c1);
-                    c0 = mfma_bf(ah0, wal[ks], c0); c1 = mfma_bf(ah1, wal[ks], c1);
-                    c0 = mfma_bf(al0, wah[ks], c0); c1 = mfma_bf(al1, wah[ks], c1);
+                    f32x4 nh[4], nl[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        nh[q] = ah[q]; nl[q] = al[q];
+                        if (ks < 7) {
+                            nh[q] = *(const f32x4 *)(h2h + ro + q * 32 * X2S + (ks + 1) * 16);
+                            nl[q] = *(const f32x4 *)(h2l + ro + q * 32 * X2S + (ks + 1) * 16);
+                        }
+                    }
+                    c0 = mfma_bf(ah[0], wah[ks], c0); c1 = mfma_bf(ah[1], wah[ks], c1);
+                    c2 = mfma_bf(ah[2], wah[ks], c2); c3 = mfma_bf(ah[3], wah[ks], c3);
+                    c0 = mfma_bf(ah[0], wal[ks], c0); c1 = mfma_bf(ah[1], wal[ks], c1);
+                    c2 = mfma_bf(ah[2], wal[ks], c2); c3 = mfma_bf(ah[3], wal[ks], c3);
+                    c0 = mfma_bf(al[0], wah[ks], c0); c1 = mfma_bf(al[1], wah[ks], c1);
+                    c2 = mfma_bf(al[2], wah[ks], c2); c3 = mfma_bf(al[3], wah[ks], c3);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { ah[q] = nh[q]; al[q] = nl[q]; }
                 }
+            }
+            auto epi = [&](const f32x16 &ca, const f32x16 &cc, int qp) {
                 // ascending local-row order with strict >: the first maximum wins
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { if (c0[r] > m) { m = c0[r]; am = (2 * qp) * 32 + mfma_row(r, lane); } }
+                for (int r = 0; r < 16; ++r) { if (ca[r] > m) { m = ca[r]; am = (2 * qp) * 32 + mfma_row(r, lane); } }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { if (c1[r] > m) { m = c1[r]; am = (2 * qp + 1) * 32 + mfma_row(r, lane); } }
+                for (int r = 0; r < 16; ++r) { if (cc[r] > m) { m = cc[r]; am = (2 * qp + 1) * 32 + mfma_row(r, lane); } }
                 if (full) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) { su += c0[r] + c1[r]; qu = fmaf(c0[r], c0[r], fmaf(c1[r], c1[r], qu)); }
+                    for (int r = 0; r < 16; ++r) { su += ca[r] + cc[r]; qu = fmaf(ca[r], ca[r], fmaf(cc[r], cc[r], qu)); }
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = mfma_row(r, lane);
-                        const float v0 = (nbase + (2 * qp) * 32 + row < N) ? c0[r] : 0.f;
-                        const float v1 = (nbase + (2 * qp + 1) * 32 + row < N) ? c1[r] : 0.f;
+                        const float v0 = (nbase + (2 * qp) * 32 + row < N) ? ca[r] : 0.f;
+                        const float v1 = (nbase + (2 * qp + 1) * 32 + row < N) ? cc[r] : 0.f;
                         su += v0 + v1; qu = fmaf(v0, v0, fmaf(v1, v1, qu));
                     }
                 }
-            }
+            };
+            epi(c0, c1, 0);
+            epi(c2, c3, 1);
             const float om = __shfl_xor(m, 32); const int oa = __shfl_xor(am, 32);
             if (om > m || (om == m && oa < am)) { m = om; am = oa; }
             su += __shfl_xor(su, 32); qu += __shfl_xor(qu, 32);
