@@ -24,3 +24,23 @@ def install_reference_aliases():
         sys.modules.setdefault("model.dataset", _ds)
     except Exception:  # dataset needs PointNetGPD_FOLDER only when instantiated
         pass
+
+
+def install_sampler_alias():
+    """Route ``from dexnet.grasping import GpgGraspSamplerPcl`` (dex-net/apps/kinect2grasp.py:33) to the GPU sampler
+    of ``pointnetgpd_amd.gpg``: patches the real ``dexnet.grasping`` module when dex-net is installed, otherwise
+    registers a minimal ``dexnet`` / ``dexnet.grasping`` pair holding only that class.  Opt-in; returns the class."""
+    import importlib
+    import sys
+    import types
+    from .gpg import GpgGraspSamplerPcl
+    try:
+        grasping = importlib.import_module("dexnet.grasping")
+    except Exception:
+        dexnet = sys.modules.get("dexnet") or types.ModuleType("dexnet")
+        grasping = types.ModuleType("dexnet.grasping")
+        dexnet.grasping = grasping
+        sys.modules["dexnet"] = dexnet
+        sys.modules["dexnet.grasping"] = grasping
+    grasping.GpgGraspSamplerPcl = GpgGraspSamplerPcl
+    return GpgGraspSamplerPcl

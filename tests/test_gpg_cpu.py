@@ -137,3 +137,24 @@ def test_sampler_host_half_against_goldens(monkeypatch):
         np.testing.assert_allclose(got, ref, rtol=0, atol=1e-11)
         # and the oracle on those draws is a prefix of the executed-reference record
         np.testing.assert_allclose(ref, fx["grasps"][:len(ref)], rtol=0, atol=1e-13)
+
+
+def test_sampler_alias_for_kinect2grasp_import():
+    """``from dexnet.grasping import GpgGraspSamplerPcl`` (kinect2grasp.py:33) resolves to the GPU sampler."""
+    import importlib
+    import sys
+    import pointnetgpd_amd
+    from pointnetgpd_amd import gpg
+    saved = {k: sys.modules.get(k) for k in ("dexnet", "dexnet.grasping")}
+    try:
+        cls = pointnetgpd_amd.install_sampler_alias()
+        assert cls is gpg.GpgGraspSamplerPcl
+        assert importlib.import_module("dexnet.grasping").GpgGraspSamplerPcl is gpg.GpgGraspSamplerPcl
+        ags = cls(go.ROBOTIQ_85, {"anything": 1})                       # (gripper, yaml_config) as at kinect2grasp.py:52
+        assert gpg._gripper_dict(ags.gripper)["hand_depth"] == 0.125
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
