@@ -62,3 +62,30 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libpngpd.so")
     with pytest.raises(RuntimeError, match="libpngpd.so not found"):
         _lib.load()
+
+
+def test_argument_validation_of_every_family():
+    """Each entry family rejects bad arguments with a status code BEFORE any launch (testable without a GPU).
+    Non-null dummy addresses are never dereferenced on these paths."""
+    from pointnetgpd_amd import _lib
+    lib = _lib.load()
+    p = 0x1000                                             # dummy non-null "device pointer"
+    INV, UNSUP = 1, 3
+    # sampler
+    assert lib.pngpd_gpg_normal_moments(None, 0, p, 10, p, 1, 0.1, 100, p, p, None) == INV
+    assert lib.pngpd_gpg_normal_moments(p, 0, p, 10, p, 1, -1.0, 100, p, p, None) == INV          # radius <= 0
+    assert lib.pngpd_hand_box_counts(p, 0, 10, p, 5, p, 2, p, None) == UNSUP                       # 1 or 4 boxes only
+    assert lib.pngpd_hand_box_counts(p, 0, 0, p, 5, p, 4, p, None) == INV                          # empty cloud
+    assert lib.pngpd_hand_box_counts_indexed(p, 0, 130, p, 2, p, 5, p, 4, p, None) == INV          # C != ceil(P/64)
+    assert lib.pngpd_hand_box_counts_indexed(p, 0, 130, p, 3, p, 5, p, 3, p, None) == UNSUP
+    # crop
+    assert lib.pngpd_crop_count_compact(p, 0, 10, p, 0, 16, p, p, None) == INV                     # G == 0
+    assert lib.pngpd_crop_resample(p, 0, p, 1, p, p, 16, 8, 2, 20, 0, None, p, p, None) == INV     # mode not in {0,1}
+    assert lib.pngpd_crop_resample(p, 0, p, 1, p, p, 1 << 20, 8, 1, 20, 0, None, p, p, None) == UNSUP  # LDS bound
+    # training passes
+    assert lib.pngpd_trunk_h_moments(p, 4, 100, None, p, p, p, p, p, p, p, 0, p, p, p, None) == INV    # S < 1
+    assert lib.pngpd_trunk_h_moments(p, 4, 100, None, p, p, p, p, p, p, p, 3, p, p, p, None) == INV    # S > ceil(N/64)
+    assert lib.pngpd_fold_conv_bn(p, p, None, None, None, None, 1e-5, 30, 8, 1, p, p, None) == INV      # MFMA_B needs C % 32 == 0
+    assert lib.pngpd_fc_fwd(p, 4, 12, p, p, 3, 0, p, None) == INV                                  # K % 8 != 0
+    assert lib.pngpd_fc_fwd(p, 4, 16, p, p, 40, 3, p, None) == INV                                 # log_softmax needs Nout <= 32
+    assert lib.pngpd_strerror(UNSUP) == b"unsupported configuration"
