@@ -241,6 +241,11 @@ int pngpd_dw1_finalize(const double *Rb, const float *trans, const double *mom, 
  * order (np.where order), truncated to max_keep.                                              */
 int pngpd_crop_count_compact(const void *cloud, int cloud_is_f64, int P, const double *frames, int G,
                              int max_keep, int *counts, int *idx, void *stream);
+/* Same, against a cloud ARENA (all clouds of a dataset resident in one (P,3) buffer): grasp g sees only the
+ * points [ranges[2g], ranges[2g] + ranges[2g+1]) — the cloud file its sample was drawn with, dataset.py:429-433 —
+ * and idx holds arena-absolute indices, so pngpd_crop_resample applies unchanged.  ranges (G,2) int32.  */
+int pngpd_crop_count_compact_ranges(const void *arena, int cloud_is_f64, int P, const double *frames,
+                                    const int *ranges, int G, int max_keep, int *counts, int *idx, void *stream);
 /* out (G,3,N) fp32 = N resampled in-box points per grasp in the hand frame (the `.T` layout of
  * dataset.py:440-444); valid (G) = count >= min_points (dataset.py:71, kinect2grasp.py:462).
  * mode 0: without replacement iff m > N (dataset.py:439); mode 1: iff m >= N (kinect2grasp.py:474),

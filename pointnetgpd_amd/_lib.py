@@ -72,6 +72,8 @@ SIGNATURES = {
     # ---- crop / resample
     "pngpd_crop_count_compact": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, ctypes.c_int,
                                                 ctypes.c_int, c_void, c_void, c_void]),
+    "pngpd_crop_count_compact_ranges": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, c_void, ctypes.c_int,
+                                                       ctypes.c_int, c_void, c_void, c_void]),
     "pngpd_crop_resample": (ctypes.c_int, [c_void, ctypes.c_int, c_void, ctypes.c_int, c_void, c_void,
                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_ulonglong, c_void, c_void, c_void, c_void]),

@@ -47,20 +47,24 @@ __device__ __forceinline__ void to_frame(const Frame &F, double x, double y, dou
 
 // One workgroup per grasp: count the in-box points and write their indices in ascending order
 // (== np.where(...)[0]) — ordered stream compaction by wave ballots + a 4-entry LDS prefix.
+// ranges != NULL: grasp g only sees points [ranges[2g], ranges[2g] + ranges[2g+1]) of a cloud ARENA (many scene /
+// object clouds resident in one buffer); the indices written are arena-absolute, so crop_resample runs unchanged.
 template <bool F64>
 __global__ __launch_bounds__(256) void crop_count_compact_kernel(
-    const void *__restrict__ cloud, int P, const double *__restrict__ frames, int max_keep,
-    int *__restrict__ counts, int *__restrict__ idx) {
+    const void *__restrict__ cloud, int P, const double *__restrict__ frames, const int *__restrict__ ranges,
+    int max_keep, int *__restrict__ counts, int *__restrict__ idx) {
     __shared__ int wcnt[4];
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     Frame F;
     load_frame(frames + (size_t)g * 18, F);
     int running = 0;
     int *out = idx + (size_t)g * max_keep;
-    for (int base = 0; base < P; base += 256) {
+    const int p_begin = ranges ? ranges[2 * g] : 0;
+    const int p_end = ranges ? p_begin + ranges[2 * g + 1] : P;
+    for (int base = p_begin; base < p_end; base += 256) {
         const int p = base + tid;
         bool in = false;
-        if (p < P) {
+        if (p < p_end) {
             double x, y, z, a, b, c;
             load_point<F64>(cloud, p, x, y, z);
             to_frame(F, x, y, z, a, b, c);
@@ -202,10 +206,23 @@ int pngpd_crop_count_compact(const void *cloud, int cloud_is_f64, int P, const d
     if (!cloud || !frames || !counts || !idx || P <= 0 || G <= 0 || max_keep <= 0) return PNGPD_ERR_INVALID_ARG;
     if (cloud_is_f64)
         hipLaunchKernelGGL(crop_count_compact_kernel<true>, dim3(G), dim3(256), 0, (hipStream_t)stream,
-                           cloud, P, frames, max_keep, counts, idx);
+                           cloud, P, frames, (const int *)nullptr, max_keep, counts, idx);
     else
         hipLaunchKernelGGL(crop_count_compact_kernel<false>, dim3(G), dim3(256), 0, (hipStream_t)stream,
-                           cloud, P, frames, max_keep, counts, idx);
+                           cloud, P, frames, (const int *)nullptr, max_keep, counts, idx);
+    return pngpd_launch_status();
+}
+
+int pngpd_crop_count_compact_ranges(const void *arena, int cloud_is_f64, int P, const double *frames,
+                                    const int *ranges, int G, int max_keep, int *counts, int *idx, void *stream) {
+    if (!arena || !frames || !ranges || !counts || !idx || P <= 0 || G <= 0 || max_keep <= 0)
+        return PNGPD_ERR_INVALID_ARG;
+    if (cloud_is_f64)
+        hipLaunchKernelGGL(crop_count_compact_kernel<true>, dim3(G), dim3(256), 0, (hipStream_t)stream,
+                           arena, P, frames, ranges, max_keep, counts, idx);
+    else
+        hipLaunchKernelGGL(crop_count_compact_kernel<false>, dim3(G), dim3(256), 0, (hipStream_t)stream,
+                           arena, P, frames, ranges, max_keep, counts, idx);
     return pngpd_launch_status();
 }
 

@@ -1,0 +1,85 @@
+"""GPU: the device-resident one-view training loader against the numpy Dataset mirror item by item (in-box counts,
+None status, labels, and every output column being one of the item's in-box points), on the synthetic data tree."""
+import numpy as np
+import pytest
+import torch
+
+from tests import synth_dataset
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("cls_name,kw", [("PointGraspOneViewDataset", dict(grasp_points_num=64, grasp_amount_per_file=12,
+                                                                          thresh_good=0.6, thresh_bad=0.6, tag="train")),
+                                         ("PointGraspOneViewDataset", dict(grasp_points_num=64, grasp_amount_per_file=12,
+                                                                          thresh_good=0.45, thresh_bad=1.2, tag="train")),   # label None in between
+                                         ("PointGraspOneViewMultiClassDataset", dict(grasp_points_num=200, grasp_amount_per_file=12,
+                                                                                    thresh_good=0.5, thresh_bad=1.2, tag="test"))])
+def test_device_loader_matches_dataset_semantics(cls_name, kw, tmp_path, monkeypatch, cuda_device):
+    from pointnetgpd_amd import crop
+    from pointnetgpd_amd.device_loader import DeviceGraspLoader
+    from pointnetgpd_amd.model import dataset as ds_mod
+    root = synth_dataset.build(str(tmp_path / "tree"))
+    monkeypatch.setenv("PointNetGPD_FOLDER", root)
+    ds = getattr(ds_mod, cls_name)(**kw)
+    assert len(ds) == 36
+    if cls_name.endswith("MultiClassDataset"):
+        ds.min_point_limit = 165                 # in-box counts on this tree are 140..190: exercises the "< limit -> None" drop
+    loader = DeviceGraspLoader(ds, batch_size=16, device=cuda_device, shuffle=True, seed=3)
+    assert len(loader) == 3
+    seen, total_kept = [], 0
+    N = kw["grasp_points_num"]
+    for data, target in loader:
+        meta = loader.last_meta
+        keep = meta["keep"].cpu().numpy()
+        counts = meta["counts"].cpu().numpy()
+        assert data.shape == (int(keep.sum()), 3, N) and data.dtype == torch.float32 and target.dtype == torch.int64
+        row = 0
+        for i, item in enumerate(meta["items"]):
+            oi, gi = np.unravel_index(item, (len(ds.object), ds.grasp_amount_per_file))
+            obj = ds.object[oi]
+            grasp = np.load(ds.d_grasp[obj])[gi]
+            pc = np.load(meta["views"][i])
+            assert meta["views"][i] in ds.d_pc[ds.transform[obj][0]]
+            frame = crop.frames_from_grasps_train(grasp[None, :], ds.transform[obj][1])[0]
+            ind, pts = crop.collect_pc_numpy(frame, pc)                    # the Dataset mirror's own crop
+            assert counts[i] == len(ind)
+            label = ds._label(grasp[-2] + grasp[-1] * 0.01)
+            expect_keep = len(ind) >= ds.min_point_limit and label is not None    # dataset.py:71-72 + label None + my_collate
+            assert bool(keep[i]) == expect_keep
+            if expect_keep:
+                assert int(target[row]) == label
+                cols = data[row].cpu().numpy().T                           # (N,3)
+                ref32 = pts.astype(np.float32)
+                d = np.abs(cols[:, None, :] - ref32[None, :, :]).max(2)
+                assert d.min(1).max() <= 1e-7                              # every column is an in-box point of THIS view
+                if len(ind) > N:
+                    assert len(set(d.argmin(1).tolist())) == N              # without replacement (dataset.py:439)
+                row += 1
+        assert row == data.shape[0]
+        seen += meta["items"].tolist()
+        total_kept += row
+    assert sorted(seen) == list(range(36)) and 0 < total_kept
+    if kw["thresh_good"] == 0.45 or cls_name.endswith("MultiClassDataset"):
+        assert total_kept < 36                    # something was dropped
+    # a second epoch reshuffles; the same (seed, epoch) reproduces the batches bit for bit
+    first = [b[0].clone() for b in DeviceGraspLoader(ds, 16, cuda_device, seed=3)]
+    again = [b[0].clone() for b in DeviceGraspLoader(ds, 16, cuda_device, seed=3)]
+    assert all(torch.equal(a, b) for a, b in zip(first, again))
+    loader.set_epoch(1)
+    other = [b[0] for b in loader]
+    assert not all(a.shape == b.shape and torch.equal(a, b) for a, b in zip(first, other))
+
+
+def test_device_loader_rejects_fullview_and_cpu(tmp_path, monkeypatch, cuda_device):
+    from pointnetgpd_amd.device_loader import DeviceGraspLoader
+    from pointnetgpd_amd.model import dataset as ds_mod
+    root = synth_dataset.build(str(tmp_path / "tree"))
+    monkeypatch.setenv("PointNetGPD_FOLDER", root)
+    full = ds_mod.PointGraspDataset(obj_points_num=4000, grasp_points_num=100, pc_file_used_num=3, grasp_amount_per_file=12,
+                                    thresh_good=0.6, thresh_bad=0.6, tag="train")
+    with pytest.raises(NotImplementedError):
+        DeviceGraspLoader(full, 8, cuda_device)
+    one = ds_mod.PointGraspOneViewDataset(grasp_points_num=64, grasp_amount_per_file=12, thresh_good=0.6, thresh_bad=0.6, tag="train")
+    with pytest.raises(RuntimeError, match="CUDA"):
+        DeviceGraspLoader(one, 8, "cpu")
