@@ -53,6 +53,10 @@ class DeviceGraspLoader:
     def __len__(self):
         return (len(self.ds) + self.B - 1) // self.B
 
+    @property
+    def dataset(self):
+        return self.ds
+
     def set_epoch(self, epoch):
         self.epoch = int(epoch)
 

@@ -83,3 +83,18 @@ def test_device_loader_rejects_fullview_and_cpu(tmp_path, monkeypatch, cuda_devi
     one = ds_mod.PointGraspOneViewDataset(grasp_points_num=64, grasp_amount_per_file=12, thresh_good=0.6, thresh_bad=0.6, tag="train")
     with pytest.raises(RuntimeError, match="CUDA"):
         DeviceGraspLoader(one, 8, "cpu")
+
+
+def test_cli_with_device_data(tmp_path, monkeypatch, cuda_device):
+    """main_1v-style training on the (synthetic) on-disk tree with the HBM-resident loader feeding the HIP step."""
+    from pointnetgpd_amd import mains
+    root = synth_dataset.build(str(tmp_path / "tree"), grasps_per_obj=6500)   # the CLI indexes 6500 / 500 grasps per file
+    monkeypatch.setenv("PointNetGPD_FOLDER", root)
+    monkeypatch.setitem(mains.VARIANTS["1v"], "num_points", 64)         # the tree's crops hold ~150 points
+    args = ["--mode", "train", "--epoch", "2", "--cuda", "--gpu", "0", "--batch-size", "8", "--num-workers", "0",
+            "--max-batches", "3",
+            "--model-path", str(tmp_path / "m"), "--log-dir", str(tmp_path / "l"), "--seed", "4", "--tag", "dd",
+            "--device-data"]
+    r = mains.run("1v", args)
+    assert np.isfinite(r["test_loss"]) and 0.0 <= r["train_acc"] <= 1.0
+    assert (tmp_path / "m" / "dd_1.model").exists()
