@@ -246,6 +246,12 @@ int pngpd_crop_count_compact(const void *cloud, int cloud_is_f64, int P, const d
  * and idx holds arena-absolute indices, so pngpd_crop_resample applies unchanged.  ranges (G,2) int32.  */
 int pngpd_crop_count_compact_ranges(const void *arena, int cloud_is_f64, int P, const double *frames,
                                     const int *ranges, int G, int max_keep, int *counts, int *idx, void *stream);
+/* Same, with an explicit point list per grasp: grasp g sees arena[gather[g][0..Pg)] in that order (duplicates
+ * allowed) — the per-sample cloud of the full-view datasets, Pg rows drawn with replacement from the stack of the
+ * randomly chosen view files (dataset.py:252-254).  gather (G,Pg) int32, arena-absolute; idx likewise.        */
+int pngpd_crop_count_compact_gather(const void *arena, int cloud_is_f64, int P, const double *frames,
+                                    const int *gather, int Pg, int G, int max_keep, int *counts, int *idx,
+                                    void *stream);
 /* out (G,3,N) fp32 = N resampled in-box points per grasp in the hand frame (the `.T` layout of
  * dataset.py:440-444); valid (G) = count >= min_points (dataset.py:71, kinect2grasp.py:462).
  * mode 0: without replacement iff m > N (dataset.py:439); mode 1: iff m >= N (kinect2grasp.py:474),

@@ -74,6 +74,8 @@ SIGNATURES = {
                                                 ctypes.c_int, c_void, c_void, c_void]),
     "pngpd_crop_count_compact_ranges": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, c_void, ctypes.c_int,
                                                        ctypes.c_int, c_void, c_void, c_void]),
+    "pngpd_crop_count_compact_gather": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, c_void, ctypes.c_int,
+                                                       ctypes.c_int, ctypes.c_int, c_void, c_void, c_void]),
     "pngpd_crop_resample": (ctypes.c_int, [c_void, ctypes.c_int, c_void, ctypes.c_int, c_void, c_void,
                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_ulonglong, c_void, c_void, c_void, c_void]),

@@ -126,6 +126,27 @@ def crop_count_compact_ranges(arena, frames, ranges, max_keep=4096):
     return counts, idx
 
 
+def crop_count_compact_gather(arena, frames, gather, max_keep=4096):
+    """arena (P,3) CUDA; frames (G,18) CUDA fp64; gather (G,Pg) CUDA int32 arena rows forming each grasp's own cloud
+    (duplicates allowed) -> counts (G) int32, idx (G,max_keep) int32 arena-absolute, in the order of ``gather``."""
+    lib = _lib.load()
+    if not arena.is_cuda or arena.dim() != 2 or arena.shape[1] != 3 or arena.dtype not in (torch.float32, torch.float64):
+        raise RuntimeError("arena: expected a CUDA (P,3) float32/float64 tensor")
+    if not frames.is_cuda or frames.dtype != torch.float64 or frames.dim() != 2 or frames.shape[1] != 18:
+        raise RuntimeError("frames: expected a CUDA (G,18) float64 tensor")
+    G = frames.shape[0]
+    if not gather.is_cuda or gather.dtype != torch.int32 or gather.dim() != 2 or gather.shape[0] != G:
+        raise RuntimeError("gather: expected a CUDA (G,Pg) int32 tensor")
+    arena, frames, gather = arena.contiguous(), frames.contiguous(), gather.contiguous()
+    counts = torch.empty(G, device=arena.device, dtype=torch.int32)
+    idx = torch.empty(G, max_keep, device=arena.device, dtype=torch.int32)
+    with _lib.device_guard(arena.device):
+        _lib.check(lib.pngpd_crop_count_compact_gather(_p(arena), int(arena.dtype == torch.float64), arena.shape[0],
+                                                       _p(frames), _p(gather), gather.shape[1], G, int(max_keep),
+                                                       _p(counts), _p(idx), _stream(arena)), "crop_count_compact_gather")
+    return counts, idx
+
+
 def crop_resample(cloud, frames, counts, idx, num_points, mode=MODE_INFER, min_points=MIN_POINTS_TO_NET,
                   seed=0, sel=None):
     """-> out (G,3,num_points) fp32 in the hand frame, valid (G) bool."""

@@ -48,23 +48,28 @@ __device__ __forceinline__ void to_frame(const Frame &F, double x, double y, dou
 // One workgroup per grasp: count the in-box points and write their indices in ascending order
 // (== np.where(...)[0]) — ordered stream compaction by wave ballots + a 4-entry LDS prefix.
 // ranges != NULL: grasp g only sees points [ranges[2g], ranges[2g] + ranges[2g+1]) of a cloud ARENA (many scene /
-// object clouds resident in one buffer); the indices written are arena-absolute, so crop_resample runs unchanged.
+// object clouds resident in one buffer).  gather != NULL: grasp g sees the Pg points arena[gather[g][0..Pg)] (a
+// per-sample random subsample of stacked views, dataset.py:252-254).  Either way the indices written are
+// arena-absolute and in the order of the grasp's own cloud, so crop_resample runs unchanged.
 template <bool F64>
 __global__ __launch_bounds__(256) void crop_count_compact_kernel(
     const void *__restrict__ cloud, int P, const double *__restrict__ frames, const int *__restrict__ ranges,
-    int max_keep, int *__restrict__ counts, int *__restrict__ idx) {
+    const int *__restrict__ gather, int Pg, int max_keep, int *__restrict__ counts, int *__restrict__ idx) {
     __shared__ int wcnt[4];
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     Frame F;
     load_frame(frames + (size_t)g * 18, F);
     int running = 0;
     int *out = idx + (size_t)g * max_keep;
-    const int p_begin = ranges ? ranges[2 * g] : 0;
-    const int p_end = ranges ? p_begin + ranges[2 * g + 1] : P;
-    for (int base = p_begin; base < p_end; base += 256) {
-        const int p = base + tid;
+    const int p_begin = (!gather && ranges) ? ranges[2 * g] : 0;
+    const int n = gather ? Pg : (ranges ? ranges[2 * g + 1] : P);
+    const int *gi = gather ? gather + (size_t)g * Pg : nullptr;
+    for (int base = 0; base < n; base += 256) {
+        const int i = base + tid;
         bool in = false;
-        if (p < p_end) {
+        int p = 0;
+        if (i < n) {
+            p = gi ? gi[i] : p_begin + i;
             double x, y, z, a, b, c;
             load_point<F64>(cloud, p, x, y, z);
             to_frame(F, x, y, z, a, b, c);
@@ -206,10 +211,10 @@ int pngpd_crop_count_compact(const void *cloud, int cloud_is_f64, int P, const d
     if (!cloud || !frames || !counts || !idx || P <= 0 || G <= 0 || max_keep <= 0) return PNGPD_ERR_INVALID_ARG;
     if (cloud_is_f64)
         hipLaunchKernelGGL(crop_count_compact_kernel<true>, dim3(G), dim3(256), 0, (hipStream_t)stream,
-                           cloud, P, frames, (const int *)nullptr, max_keep, counts, idx);
+                           cloud, P, frames, (const int *)nullptr, (const int *)nullptr, 0, max_keep, counts, idx);
     else
         hipLaunchKernelGGL(crop_count_compact_kernel<false>, dim3(G), dim3(256), 0, (hipStream_t)stream,
-                           cloud, P, frames, (const int *)nullptr, max_keep, counts, idx);
+                           cloud, P, frames, (const int *)nullptr, (const int *)nullptr, 0, max_keep, counts, idx);
     return pngpd_launch_status();
 }
 
@@ -219,10 +224,24 @@ int pngpd_crop_count_compact_ranges(const void *arena, int cloud_is_f64, int P, 
         return PNGPD_ERR_INVALID_ARG;
     if (cloud_is_f64)
         hipLaunchKernelGGL(crop_count_compact_kernel<true>, dim3(G), dim3(256), 0, (hipStream_t)stream,
-                           arena, P, frames, ranges, max_keep, counts, idx);
+                           arena, P, frames, ranges, (const int *)nullptr, 0, max_keep, counts, idx);
     else
         hipLaunchKernelGGL(crop_count_compact_kernel<false>, dim3(G), dim3(256), 0, (hipStream_t)stream,
-                           arena, P, frames, ranges, max_keep, counts, idx);
+                           arena, P, frames, ranges, (const int *)nullptr, 0, max_keep, counts, idx);
+    return pngpd_launch_status();
+}
+
+int pngpd_crop_count_compact_gather(const void *arena, int cloud_is_f64, int P, const double *frames,
+                                    const int *gather, int Pg, int G, int max_keep, int *counts, int *idx,
+                                    void *stream) {
+    if (!arena || !frames || !gather || !counts || !idx || P <= 0 || Pg <= 0 || G <= 0 || max_keep <= 0)
+        return PNGPD_ERR_INVALID_ARG;
+    if (cloud_is_f64)
+        hipLaunchKernelGGL(crop_count_compact_kernel<true>, dim3(G), dim3(256), 0, (hipStream_t)stream,
+                           arena, P, frames, (const int *)nullptr, gather, Pg, max_keep, counts, idx);
+    else
+        hipLaunchKernelGGL(crop_count_compact_kernel<false>, dim3(G), dim3(256), 0, (hipStream_t)stream,
+                           arena, P, frames, (const int *)nullptr, gather, Pg, max_keep, counts, idx);
     return pngpd_launch_status();
 }
 

@@ -71,7 +71,7 @@ def build_parser():
                    help="single-GPU --cuda training: replay full-size batches from a captured HIP graph "
                         "(train.GraphedTrainStep); ragged batches (my_collate dropped samples) run eagerly")
     p.add_argument("--device-data", action="store_true",
-                   help="one-view variants, single-GPU --cuda: keep every cloud resident in HBM and crop/resample "
+                   help="single-GPU --cuda: keep every cloud resident in HBM and crop/resample "
                         "training batches on the GPU (device_loader.DeviceGraspLoader) instead of DataLoader workers")
     p.add_argument("--log-dir", type=str, default="./assets/log/")
     return p
@@ -152,10 +152,11 @@ def _make_loaders(cfg, args):
         common_tr = dict(common, shuffle=False, sampler=sampler)
     else:
         common_tr = common
-    if getattr(args, "device_data", False) and args.cuda and sampler is None and not args.synthetic and not cfg["fullview"]:
+    if getattr(args, "device_data", False) and args.cuda and sampler is None and not args.synthetic:
         from .device_loader import DeviceGraspLoader
         dev = torch.device("cuda", args.gpu if args.gpu != -1 else 0)
-        train_loader = DeviceGraspLoader(tr, args.batch_size, dev, shuffle=True, seed=args.seed or 0)
+        train_loader = DeviceGraspLoader(tr, args.batch_size, dev, shuffle=True, seed=args.seed or 0,
+                                         max_keep=16384 if cfg["fullview"] else 8192)
         return train_loader, torch.utils.data.DataLoader(te, **common), train_loader   # set_epoch() like a sampler
     return (torch.utils.data.DataLoader(tr, **common_tr), torch.utils.data.DataLoader(te, **common), sampler)
 

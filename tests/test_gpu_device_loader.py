@@ -71,18 +71,71 @@ def test_device_loader_matches_dataset_semantics(cls_name, kw, tmp_path, monkeyp
     assert not all(a.shape == b.shape and torch.equal(a, b) for a, b in zip(first, other))
 
 
-def test_device_loader_rejects_fullview_and_cpu(tmp_path, monkeypatch, cuda_device):
+def test_device_loader_fullview_matches_dataset_semantics(tmp_path, monkeypatch, cuda_device):
+    """Full-view datasets: the per-sample cloud is the (device-built) gather list over the stacked random views;
+    counts / None status / labels / membership checked against the mirror's numpy crop of arena[gather]."""
+    from pointnetgpd_amd import crop
     from pointnetgpd_amd.device_loader import DeviceGraspLoader
     from pointnetgpd_amd.model import dataset as ds_mod
     root = synth_dataset.build(str(tmp_path / "tree"))
     monkeypatch.setenv("PointNetGPD_FOLDER", root)
-    full = ds_mod.PointGraspDataset(obj_points_num=4000, grasp_points_num=100, pc_file_used_num=3, grasp_amount_per_file=12,
-                                    thresh_good=0.6, thresh_bad=0.6, tag="train")
-    with pytest.raises(NotImplementedError):
-        DeviceGraspLoader(full, 8, cuda_device)
+    ds = ds_mod.PointGraspMultiClassDataset(obj_points_num=4000, grasp_points_num=100, pc_file_used_num=3,
+                                            grasp_amount_per_file=12, thresh_good=0.5, thresh_bad=1.2, tag="train")
+    ds.min_point_limit = 225                        # in-box counts here are ~185..250: exercises the drop
+    loader = DeviceGraspLoader(ds, batch_size=16, device=cuda_device, shuffle=True, seed=5)
+    arena = loader.arena.cpu().numpy()
+    assert arena.shape == (3 * 6 * 3000, 3)          # every view (NP1 + NP3) of every object, once
+    kept, dropped = 0, 0
+    for data, target in loader:
+        meta = loader.last_meta
+        gather = meta["gather"].cpu().numpy()
+        keep, counts = meta["keep"].cpu().numpy(), meta["counts"].cpu().numpy()
+        assert gather.shape == (len(meta["items"]), 4000)
+        row = 0
+        for i, item in enumerate(meta["items"]):
+            oi, gi = np.unravel_index(item, (len(ds.object), ds.grasp_amount_per_file))
+            obj = ds.object[oi]
+            assert len(meta["views"][i]) == 3 and all(v in ds.d_pc[ds.transform[obj][0]] for v in meta["views"][i])
+            spans = [loader.view_range[v] for v in meta["views"][i]]
+            inside = np.zeros(4000, bool)
+            for s0, n0 in spans:
+                inside |= (gather[i] >= s0) & (gather[i] < s0 + n0)
+            assert inside.all()                                            # rows come from the chosen views only
+            grasp = np.load(ds.d_grasp[obj])[gi]
+            frame = crop.frames_from_grasps_train(grasp[None, :], ds.transform[obj][1])[0]
+            ind, pts = crop.collect_pc_numpy(frame, arena[gather[i]])      # the mirror's crop of the same sample cloud
+            assert counts[i] == len(ind)
+            label = ds._label(grasp[-2] + grasp[-1] * 0.01)
+            assert bool(keep[i]) == (len(ind) >= ds.min_point_limit)
+            if keep[i]:
+                assert int(target[row]) == label
+                cols = data[row].cpu().numpy().T
+                d = np.abs(cols[:, None, :] - pts.astype(np.float32)[None, :, :]).max(2)
+                assert d.min(1).max() <= 1e-7
+                row += 1
+                kept += 1
+            else:
+                dropped += 1
+        assert row == data.shape[0]
+    assert kept > 0 and dropped > 0
+    # view slots are drawn in proportion to their length and rows uniformly: with equal-length views every arena row
+    # of the chosen views is equally likely -> mean index of a sample sits near the mean of its spans' centres
+    g0 = gather[0].astype(np.float64)
+    centres = np.mean([s0 + n0 / 2 for s0, n0 in [loader.view_range[v] for v in meta["views"][0]]])
+    assert abs(g0.mean() - centres) < 4 * 3000 / np.sqrt(12) * np.sqrt(3) / np.sqrt(4000) * 6 + 1500
+
+
+def test_device_loader_rejects_cpu_and_projection(tmp_path, monkeypatch, cuda_device):
+    from pointnetgpd_amd.device_loader import DeviceGraspLoader
+    from pointnetgpd_amd.model import dataset as ds_mod
+    root = synth_dataset.build(str(tmp_path / "tree"))
+    monkeypatch.setenv("PointNetGPD_FOLDER", root)
     one = ds_mod.PointGraspOneViewDataset(grasp_points_num=64, grasp_amount_per_file=12, thresh_good=0.6, thresh_bad=0.6, tag="train")
     with pytest.raises(RuntimeError, match="CUDA"):
         DeviceGraspLoader(one, 8, "cpu")
+    one.projection = True
+    with pytest.raises(NotImplementedError):
+        DeviceGraspLoader(one, 8, cuda_device)
 
 
 def test_cli_with_device_data(tmp_path, monkeypatch, cuda_device):
