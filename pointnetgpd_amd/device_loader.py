@@ -24,38 +24,76 @@ from . import crop
 
 
 class DeviceGraspLoader:
-    """Iterable of ``(data (B',3,N) fp32 CUDA, target (B',) int64 CUDA)`` batches over a one-view mirror dataset
-    (``model.dataset.PointGraspOneViewDataset`` / ``...MultiClassDataset``).  ``len()`` = batches per epoch.
-    ``last_meta`` holds, for the most recent batch, the item indices, the chosen view files and the keep mask."""
+    """Iterable of ``(data (B',3,N) fp32 CUDA, target (B',) int64 CUDA)`` batches over one of the four mirror
+    datasets of ``model.dataset`` (one-view and full-view, 2- and 3-class).  ``len()`` = batches per epoch.
+    ``last_meta`` holds, for the most recent batch, the item indices, the chosen view files, the in-box counts, the
+    keep mask, the labels (-1 = the reference's ``None``) and, for full-view datasets, the gather lists."""
 
     def __init__(self, dataset, batch_size, device, shuffle=True, seed=0, max_keep=8192):
-        self.fullview = not hasattr(dataset, "minimum_point_amount")
         if getattr(dataset, "projection", False):
             raise NotImplementedError("projection=True belongs to the GPD baseline")
         self.ds, self.B, self.device = dataset, int(batch_size), torch.device(device)
         self.shuffle, self.seed, self.max_keep, self.epoch = bool(shuffle), int(seed), int(max_keep), 0
         if self.device.type != "cuda":
             raise RuntimeError("DeviceGraspLoader needs a CUDA device (the host path is model.dataset + DataLoader)")
-        # ---- the arena: every view of every object, once
-        self.view_range = {}                                  # path -> (start, len)
+        chunks = self._index(dataset)
+        self.arena = torch.from_numpy(np.concatenate(chunks, 0)).to(self.device)
+        self.last_meta = None
+
+    def _index(self, dataset):
+        """Host tables (no device work): arena layout, per-object grasp rows, labels and view ranges."""
+        self.ds = dataset
+        self.fullview = not hasattr(dataset, "minimum_point_amount")
+        self.view_range = {}                                  # path -> (start, len) in the arena
         chunks, off = [], 0
+        self.files, self.grasps, self.labels, self.transforms = [], [], [], []
         for obj in dataset.object:
-            for path in dataset.d_pc[dataset.transform[obj][0]]:
+            files = list(dataset.d_pc[dataset.transform[obj][0]])
+            for path in files:
                 if path in self.view_range:
                     continue
                 pc = np.asarray(np.load(path), dtype=np.float64).reshape(-1, 3)
                 self.view_range[path] = (off, len(pc))
                 chunks.append(pc)
                 off += len(pc)
-        self.arena = torch.from_numpy(np.concatenate(chunks, 0)).to(self.device)
-        self.grasps = {obj: np.asarray(np.load(dataset.d_grasp[obj]), dtype=np.float64) for obj in dataset.object}
-        self.last_meta = None
+            g = np.asarray(np.load(dataset.d_grasp[obj]), dtype=np.float64)
+            lab = [dataset._label(r[-2] + r[-1] * 0.01) for r in g]        # dataset.py:446-453 / :535-541, once
+            self.files.append(files)
+            self.grasps.append(g)
+            self.labels.append(np.array([-1 if v is None else v for v in lab], dtype=np.int64))
+            self.transforms.append(dataset.transform[obj][1])
+        self.nfiles = np.array([len(f) for f in self.files], dtype=np.int64)
+        self.range_tab = np.zeros((len(self.files), int(self.nfiles.max()), 2), dtype=np.int64)
+        for oi, files in enumerate(self.files):
+            self.range_tab[oi, :len(files)] = [self.view_range[f] for f in files]
+        return chunks
+
+    def _assemble(self, items, rng):
+        """Host half of a batch, vectorised per object: frames (n,18), view picks, labels (-1 = the reference's None)."""
+        ds = self.ds
+        obj_ind, grasp_ind = np.unravel_index(items, (len(ds.object), ds.grasp_amount_per_file))
+        n = len(items)
+        frames = np.empty((n, 18))
+        labels = np.empty(n, dtype=np.int64)
+        for oi in np.unique(obj_ind):
+            sel = obj_ind == oi
+            frames[sel] = crop.frames_from_grasps_train(self.grasps[oi][grasp_ind[sel]], self.transforms[oi])
+            labels[sel] = self.labels[oi][grasp_ind[sel]]
+        if self.fullview:                                     # k views WITH replacement (:252-253)
+            pick = rng.integers(0, self.nfiles[obj_ind][:, None], size=(n, ds.pc_file_used_num))
+            spans = self.range_tab[obj_ind[:, None], pick]    # (n,k,2)
+            views = [[self.files[o][j] for j in row] for o, row in zip(obj_ind, pick)]
+        else:                                                 # uniform view (:425-428, shuffle-then-last)
+            pick = rng.integers(0, self.nfiles[obj_ind])
+            spans = self.range_tab[obj_ind, pick]             # (n,2)
+            views = [self.files[o][j] for o, j in zip(obj_ind, pick)]
+        return frames, labels, spans, views
 
     def _gather_lists(self, view_sets, batch_index):
         """(B, obj_points_num) int32 arena rows: ``pc[np.random.choice(len(pc), size=obj_points_num)]`` of the stacked
         views (:253-254) = pick a view slot with probability len_slot / len_stack, then a uniform row of that view."""
         dev = self.device
-        vs = torch.tensor(view_sets, dtype=torch.int64, device=dev)                  # (B,k,2) start, len
+        vs = torch.from_numpy(np.ascontiguousarray(view_sets, dtype=np.int64)).to(dev)   # (B,k,2) start, len
         start, length = vs[..., 0], vs[..., 1]
         gen = torch.Generator(device=dev)
         gen.manual_seed((self.seed * 1000003 + self.epoch) * 100003 + batch_index)
@@ -82,35 +120,15 @@ class DeviceGraspLoader:
         order = rng.permutation(len(ds)) if self.shuffle else np.arange(len(ds))
         for bi, s in enumerate(range(0, len(order), self.B)):
             items = order[s:s + self.B]
-            obj_ind, grasp_ind = np.unravel_index(items, (len(ds.object), ds.grasp_amount_per_file))
-            frames = np.empty((len(items), 18))
-            ranges = np.empty((len(items), 2), dtype=np.int32)
-            labels = np.empty(len(items), dtype=np.int64)
-            has_label = np.ones(len(items), dtype=bool)
-            views, view_sets = [], []
-            for i, (oi, gi) in enumerate(zip(obj_ind, grasp_ind)):
-                obj = ds.object[oi]
-                files = ds.d_pc[ds.transform[obj][0]]
-                if self.fullview:                                         # k views WITH replacement (:252-253)
-                    pick = rng.integers(0, len(files), size=ds.pc_file_used_num)
-                    view_sets.append([self.view_range[files[j]] for j in pick])
-                    views.append([files[j] for j in pick])
-                else:
-                    view = files[int(rng.integers(0, len(files)))]        # uniform view (:425-428)
-                    views.append(view)
-                    ranges[i] = self.view_range[view]
-                grasp = self.grasps[obj][gi]
-                frames[i] = crop.frames_from_grasps_train(grasp[None, :], ds.transform[obj][1])[0]
-                lab = ds._label(grasp[-2] + grasp[-1] * 0.01)             # :446-453
-                has_label[i] = lab is not None
-                labels[i] = -1 if lab is None else lab
+            frames, labels, spans, views = self._assemble(items, rng)
+            has_label = labels >= 0
             fr = torch.from_numpy(frames).to(self.device)
             if self.fullview:
-                gather = self._gather_lists(view_sets, bi)
+                gather = self._gather_lists(spans, bi)
                 counts, idx = crop.crop_count_compact_gather(self.arena, fr, gather, self.max_keep)
             else:
                 gather = None
-                rg = torch.from_numpy(ranges).to(self.device)
+                rg = torch.from_numpy(spans.astype(np.int32)).to(self.device)
                 counts, idx = crop.crop_count_compact_ranges(self.arena, fr, rg, self.max_keep)
             out, valid = crop.crop_resample(self.arena, fr, counts, idx, ds.grasp_points_num, crop.MODE_TRAIN,
                                             ds.min_point_limit, seed=(self.seed * 1000003 + self.epoch) * 100003 + bi)

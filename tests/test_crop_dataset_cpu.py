@@ -116,3 +116,44 @@ def test_dataset_projection_is_out_of_scope():
                                              thresh_bad=0.6, tag="train", projection=True)
         with pytest.raises(NotImplementedError):
             ds[0]
+
+
+def test_device_loader_host_half(tmp_path, monkeypatch):
+    """CPU: the host half of device_loader.DeviceGraspLoader (arena layout, per-object vectorised frames, cached
+    labels, view picks) against a per-item evaluation with the Dataset mirror's own pieces.  (The device half —
+    two kernel launches — is covered by tests/test_gpu_device_loader.py.)"""
+    from pointnetgpd_amd import crop
+    from pointnetgpd_amd.device_loader import DeviceGraspLoader
+    from pointnetgpd_amd.model import dataset as ds_mod
+    root = synth_dataset.build(str(tmp_path / "tree"))
+    monkeypatch.setenv("PointNetGPD_FOLDER", root)
+    for ds in (ds_mod.PointGraspOneViewDataset(grasp_points_num=64, grasp_amount_per_file=12, thresh_good=0.45,
+                                               thresh_bad=1.2, tag="train"),
+               ds_mod.PointGraspMultiClassDataset(obj_points_num=4000, grasp_points_num=100, pc_file_used_num=3,
+                                                  grasp_amount_per_file=12, thresh_good=0.5, thresh_bad=1.2, tag="test")):
+        ld = object.__new__(DeviceGraspLoader)               # host tables only: no device, no arena upload
+        chunks = ld._index(ds)
+        arena = np.concatenate(chunks, 0)
+        n_views = 3 if not ld.fullview else 6
+        assert arena.shape == (3 * n_views * 3000, 3)
+        for path, (s0, n0) in ld.view_range.items():
+            assert np.array_equal(arena[s0:s0 + n0], np.load(path))
+        rng = np.random.default_rng(7)
+        items = rng.permutation(len(ds))[:20]
+        frames, labels, spans, views = ld._assemble(items, rng)
+        for i, item in enumerate(items):
+            oi, gi = np.unravel_index(item, (len(ds.object), ds.grasp_amount_per_file))
+            obj = ds.object[oi]
+            grasp = np.load(ds.d_grasp[obj])[gi]
+            ref = crop.frames_from_grasps_train(grasp[None, :], ds.transform[obj][1])[0]
+            np.testing.assert_allclose(frames[i], ref, rtol=0, atol=1e-15)
+            lab = ds._label(grasp[-2] + grasp[-1] * 0.01)
+            assert labels[i] == (-1 if lab is None else lab)
+            files = ds.d_pc[ds.transform[obj][0]]
+            if ld.fullview:
+                assert len(views[i]) == 3 and all(v in files for v in views[i])
+                assert [tuple(r) for r in spans[i]] == [ld.view_range[v] for v in views[i]]
+            else:
+                assert views[i] in files and tuple(spans[i]) == ld.view_range[views[i]]
+        if not ld.fullview:
+            assert (labels == -1).any() and (labels >= 0).any()      # thresholds 0.45 / 1.2 leave a None band
