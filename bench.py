@@ -1,17 +1,27 @@
 #!/usr/bin/env python3
 """bench.py — grasps/s of the PointNetGPD grasp-evaluation hot path on MI355X.
 
-Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` (for N>1 launched under
-torch.distributed.run, one rank per GPU).  Prints ONE JSON line on rank 0.
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``.  For N > 1 the driver launches it under
+``torch.distributed.run`` (one rank per GPU, RANK/LOCAL_RANK/WORLD_SIZE in the environment); run from a plain shell
+with ``--gpus N`` it launches its own N ranks the same way.  Rank 0 prints ONE JSON line.
 
-Workload = BASELINE.json configs[1]: 2-class PointNetCls, N=1024 points, batch 1024 clouds per
-GPU, fp32, synthetic in-gripper clouds already resident in HBM.  One "step" = one eval-mode
-``PointNetCls.forward`` over the batch (STN trunk + STN FC + feat trunk + head, log-probs left on
-the device).  Inference shards by batch with no data-path collective -> weak scaling.
+Workload = BASELINE.json configs[1]: 2-class PointNetCls, N = 1024 points, 1024 clouds per GPU, fp32, synthetic
+in-gripper clouds already resident in HBM.  One "step" = one eval-mode ``PointNetCls.forward`` over the batch (STN
+trunk + STN FC + feat trunk + head, log-probs left on the device).  Inference shards by batch with no data-path
+collective -> weak scaling.  The training step (forward with batch-statistics BatchNorm + nll_loss + backward +
+Adam, plus one flat RCCL all-reduce of the 1.6 M gradients when N > 1) is reported under "train", both with the
+per-GPU batch fixed (weak) and with the global batch fixed (strong).
+
+Timing: W warm-up steps, then blocks of exactly K steps, each bracketed by barrier + synchronize on both sides and
+by HIP events on the launch stream; blocks repeat until >= --min-seconds of timed work and the MEDIAN block is
+reported (max over ranks per block).
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -19,23 +29,47 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 FLOP_PER_POINT_TRUNK = 2 * (3 * 64 + 64 * 128 + 128 * 1024)   # 278,912
 FLOP_FC_K2 = 2_627_072
 PEAK_FP32_MFMA_TFLOPS = 157.3                                   # MI355X_MICROARCH.md
+PEAK_BF16_MFMA_TFLOPS = 2500.0
 HBM_PEAK_GBS = 8000.0
+REF_ROOT = "/root/reference"
+
+# MFMA FLOPs one training step actually executes per point and trunk: every pass recomputes layers
+# 1-2 (L12); pass C adds layer 3; pass D the 128x128 mat-vec, the one-hot sparse term (dense-ified: ~1 hit per point
+# -> 2*32*128 per hit) and 10 of the 16 Gram blocks; pass E W2^T dz2 and dW2; the gather pass one more L12.
+_L12 = 2 * (3 * 64 + 64 * 128)
+EXEC_FLOP_PER_POINT_TRUNK = {
+    "B bn2 stats": _L12,
+    "C forward": _L12 + 2 * 128 * 1024,
+    "gather": _L12,
+    "D": _L12 + 2 * 128 * 128 + 2 * 32 * 128 + (10 * 2 * 128 * 128) // 16,
+    "E": _L12 + 2 * 128 * 64 + 2 * 128 * 64,
+}
 
 
 def flops_per_grasp(n, k=2):
     return n * (2 * FLOP_PER_POINT_TRUNK + 18) + FLOP_FC_K2 + (512 if k == 3 else 0)
 
 
+def train_exec_flops_per_grasp(n):
+    """Executed matrix FLOPs of one training step per grasp: two trunks + the FC stacks forward and backward (3x)."""
+    return 2 * n * sum(EXEC_FLOP_PER_POINT_TRUNK.values()) + 3 * FLOP_FC_K2
+
+
 def build_model(num_points, k, device):
+    import torch
     from pointnetgpd_amd.model.pointnet import PointNetCls
     torch.manual_seed(0)
     m = PointNetCls(num_points=num_points, input_chann=3, k=k)
-    # non-trivial eval-mode BN: the same recipe the parity tests use
+    _randomize_bn(m)
+    return m.eval().to(device)
+
+
+def _randomize_bn(m):
+    """Non-trivial eval-mode BN: the same recipe the parity tests use."""
+    import torch
     g = torch.Generator().manual_seed(4321)
     with torch.no_grad():
         for name, buf in m.named_buffers():
@@ -49,38 +83,194 @@ def build_model(num_points, k, device):
                     p.copy_(torch.rand(p.shape, generator=g) + 0.5)
                 else:
                     p.copy_(torch.randn(p.shape, generator=g) * 0.1)
-    return m.eval().to(device)
 
 
 def synth_clouds(b, n, seed, device):
+    import torch
     g = torch.Generator().manual_seed(seed)
     w = 0.085
     u = torch.rand(b, 3, n, generator=g) - 0.5
     return (u * torch.tensor([w / 2, w, w / 2]).view(1, 3, 1)).float().contiguous().to(device)
 
 
-def cpu_baseline(num_points, k, budget_s=20.0):
-    """The oracle's torch-functional restatement (the reference's own ATen op sequence) timed on
-    this box's host cores, on a bounded sample of the same workload."""
+# ------------------------------------------------------------------------------------------------------------
+# CPU baseline: the UNMODIFIED reference when /root/reference is importable (build container),
+# else the oracle's restatement of the same ATen op sequence (GPU box).  Bounded samples, ~20 s in total.
+# ------------------------------------------------------------------------------------------------------------
+def _load_reference_pointnet():
+    import importlib.util
+    path = os.path.join(REF_ROOT, "PointNetGPD", "model", "pointnet.py")
+    if not os.path.exists(path):
+        return None
+    spec = importlib.util.spec_from_file_location("_reference_pointnet", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _time_loop(fn, budget_s, lo=2, hi=20):
+    t0 = time.perf_counter(); fn(); warm = time.perf_counter() - t0
+    iters = max(lo, min(hi, int(budget_s / max(warm, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    return (time.perf_counter() - t0) / iters, iters
+
+
+def cpu_baseline(num_points, k, budget_s=7.0):
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
     from oracle import pointnet_oracle as po
-    # measured on the GPU box (2x EPYC 9575F, 256 hw threads): 8/16/32/64/128 threads give
-    # 119/135/127/104/63 grasps/s -> 16 threads is the best this op sequence reaches.
+    from oracle import crop_oracle as co
+    # measured on the GPU box (2x EPYC 9575F, 256 hw threads): 8/16/32/64/128 threads give 119/135/127/104/63
+    # grasps/s for this op sequence -> 16 threads is the best it reaches.
     cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
-    m = build_model(num_points, k, torch.device("cpu"))
-    sd = {kk: v.detach().clone() for kk, v in m.state_dict().items()}
+    cpu = torch.device("cpu")
+    ours = build_model(num_points, k, cpu)
+    sd = {kk: v.detach().clone() for kk, v in ours.state_dict().items()}
     b = 64
-    x = synth_clouds(b, num_points, 99, torch.device("cpu"))
-    with torch.no_grad():
-        t0 = time.perf_counter(); po.forward_torch(sd, x); warm = time.perf_counter() - t0
-        iters = max(2, min(20, int(budget_s / max(warm, 1e-3))))
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            po.forward_torch(sd, x)
-        dt = (time.perf_counter() - t0) / iters
-    return {"value": round(b / dt, 2), "unit": "grasps/s", "cores": cores, "kind": "port",
-            "sample": f"oracle.forward_torch (reference ATen op sequence, eval, fp32), B={b} N={num_points}, "
-                      f"{iters} iters, {cores} threads"}
+    x = synth_clouds(b, num_points, 99, cpu)
+    y = (torch.arange(b) % k).long()
+    ref = _load_reference_pointnet()
+    if ref is not None:
+        kind = "reference"
+        rm = ref.PointNetCls(num_points=num_points, input_chann=3, k=k)
+        rm.load_state_dict(sd)
+        rm.eval()
+
+        def fwd():
+            with torch.no_grad():
+                rm(x)
+        eval_dt, eval_it = _time_loop(fwd, budget_s)
+        rm.train()
+        opt = torch.optim.Adam(rm.parameters(), lr=0.005)
+
+        def step():
+            opt.zero_grad()
+            lp, _ = rm(x)
+            F.nll_loss(lp, y).backward()
+            opt.step()
+        train_dt, train_it = _time_loop(step, budget_s, lo=2, hi=10)
+        what = "unmodified reference PointNetCls (/root/reference/PointNetGPD/model/pointnet.py), eager"
+    else:
+        kind = "port"
+
+        def fwd():
+            with torch.no_grad():
+                po.forward_torch(sd, x)
+        eval_dt, eval_it = _time_loop(fwd, budget_s)
+        work = {n: v.clone().requires_grad_(v.is_floating_point() and "running_" not in n) for n, v in sd.items()}
+        opt = torch.optim.Adam([v for v in work.values() if v.requires_grad], lr=0.005)
+
+        def step():
+            opt.zero_grad()
+            lp, _ = po.forward_torch(work, x, training=True)
+            F.nll_loss(lp, y).backward()
+            opt.step()
+        train_dt, train_it = _time_loop(step, budget_s, lo=2, hi=10)
+        what = "oracle.forward_torch (the reference's ATen op sequence; /root/reference absent on this box)"
+    # crop: collect_pc (dataset.py:15-76) in a Python loop on one core, 20,000-point cloud
+    rng = np.random.default_rng(5)
+    pc = rng.uniform(-0.15, 0.15, size=(20000, 3))
+    grasps = np.zeros((64, 12))
+    grasps[:, 0:3] = pc[rng.integers(0, len(pc), 64)]
+    ax = rng.normal(size=(64, 3)); grasps[:, 3:6] = ax / np.linalg.norm(ax, axis=1, keepdims=True)
+    grasps[:, 6] = 0.085; grasps[:, 7] = rng.uniform(0, np.pi, 64)
+    crop_kind, collect = "port", co.collect_pc_train
+    try:
+        if os.path.exists(os.path.join(REF_ROOT, "PointNetGPD", "model", "dataset.py")):
+            import types
+            sys.modules.setdefault("open3d", types.ModuleType("open3d"))
+            os.environ.setdefault("PointNetGPD_FOLDER", REF_ROOT)
+            import importlib.util
+            spec = importlib.util.spec_from_file_location(
+                "_reference_dataset", os.path.join(REF_ROOT, "PointNetGPD", "model", "dataset.py"))
+            rd = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(rd)
+            ds = rd.BaseGraspDataset.__new__(rd.BaseGraspDataset)
+            ds.min_point_limit = 50
+            ds.projection = False
+            collect, crop_kind = (lambda g, p, t: ds.collect_pc(g, p, t)), "reference"
+    except Exception:
+        crop_kind, collect = "port", co.collect_pc_train
+    torch.set_num_threads(1)
+    eye = np.eye(4)
+    t0 = time.perf_counter()
+    n_crop = 0
+    while time.perf_counter() - t0 < 3.0:
+        collect(grasps[n_crop % 64], pc, eye)
+        n_crop += 1
+    crop_dt = (time.perf_counter() - t0) / n_crop
+    torch.set_num_threads(cores)
+    return {"value": round(b / eval_dt, 2), "unit": "grasps/s", "cores": cores, "kind": kind,
+            "sample": f"{what}, eval forward, fp32, B={b} N={num_points}, {eval_it} iters, {cores} threads",
+            "train_step": {"value": round(b / train_dt, 2), "unit": "grasps/s", "iters": train_it,
+                           "step": "fwd+nll_loss+bwd+Adam, same module and batch"},
+            "crop": {"value": round(1.0 / crop_dt, 1), "unit": "grasps/s", "cores": 1, "kind": crop_kind,
+                     "sample": f"collect_pc (dataset.py:15-76) Python loop, 20,000-point fp64 cloud, {n_crop} grasps"}}
+
+
+# ------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _self_spawn(args):
+    """``python bench.py --gpus N`` from a plain shell: launch the N ranks exactly as the driver would."""
+    import torch
+    one_gpu = os.environ.get("PNGPD_BENCH_DEBUG_ONE_GPU") == "1"
+    have = torch.cuda.device_count()
+    if have < args.gpus and not one_gpu:
+        print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible", file=sys.stderr)
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+class Timer:
+    """Blocks of exactly ``steps`` steps, each bracketed by barrier + synchronize and by HIP events on the launch
+    stream; repeated until ``min_seconds`` of timed work; max over ranks per block; median block reported."""
+
+    def __init__(self, dev, dist, min_seconds, max_blocks=400):
+        self.dev, self.dist, self.min_seconds, self.max_blocks = dev, dist, min_seconds, max_blocks
+
+    def sync_all(self):
+        import torch
+        torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+            torch.cuda.synchronize()
+
+    def run(self, step, steps, warmup):
+        import torch
+        out = None
+        for _ in range(warmup):
+            out = step()
+        walls, evs, total = [], [], 0.0
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        while True:
+            self.sync_all()
+            t0 = time.perf_counter()
+            e0.record()
+            for _ in range(steps):
+                out = step()
+            e1.record()
+            self.sync_all()
+            wall = time.perf_counter() - t0
+            ev = e0.elapsed_time(e1) * 1e-3
+            if self.dist is not None:
+                t = torch.tensor([wall, ev], device=self.dev, dtype=torch.float64)
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+                wall, ev = t[0].item(), t[1].item()
+            walls.append(wall); evs.append(ev); total += wall
+            if total >= self.min_seconds or len(walls) >= self.max_blocks:      # identical on every rank
+                break
+        return {"wall": statistics.median(walls), "events": statistics.median(evs), "blocks": len(walls),
+                "min_wall": min(walls), "out": out}
 
 
 def main():
@@ -88,86 +278,83 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--batch", type=int, default=1024, help="clouds per GPU")
     ap.add_argument("--num-points", type=int, default=1024)
     ap.add_argument("--classes", type=int, default=2)
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="timed work per leg (blocks of --steps repeat)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-train", action="store_true", help="skip the training-step leg")
-    ap.add_argument("--no-fast", action="store_true", help="skip the opt-in bf16x3 inference leg")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step legs")
+    ap.add_argument("--no-fast", action="store_true", help="skip the opt-in bf16x3 legs")
     ap.add_argument("--graph", action="store_true", help="also time the train step replayed from a HIP graph")
     args = ap.parse_args()
 
+    env_world = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if args.gpus > 1 and env_world == 0:
+        sys.exit(_self_spawn(args))
+
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = max(env_world, 1)
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; reporting the ranks that actually run",
+              file=sys.stderr)
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # Debug hook (not used by the driver): PNGPD_BENCH_DEBUG_ONE_GPU=1 runs every rank on cuda:0 over gloo so
-        # that the N>1 control flow can be exercised on a 1-GPU box.  Numbers from such a run are meaningless.
-        one_gpu = os.environ.get("PNGPD_BENCH_DEBUG_ONE_GPU") == "1"
-        if one_gpu:
-            local_rank = 0
+        # Debug switch (never set by the driver): every rank on cuda:0 over gloo, so that the N > 1 control flow runs
+        # on a 1-GPU box (tests/test_gpu_ddp.py).  Numbers from such a run are meaningless and say so.
+        if os.environ.get("PNGPD_BENCH_DEBUG_ONE_GPU") == "1":
+            local_rank, backend = 0, "gloo"
             torch.cuda.set_device(0)
             dist.init_process_group("gloo")
         else:
+            backend = "nccl"           # RCCL on ROCm
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    collective_ranks = 1
+    if dist is not None:
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)
+        collective_ranks = int(one.item())
+        world = dist.get_world_size()
 
     B, N, k = args.batch, args.num_points, args.classes
-    if os.environ.get("PNGPD_TRUNK_BLOCKS"):      # tuning experiments only
-        from pointnetgpd_amd import ops as _ops
-        _ops.set_option("trunk_target_blocks", int(os.environ["PNGPD_TRUNK_BLOCKS"]))
+    splits = int(os.environ.get("PNGPD_TRUNK_SPLITS", "0"))      # tuning experiments only (per-call argument)
     model = build_model(N, k, dev)
     x = synth_clouds(B, N, 1234 + rank, dev)
+    timer = Timer(dev, dist, args.min_seconds)
 
-    def sync_all():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
+    from pointnetgpd_amd import ops
+    from pointnetgpd_amd.model import pointnet as pn
+    if splits:
+        _orig = ops.trunk_fwd_infer
+        ops.trunk_fwd_infer = lambda *a, **kw: _orig(*a, **dict(kw, splits=splits))
+
+    def infer_step():
+        return model(x)[0]
 
     with torch.no_grad():
-        for _ in range(args.warmup):
-            model(x)
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out, _ = model(x)
-        sync_all()
-        dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+        inf = timer.run(infer_step, args.steps, args.warmup)
+    out = inf["out"]
     assert torch.isfinite(out).all()
+    dt = inf["wall"]
 
     # ---- opt-in fast path: the same forward with the trunk on split-bf16 (bf16x3) matrix-core products
     fast_res = None
     if not args.no_fast:
-        from pointnetgpd_amd.model import pointnet as pn
         pn.set_inference_precision("bf16x3")
         try:
             with torch.no_grad():
-                for _ in range(args.warmup):
-                    fout, _ = model(x)
-                sync_all()
-                t0 = time.perf_counter()
-                for _ in range(args.steps):
-                    fout, _ = model(x)
-                sync_all()
-                fdt = time.perf_counter() - t0
-            if dist is not None:
-                t = torch.tensor([fdt], device=dev, dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                fdt = t.item()
+                f = timer.run(infer_step, args.steps, args.warmup)
             fast_res = {"mode": "bf16x3 split products on v_mfma_f32_32x32x16_bf16, fp32 accumulate (opt-in)",
-                        "value": round(world * B * args.steps / fdt, 1), "unit": "grasps/s",
-                        "ms_per_step": round(fdt / args.steps * 1e3, 4),
-                        "max_abs_dlogp_vs_fp32": float((fout - out).abs().max().item())}
+                        "value": round(world * B * args.steps / f["wall"], 1), "unit": "grasps/s",
+                        "ms_per_step": round(f["wall"] / args.steps * 1e3, 4), "blocks": f["blocks"],
+                        "max_abs_dlogp_vs_fp32": float((f["out"] - out).abs().max().item())}
         finally:
             pn.set_inference_precision("fp32")
 
@@ -175,132 +362,101 @@ def main():
     train_res = None
     if not args.no_train:
         import torch.nn.functional as F
-        tmodel = build_model(N, k, dev).train()
-        opt = torch.optim.Adam(tmodel.parameters(), lr=0.005, fused=True)
-        y = (torch.arange(B, device=dev) % k).long()
-        params = [p for p in tmodel.parameters()]
+        from pointnetgpd_amd import train as _train
         tsteps = max(3, args.steps // 4)
+        twarm = max(2, args.warmup // 4)
 
-        averager = None
+        def make_leg(bt):
+            tmodel = build_model(N, k, dev).train()
+            opt = torch.optim.Adam(tmodel.parameters(), lr=0.005, fused=True)
+            xt = x[:bt].contiguous()
+            yt = (torch.arange(bt, device=dev) % k).long()
+            averager = None
+            if dist is not None:
+                from pointnetgpd_amd import ddp
+                averager = ddp.GradAverager(tmodel)     # broadcasts rank 0's replica once
+
+            def train_step():
+                if averager is not None:
+                    averager.sync_buffers()             # rank 0's BatchNorm running statistics, as in mains.py
+                opt.zero_grad(set_to_none=True)
+                lp, _ = tmodel(xt)
+                loss = F.nll_loss(lp, yt)
+                loss.backward()
+                if averager is not None:   # data-parallel: ONE flat RCCL all-reduce of the 1.6 M gradients
+                    averager.average_gradients()
+                opt.step()
+                return loss
+            return train_step
+
+        def leg_result(r, bt):
+            gps = world * bt * tsteps / r["wall"]
+            ex = gps * train_exec_flops_per_grasp(N) / 1e12
+            return {"value": round(gps, 1), "unit": "grasps/s", "batch_per_gpu": bt, "global_batch": bt * world,
+                    "steps": tsteps, "blocks": r["blocks"], "ms_per_step": round(r["wall"] / tsteps * 1e3, 3),
+                    "ms_per_step_events": round(r["events"] / tsteps * 1e3, 3),
+                    "tflops_executed": round(ex, 2),
+                    "tflops_executed_frac_of_fp32_mfma_peak": round(ex / (world * PEAK_FP32_MFMA_TFLOPS), 4),
+                    "tflops_effective_3x_fwd": round(gps * 3 * flops_per_grasp(N, k) / 1e12, 2)}
+
+        step = make_leg(B)
+        r = timer.run(step, tsteps, twarm)
+        assert torch.isfinite(r["out"]).all()
+        weak = leg_result(r, B)
+        train_res = dict(weak)
+        train_res["step"] = ("fwd(batch-stat BN)+nll_loss+bwd+Adam(fused)" +
+                             ("+one flat gradient all-reduce" if dist else ""))
+        train_res["tflops_note"] = ("tflops_executed = MFMA FLOPs the passes really issue (closed-form backward; "
+                                    "DESIGN.md §3); tflops_effective_3x_fwd = the usual 3x-forward accounting, "
+                                    "NOT a utilisation figure")
         if dist is not None:
-            from pointnetgpd_amd import ddp
-            averager = ddp.GradAverager(tmodel)     # broadcasts rank 0's replica once
-
-        def train_step():
-            if averager is not None:
-                averager.sync_buffers()             # rank 0's BatchNorm running statistics, as in mains.py
-            opt.zero_grad(set_to_none=True)
-            lp, _ = tmodel(x)
-            loss = F.nll_loss(lp, y)
-            loss.backward()
-            if averager is not None:   # data-parallel: ONE flat RCCL all-reduce of the 1.6 M gradients
-                averager.average_gradients()
-            opt.step()
-            return loss
-
-        for _ in range(max(2, args.warmup // 4)):
-            train_step()
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(tsteps):
-            loss = train_step()
-        sync_all()
-        tdt = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([tdt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            tdt = t.item()
-        assert torch.isfinite(loss).all()
-        final_eager_loss = loss.item()
-        graph_res = None
+            train_res["weak"] = weak
+            bs = max(2, B // world)
+            rs = timer.run(make_leg(bs), tsteps, twarm)
+            assert torch.isfinite(rs["out"]).all()
+            train_res["strong"] = leg_result(rs, bs)
         if args.graph and dist is None:
-            # the same step captured once as a HIP graph and replayed: removes the launch latency of the
-            # ~600 small kernels of the parameter-sized fp64 algebra between the passes
-            del loss                       # no autograd state of the eager leg may stay alive
-            gmodel = build_model(N, k, dev).train()
-            gopt = torch.optim.Adam(gmodel.parameters(), lr=0.005, capturable=True, fused=True)
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    gopt.zero_grad(set_to_none=True)
-                    lp, _ = gmodel(x); wl = F.nll_loss(lp, y); wl.backward(); gopt.step()
-                del lp, wl
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            gopt.zero_grad(set_to_none=True)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                lp, _ = gmodel(x)
-                gloss = F.nll_loss(lp, y)
-                gloss.backward()
-                gopt.step()
-            for _ in range(2):
-                g.replay()
-            sync_all()
-            t0 = time.perf_counter()
-            for _ in range(tsteps):
-                g.replay()
-            sync_all()
-            gdt = time.perf_counter() - t0
-            assert torch.isfinite(gloss).all()
-            graph_res = {"value": round(B * tsteps / gdt, 1), "ms_per_step": round(gdt / tsteps * 1e3, 3),
-                         "final_loss": round(gloss.item(), 5)}
-        fast_train = None
+            gstep = _train.GraphedTrainStep(build_model(N, k, dev), batch=B, num_points=N, lr=0.005)
+            yt = (torch.arange(B, device=dev) % k).long()
+            rg = timer.run(lambda: gstep(x, yt)[0], tsteps, 2)
+            train_res["hip_graph_replay"] = {"value": round(B * tsteps / rg["wall"], 1),
+                                             "ms_per_step": round(rg["wall"] / tsteps * 1e3, 3)}
         if not args.no_fast:
-            from pointnetgpd_amd import train as _train
             _train.set_train_precision("bf16x3")
             try:
-                for _ in range(2):
-                    train_step()
-                sync_all()
-                t0 = time.perf_counter()
-                for _ in range(tsteps):
-                    floss = train_step()
-                sync_all()
-                ftdt = time.perf_counter() - t0
+                rf = timer.run(step, tsteps, 2)
             finally:
                 _train.set_train_precision("fp32")
-            if dist is not None:
-                t = torch.tensor([ftdt], device=dev, dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                ftdt = t.item()
-            assert torch.isfinite(floss).all()
-            fast_train = {"mode": "forward main pass on bf16x3 split products (opt-in)",
-                          "value": round(world * B * tsteps / ftdt, 1), "ms_per_step": round(ftdt / tsteps * 1e3, 3)}
-        train_res = {"value": round(world * B * tsteps / tdt, 1), "unit": "grasps/s", "steps": tsteps,
-                     "ms_per_step": round(tdt / tsteps * 1e3, 3),
-                     "step": "fwd(batch-stat BN)+nll_loss+bwd+Adam(fused)" + ("+RCCL grad all-reduce" if dist else ""),
-                     "tflops_effective_3x_fwd": round(world * B * tsteps / tdt * 3 * flops_per_grasp(N, k) / 1e12, 2)}
-        if graph_res is not None:
-            train_res["hip_graph_replay"] = graph_res
-        if fast_train is not None:
-            train_res["fast_bf16x3"] = fast_train
+            assert torch.isfinite(rf["out"]).all()
+            train_res["fast_bf16x3"] = {"mode": "forward main pass on bf16x3 split products (opt-in)",
+                                        "value": round(world * B * tsteps / rf["wall"], 1),
+                                        "ms_per_step": round(rf["wall"] / tsteps * 1e3, 3)}
 
     # ---- dominant kernel (fused trunk) timed live with events on the launch stream
-    from pointnetgpd_amd import ops
-    from pointnetgpd_amd.model import pointnet as pn
     wts = pn._trunk_infer_weights(model.feat.stn, dev)
-    reps = max(10, args.steps)
+    reps = max(20, args.steps)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     with torch.no_grad():
-        ops.trunk_fwd_infer(x, None, *wts, relu_last=True)
+        for _ in range(3):
+            ops.trunk_fwd_infer(x, None, *wts, relu_last=True)
         torch.cuda.synchronize()
         e0.record()
         for _ in range(reps):
             ops.trunk_fwd_infer(x, None, *wts, relu_last=True)
         e1.record()
         torch.cuda.synchronize()
-    trunk_ms = e0.elapsed_time(e1) / reps
+    trunk_ms = e0.elapsed_time(e1) / reps       # includes the 5 us partial-max combine when S > 1
     trunk_flops = B * N * FLOP_PER_POINT_TRUNK
     achieved = trunk_flops / (trunk_ms * 1e-3) / 1e12
 
-    traffic = None
+    traffic, traffic_src = None, None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_trunk.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "pmc_trunk.json")) as f:
             pmc = json.load(f)
-        if B == 1024 and N == 1024:
+        if B == pmc.get("B") and N == pmc.get("N"):
             traffic = pmc["traffic_bytes_per_launch"]
+            traffic_src = (f"STORED rocprofv3 PMC figure (not measured in this run): profiles/pmc_trunk.json, "
+                           f"taken at commit {pmc.get('commit', '?')}; 2*FETCH_SIZE + WRITE_SIZE, separate passes")
     except Exception:
         pass
     if rank == 0:
@@ -309,23 +465,28 @@ def main():
         res = {
             "metric": "grasps/sec (train+infer) at B=1024,N=1024",
             "value_is": "inference leg (eval forward, exact fp32); the training-step leg is under 'train'",
-            "value": round(value, 1), "unit": "grasps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "value": round(value, 1), "unit": "grasps/s", "n_gpus": world, "collective_ranks": collective_ranks,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "ms_per_step_events": round(inf["events"] / args.steps * 1e3, 4),
+            "timing": f"median of {inf['blocks']} blocks of {args.steps} steps (barrier+synchronize on both sides, "
+                      f"max over ranks; HIP events agree: ms_per_step_events)",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 2-class PointNetCls eval forward, fp32, "
                                    "synthetic in-gripper clouds resident in HBM",
                        "batch_per_gpu": B, "num_points": N, "classes": k, "mode": "infer",
-                       "sharding": f"batch x{world}, no collective"},
+                       "sharding": f"batch x{world}, no collective", "backend": backend},
             "tflops_effective": round(value * flops_per_grasp(N, k) / 1e12, 2),
             "hbm_algorithmic_gbs": round(value / world * alg_bytes / B / 1e9, 3),
             "roofline": {"bound": "mfma", "kernel": "trunk_infer_kernel", "achieved": round(achieved, 2),
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                         "traffic_unit": "HBM bytes/launch (rocprofv3 PMC, profiles/r01_pmc_trunk.json)",
-                         "avg_launch_ms": round(trunk_ms, 4),
-                         "flops_per_launch": trunk_flops},
+                         "traffic_unit": "HBM bytes/launch", "traffic_source": traffic_src,
+                         "avg_launch_ms": round(trunk_ms, 4), "flops_per_launch": trunk_flops,
+                         "hbm_frac_algorithmic": round(value / world * alg_bytes / B / 1e9 / HBM_PEAK_GBS, 6)},
         }
+        if backend == "gloo":
+            res["debug_one_gpu"] = "all ranks on cuda:0 over gloo: control-flow test only, numbers are meaningless"
         if fast_res is not None:
             res["infer_fast_bf16x3"] = fast_res
         if train_res is not None:
@@ -334,6 +495,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(N, k)
         print(json.dumps(res), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

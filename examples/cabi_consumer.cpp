@@ -82,13 +82,14 @@ int main(int argc, char **argv) {
     }
     HIP_OK(hipMalloc((void **)&dpool, (size_t)B * 1024 * sizeof(float)));
     HIP_OK(hipMalloc((void **)&dout, (size_t)B * 9 * sizeof(float)));
-    const size_t wsb = pngpd_trunk_workspace_bytes(B, N);
+    const int splits = pngpd_trunk_infer_splits(B, N, 0);
+    const size_t wsb = pngpd_trunk_workspace_bytes(B, N, splits);
     void *ws = nullptr;
     HIP_OK(hipMalloc(&ws, wsb ? wsb : 4));
     // a too-small workspace must be refused, not overrun
-    if (wsb > 4 && pngpd_trunk_fwd_infer(dx, B, N, dT, dWf[0], dbf[0], dWf[1], dbf[1], dWf[2], dbf[2], 0, dpool, ws, 4, st) !=
+    if (wsb > 4 && pngpd_trunk_fwd_infer(dx, B, N, dT, dWf[0], dbf[0], dWf[1], dbf[1], dWf[2], dbf[2], 0, splits, dpool, ws, 4, st) !=
                        PNGPD_ERR_WORKSPACE) { std::fprintf(stderr, "workspace check missing\n"); return 4; }
-    PN_OK(pngpd_trunk_fwd_infer(dx, B, N, dT, dWf[0], dbf[0], dWf[1], dbf[1], dWf[2], dbf[2], 0, dpool, ws, wsb, st));
+    PN_OK(pngpd_trunk_fwd_infer(dx, B, N, dT, dWf[0], dbf[0], dWf[1], dbf[1], dWf[2], dbf[2], 0, splits, dpool, ws, wsb, st));
     PN_OK(pngpd_fc_fwd(dpool, B, 1024, dWfc, dbfc, 9, PNGPD_EPI_ADD_IDEN3, dout, st));
     HIP_OK(hipStreamSynchronize(st));
     std::vector<float> pool((size_t)B * 1024), out((size_t)B * 9);

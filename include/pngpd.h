@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PNGPD_ABI_VERSION 1
+#define PNGPD_ABI_VERSION 2
 
 enum {
     PNGPD_OK = 0,
@@ -53,9 +53,6 @@ enum {
 
 int pngpd_abi_version(void);
 const char *pngpd_strerror(int code);
-/* Tuning knobs for experiments ("trunk_target_blocks": workgroups the trunk launch aims for). */
-int pngpd_set_option(const char *name, int value);
-
 /*
  * Fold an eval-mode BatchNorm1d into the preceding 1x1 Conv1d / Linear and lay the
  * weight out for the kernels.  Replaces the eval-mode `self.bnX(self.convX(x))`
@@ -81,12 +78,16 @@ int pngpd_fold_conv_bn(const float *W, const float *b, const float *gamma, const
  *   w1 (64,3) rowmajor folded, b1 (64);  w2p (128,64) MFMA_B folded, b2 (128);
  *   w3p (1024,128) MFMA_B folded, b3 (1024)
  *   out_pool (B,1024) fp32
- *   workspace: pngpd_trunk_workspace_bytes(B,N) bytes of device scratch.
+ *   splits: workgroups per cloud (each takes a range of 64-point tiles; the partial maxima are combined by a
+ *           second tiny launch); <= 0 selects pngpd_trunk_infer_splits(B, N, 0).  An explicit argument — the
+ *           library holds no process-global tuning state.
+ *   workspace: pngpd_trunk_workspace_bytes(B, N, splits) bytes of device scratch (0 when one workgroup per cloud).
  */
-size_t pngpd_trunk_workspace_bytes(int B, int N);
+int pngpd_trunk_infer_splits(int B, int N, int target_blocks);   /* target_blocks <= 0: the default (2048) */
+size_t pngpd_trunk_workspace_bytes(int B, int N, int splits);
 int pngpd_trunk_fwd_infer(const float *x, int B, int N, const float *trans,
                           const float *w1, const float *b1, const float *w2p, const float *b2,
-                          const float *w3p, const float *b3, int relu_last,
+                          const float *w3p, const float *b3, int relu_last, int splits,
                           float *out_pool, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
@@ -106,17 +107,20 @@ int pngpd_fc_fwd(const float *in, int B, int K, const float *W, const float *bia
  * weights (2*C*K halfwords each).
  */
 int pngpd_split_pack_bf16(const float *W, int C, int K, void *out, void *stream);
+/* splits as above but over 128-point tiles (pngpd_trunk_infer_x3_splits; default target 1024 workgroups);
+ * workspace >= B*S*1024*4 bytes when S > 1. */
+int pngpd_trunk_infer_x3_splits(int B, int N, int target_blocks);
 int pngpd_trunk_fwd_infer_x3(const float *x, int B, int N, const float *trans,
                              const float *w1, const float *b1, const void *w2x, const float *b2,
-                             const void *w3x, const float *b3, int relu_last,
+                             const void *w3x, const float *b3, int relu_last, int splits,
                              float *out_pool, void *workspace, size_t workspace_bytes, void *stream);
 /* OPT-IN bf16x3 variant of pass C (pngpd_trunk_fwd_train below): identical outputs/semantics, GEMM layers on
  * split-bf16 products.  w2x = split_pack_bf16(raw W2), w3sx = split_pack_bf16(sign(gamma3)*W3).  S = number of
- * workgroups per cloud (1 <= S <= ceil(N/128)); pmax/parg (B*S,1024), psum (B*S,2,1024).                    */
+ * workgroups per cloud (1 <= S <= ceil(N/128)); pmax/parg (B*S,1024), psum (B*S,2,1024), psh (B*S*2,128).   */
 int pngpd_trunk_fwd_train_x3(const float *x, int B, int N, const float *trans,
                              const float *w1, const float *b1, const float *s1c, const float *t1c,
                              const void *w2x, const float *s2c, const float *t2c, const void *w3sx, int S,
-                             float *pmax, int *parg, float *psum, void *stream);
+                             float *pmax, int *parg, float *psum, float *psh, void *stream);
 
 /* =======================================================================================
  * Training path (batch-statistics BatchNorm, backward).  The trunk's forward/backward is a
@@ -126,11 +130,13 @@ int pngpd_trunk_fwd_train_x3(const float *x, int B, int N, const float *trans,
  * Common arguments: x (B,3,N); trans (B,3,3) or NULL; layer-1/2 per-channel forms
  *   h1 = relu((W1 x' + b1)*s1c + t1c),  h2 = relu((W2 h1)*s2c + t2c)
  * w1 (64,3) raw rowmajor, b1/s1c/t1c (64); w2p (128,64) raw MFMA_B packed, s2c/t2c (128).
- * "blk" below = B * pngpd_trunk_train_splits(B,N) workgroups; partial buffers are reduced
- * by the caller (deterministic, no atomics).
+ * "blk" below = B * S workgroups: S (workgroups per cloud, 1 <= S <= ceil(N/64)) is an explicit argument of
+ * every pass — there is no process-global tuning state; pngpd_trunk_splits() only suggests a value, and
+ * the caller sizes the partial buffers with the S it passes.  Partial buffers are reduced by
+ * pngpd_reduce_partials* (deterministic, no atomics).
  * ======================================================================================= */
-int pngpd_train_set_target_blocks(int blocks);
-int pngpd_trunk_train_splits(int B, int N);
+/* S that gives about target_blocks workgroups (<= 0: the default, 1024 = two resident rounds of 2 per CU). */
+int pngpd_trunk_splits(int B, int N, int target_blocks);
 
 /* pass A: per-cloud fp64 moments  mom (B,9) = {sx,sy,sz,sxx,sxy,sxz,syy,syz,szz}  (BN1 stats in closed form) */
 int pngpd_cloud_moments(const float *x, int B, int N, double *mom, void *stream);
@@ -138,23 +144,16 @@ int pngpd_cloud_moments(const float *x, int B, int N, double *mom, void *stream)
 /* pass B: BN2 statistics.  part (blk,128,2) = per-workgroup sum / sum-of-squares of z2 = W2 h1 */
 int pngpd_trunk_bn2_stats(const float *x, int B, int N, const float *trans,
                           const float *w1, const float *b1, const float *s1c, const float *t1c,
-                          const float *w2p, float *part, void *stream);
+                          const float *w2p, int S, float *part, void *stream);
 
 /* pass C: layer 3 with sign-folded weights w3sp = MFMA_B(sign(gamma3) * W3):
  *   pmax/parg (blk,1024): max / argmax over the workgroup's points of z3s = w3s . h2
- *   psum (blk,2,1024):    sum / sum of squares of z3s over valid points                     */
+ *   psum (blk,2,1024):    sum / sum of squares of z3s over valid points
+ *   psh  (blk,128):       sum of h2 over valid points (its mean enters pass D's cvec and the closed-form dW3) */
 int pngpd_trunk_fwd_train(const float *x, int B, int N, const float *trans,
                           const float *w1, const float *b1, const float *s1c, const float *t1c,
-                          const float *w2p, const float *s2c, const float *t2c, const float *w3sp,
-                          float *pmax, int *parg, float *psum, void *stream);
-
-/* second moments of the hidden activations (needed by the closed-form dW3 / dW2), per workgroup; S workgroups
- * share a cloud's tiles (1 <= S <= ceil(N/64); S > 1 fills the chip at small B):
- *   ps2 (B*S,128,128) = sum_n h2 h2^T, ps1 (B*S,64,64) (reserved, zeros), psh (B*S,192) = [sum h2 | 0] */
-int pngpd_trunk_h_moments(const float *x, int B, int N, const float *trans,
-                          const float *w1, const float *b1, const float *s1c, const float *t1c,
-                          const float *w2p, const float *s2c, const float *t2c, int S,
-                          float *ps2, float *ps1, float *psh, void *stream);
+                          const float *w2p, const float *s2c, const float *t2c, const float *w3sp, int S,
+                          float *pmax, int *parg, float *psum, float *psh, void *stream);
 
 /* sparse (arg-extremum) term of dW3:  Gp (ceil(B/clouds_per_range),1024,128),
  *   Gp[r][c][:] = sum_{b in range r} coef[b][c] * h2[b][:, idx[b][c]]                         */
@@ -163,24 +162,29 @@ int pngpd_trunk_bwd_gather(const float *x, int B, int N, const float *trans,
                            const float *w2p, const float *s2c, const float *t2c,
                            const int *idx, const float *coef, int clouds_per_range, float *Gp, void *stream);
 
-/* backward pass D: g2buf (B,N,128) = dL/d(bn2 out);  pa (blk,128,2) = sum g2, sum g2*zhat2.
- *   zhat2 = z2*is2 + nm2;  Ap = MFMA_B(A), A (128,128)
- *   symmetric; dh2 = cvec - h2 A + sum_{c: idx[b][c]==n} coef[b][c] W3[c]; w3 (1024,128) raw.  */
+/* backward pass D: g2 = dL/d(bn2 out) per point, handed to pass E in g2t (pngpd_trunk_g2t_bytes(B,N) bytes; an
+ *   opaque lane-major tile layout shared by the two kernels: [(b*T+tile)][8][256] float4, value 4*q+e of thread t
+ *   = point block (4q+e)>>4, MFMA register (4q+e)&15, channel 32*(t>>6) + (t&31));
+ *   pa (blk,128,2) = sum g2, sum g2*zhat2;  ps2 (blk,12,16,64) = raw accumulators of 10 of the 16 32x32 blocks of
+ *   sum_points h2 h2^T (slot 3w+q of wave w: blocks (w,w), (w,(w+1)%4), (w,w+2 | w<2); the rest by symmetry).
+ *   zhat2 = z2*is2 + nm2;  Ap = MFMA_B(A), A (128,128) symmetric;
+ *   dh2 = cvec - h2 A + sum_{c: idx[b][c]==n} coef[b][c] W3[c]; w3 (1024,128) raw row-major.  */
+size_t pngpd_trunk_g2t_bytes(int B, int N);
 int pngpd_trunk_bwd_d(const float *x, int B, int N, const float *trans,
                       const float *w1, const float *b1, const float *s1c, const float *t1c,
                       const float *w2p, const float *s2c, const float *t2c,
                       const float *is2, const float *nm2, const float *Ap, const float *cvec,
-                      const float *w3, const int *idx, const float *coef,
-                      float *g2buf, float *pa, void *stream);
+                      const float *w3, const int *idx, const float *coef, int S,
+                      float *g2t, float *pa, float *ps2, void *stream);
 
 /* backward pass E: dz2 = dsc2*(g2 - a1m - zhat2*a2m); dh1 = W2^T dz2 (w2tp = MFMA_B(W2^T as (64,128)));
  *   g1 = dh1*(h1>0); pc (blk,64,2) = sum g1, sum g1*zhat1; pR (blk,64,3) = sum_points g1 x^T (original x);
- *   pW2 (blk,128,64) = sum_points dz2 h1^T — the workgroup's share of dL/dW2                          */
+ *   pW2 (blk,128,64) = sum_points dz2 h1^T — the workgroup's share of dL/dW2.  S as passed to pass D.       */
 int pngpd_trunk_bwd_e(const float *x, int B, int N, const float *trans,
                       const float *w1, const float *b1, const float *s1c, const float *t1c,
                       const float *w2p, const float *is1, const float *nm1, const float *is2, const float *nm2,
                       const float *a1m, const float *a2m, const float *dsc2, const float *w2tp,
-                      const float *g2buf, float *pc, float *pR, float *pW2, void *stream);
+                      const float *g2t, int S, float *pc, float *pR, float *pW2, void *stream);
 
 /* BatchNorm1d over the batch dimension for the FC stacks (pointnet.py:35-36,191-192, train mode),
  * optional fused ReLU; biased variance returned (the caller updates running stats). */
@@ -216,10 +220,18 @@ int pngpd_bn3_bwd_prep(const float *dp, const float *pooled, const float *zhat, 
                        double *m12, void *stream);
 /* out (outer,n) f64 = sum over r of in (outer,R,n) f32 — deterministic reduction of per-workgroup partials */
 int pngpd_reduce_partials(const float *in, int outer, int R, int n, double *out, void *stream);
-/* dW3 (1024,128); Ap = MFMA_B(A) (128x128), cvec (128): the operands of pngpd_trunk_bwd_d */
-int pngpd_dw3_finalize(const double *G, const double *S2, const double *sh, int B, int N, const float *w3,
+/* up to four such reductions in one launch (in_i == NULL: slot unused) */
+int pngpd_reduce_partials4(const float *in0, int outer0, int R0, int n0, double *out0,
+                           const float *in1, int outer1, int R1, int n1, double *out1,
+                           const float *in2, int outer2, int R2, int n2, double *out2,
+                           const float *in3, int outer3, int R3, int n3, double *out3, void *stream);
+/* the operands of pngpd_trunk_bwd_d: Ap = MFMA_B(A) (128x128), cvec (128); sh f64 (128) = sum of h2 (pass C) */
+int pngpd_a_cvec_finalize(const double *sh, int B, int N, const float *w3, const float *g3, const double *stats3,
+                          const double *m12, float eps, float *Ap, float *cvec, void *stream);
+/* dW3 (1024,128) from G f64 (1024,128), S2c f64 (12,16,64) = the reduced ps2 blocks of pass D, sh f64 (128) */
+int pngpd_dw3_finalize(const double *G, const double *S2c, const double *sh, int B, int N, const float *w3,
                        const float *g3, const double *stats3, const double *m12, float eps, float *dW3,
-                       float *Ap, float *cvec, void *stream);
+                       void *stream);
 /* a12 f64 (128,2) = sum g2, sum g2*zhat2 -> dg2, dbe2 (128); evec (3,128) = a1/M, a2/M, g2/sig2: the
  * operands of pngpd_trunk_bwd_e */
 int pngpd_bwd_e_prep(const double *a12, int B, int N, const float *g2, const double *stats2, float eps,

@@ -153,12 +153,26 @@ def _bn_torch(F, z, sd, prefix, training):
                         training, BN_MOMENTUM, BN_EPS)
 
 
+CONV_AS_MATMUL = False   # see _conv1x1_torch
+
+
+def _conv1x1_torch(F, x, w, b):
+    """Conv1d(kernel_size=1) (pointnet.py:12-14).  Default: the reference's own ATen op (F.conv1d).  With
+    CONV_AS_MATMUL the same contraction is written as ``W[:, :, 0] @ x + b`` — used ONLY when a test runs this
+    oracle in fp64 on the GPU, where the conv backend (MIOpen) has no double kernels; the arithmetic
+    (sum over input channels, then bias) is identical."""
+    if CONV_AS_MATMUL:
+        import torch
+        return torch.matmul(w[:, :, 0], x) + b[None, :, None]
+    return F.conv1d(x, w, b)
+
+
 def _trunk_torch(F, x, sd, prefix, training, relu_last):
-    x = F.relu(_bn_torch(F, F.conv1d(x, sd[prefix + "conv1.weight"], sd[prefix + "conv1.bias"]),
+    x = F.relu(_bn_torch(F, _conv1x1_torch(F, x, sd[prefix + "conv1.weight"], sd[prefix + "conv1.bias"]),
                          sd, prefix + "bn1", training))
-    x = F.relu(_bn_torch(F, F.conv1d(x, sd[prefix + "conv2.weight"], sd[prefix + "conv2.bias"]),
+    x = F.relu(_bn_torch(F, _conv1x1_torch(F, x, sd[prefix + "conv2.weight"], sd[prefix + "conv2.bias"]),
                          sd, prefix + "bn2", training))
-    x = _bn_torch(F, F.conv1d(x, sd[prefix + "conv3.weight"], sd[prefix + "conv3.bias"]),
+    x = _bn_torch(F, _conv1x1_torch(F, x, sd[prefix + "conv3.weight"], sd[prefix + "conv3.bias"]),
                   sd, prefix + "bn3", training)
     if relu_last:
         x = F.relu(x)

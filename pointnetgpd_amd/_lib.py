@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PNGPD_LIB") or os.path.join(_HERE, "libpngpd.so")   # PNGPD_LIB: A/B builds only
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 _load_error = None
@@ -21,31 +21,34 @@ c_void = ctypes.c_void_p
 SIGNATURES = {
     "pngpd_abi_version": (ctypes.c_int, []),
     "pngpd_strerror": (ctypes.c_char_p, [ctypes.c_int]),
-    "pngpd_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     "pngpd_fold_conv_bn": (ctypes.c_int, [c_f32p] * 6 + [ctypes.c_float, ctypes.c_int, ctypes.c_int,
                                                        ctypes.c_int, c_f32p, c_f32p, c_void]),
-    "pngpd_trunk_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "pngpd_trunk_infer_splits": (ctypes.c_int, [ctypes.c_int] * 3),
+    "pngpd_trunk_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
     "pngpd_trunk_fwd_infer": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, c_f32p] + [c_f32p] * 6 +
-                              [ctypes.c_int, c_f32p, c_void, ctypes.c_size_t, c_void]),
+                              [ctypes.c_int, ctypes.c_int, c_f32p, c_void, ctypes.c_size_t, c_void]),
     "pngpd_fc_fwd": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, ctypes.c_int,
                                     ctypes.c_int, c_f32p, c_void]),
     "pngpd_split_pack_bf16": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, c_void]),
+    "pngpd_trunk_infer_x3_splits": (ctypes.c_int, [ctypes.c_int] * 3),
     "pngpd_trunk_fwd_infer_x3": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, c_f32p] + [c_f32p] * 6 +
-                                 [ctypes.c_int, c_f32p, c_void, ctypes.c_size_t, c_void]),
+                                 [ctypes.c_int, ctypes.c_int, c_f32p, c_void, ctypes.c_size_t, c_void]),
     "pngpd_trunk_fwd_train_x3": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 9 +
-                                 [ctypes.c_int, c_f32p, c_f32p, c_f32p, c_void]),
-    # ---- training passes
-    "pngpd_train_set_target_blocks": (ctypes.c_int, [ctypes.c_int]),
-    "pngpd_trunk_train_splits": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+                                 [ctypes.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_void]),
+    # ---- training passes (S = workgroups per cloud is an explicit argument everywhere)
+    "pngpd_trunk_splits": (ctypes.c_int, [ctypes.c_int] * 3),
+    "pngpd_trunk_g2t_bytes": (ctypes.c_size_t, [ctypes.c_int] * 2),
     "pngpd_cloud_moments": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, c_f32p, c_void]),
-    "pngpd_trunk_bn2_stats": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 7 + [c_void]),
-    "pngpd_trunk_fwd_train": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 12 + [c_void]),
-    "pngpd_trunk_h_moments": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 8 + [ctypes.c_int] +
-                              [c_f32p] * 3 + [c_void]),
+    "pngpd_trunk_bn2_stats": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 6 + [ctypes.c_int,
+                                                                                                  c_f32p, c_void]),
+    "pngpd_trunk_fwd_train": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 9 + [ctypes.c_int] +
+                              [c_f32p] * 4 + [c_void]),
     "pngpd_trunk_bwd_gather": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 10 +
                                [ctypes.c_int, c_f32p, c_void]),
-    "pngpd_trunk_bwd_d": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 17 + [c_void]),
-    "pngpd_trunk_bwd_e": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 18 + [c_void]),
+    "pngpd_trunk_bwd_d": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 15 + [ctypes.c_int] +
+                          [c_f32p] * 3 + [c_void]),
+    "pngpd_trunk_bwd_e": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 15 + [ctypes.c_int] +
+                          [c_f32p] * 3 + [c_void]),
     "pngpd_bn1d_fwd_train": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, ctypes.c_float,
                                             ctypes.c_int, c_f32p, c_f32p, c_f32p, c_void]),
     "pngpd_bn1d_bwd": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, c_f32p,
@@ -63,8 +66,11 @@ SIGNATURES = {
     "pngpd_bn3_bwd_prep": (ctypes.c_int, [c_void, c_void, c_void, ctypes.c_int, ctypes.c_int, c_void, c_void,
                                           ctypes.c_float, ctypes.c_int] + [c_void] * 4 + [c_void]),
     "pngpd_reduce_partials": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void, c_void]),
+    "pngpd_reduce_partials4": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void] * 4 + [c_void]),
+    "pngpd_a_cvec_finalize": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int] + [c_void] * 4 + [ctypes.c_float] +
+                              [c_void] * 2 + [c_void]),
     "pngpd_dw3_finalize": (ctypes.c_int, [c_void, c_void, c_void, ctypes.c_int, ctypes.c_int] + [c_void] * 4 +
-                           [ctypes.c_float] + [c_void] * 3 + [c_void]),
+                           [ctypes.c_float] + [c_void] + [c_void]),
     "pngpd_bwd_e_prep": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, c_void, ctypes.c_float,
                                         c_void, c_void, c_void, c_void]),
     "pngpd_dw1_finalize": (ctypes.c_int, [c_void, c_void, c_void, ctypes.c_int, ctypes.c_int] + [c_void] * 5 +

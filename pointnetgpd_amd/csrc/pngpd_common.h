@@ -21,6 +21,22 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 
 __device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+// Dynamic LDS above 48 KB needs a per-kernel opt-in.  Idempotent and checked on every call: no "already set"
+// flag to race on, and a failure is reported instead of surfacing later as a launch error.
+static inline int pngpd_allow_lds(const void *fn, size_t bytes) {
+    if (bytes <= 48 * 1024) return PNGPD_OK;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return e == hipSuccess ? PNGPD_OK : (PNGPD_ERR_HIP + (int)e);
+}
+
+// Workgroups per cloud for a launch that aims at `target` workgroups: ceil(target / B) clamped to [1, T].
+static inline int pngpd_splits_for(int B, int T, int target) {
+    int S = (target + B - 1) / B;
+    if (S < 1) S = 1;
+    if (S > T) S = T;
+    return S;
+}
+
 static inline int pngpd_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PNGPD_OK : (PNGPD_ERR_HIP + (int)e);

@@ -254,13 +254,13 @@ int pngpd_crop_resample(const void *cloud, int cloud_is_f64, const double *frame
     const size_t lds = (size_t)max_keep * sizeof(int);
     if (lds > 150 * 1024) return PNGPD_ERR_UNSUPPORTED;
     if (cloud_is_f64) {
-        if (lds > 48 * 1024)
-            hipFuncSetAttribute((const void *)crop_resample_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const int st = pngpd_allow_lds((const void *)crop_resample_kernel<true>, lds);
+        if (st != PNGPD_OK) return st;
         hipLaunchKernelGGL(crop_resample_kernel<true>, dim3(G), dim3(256), lds, (hipStream_t)stream,
                            cloud, frames, counts, idx, max_keep, N, mode, min_points, seed, sel, out, valid);
     } else {
-        if (lds > 48 * 1024)
-            hipFuncSetAttribute((const void *)crop_resample_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const int st = pngpd_allow_lds((const void *)crop_resample_kernel<false>, lds);
+        if (st != PNGPD_OK) return st;
         hipLaunchKernelGGL(crop_resample_kernel<false>, dim3(G), dim3(256), lds, (hipStream_t)stream,
                            cloud, frames, counts, idx, max_keep, N, mode, min_points, seed, sel, out, valid);
     }

@@ -19,14 +19,9 @@ struct TrainChan {
     const float *w2p, *s2c, *t2c;       // layer 2: raw MFMA_B packed (128,64), scale, shift
 };
 
-static int g_train_target_blocks = 2048;
-
-static int train_splits(int B, int T) {
-    int S = (g_train_target_blocks + B - 1) / B;
-    if (S < 1) S = 1;
-    if (S > T) S = T;
-    return S;
-}
+// Workgroups per cloud: the caller passes S explicitly (pngpd_trunk_splits() suggests one); nothing here is
+// process-global, so buffer sizes computed by the caller and the launch always agree.
+static inline bool splits_ok(int S, int T) { return S >= 1 && S <= T; }
 
 // ---------------------------------------------------------------------------------------
 // pass A: per-cloud input moments in fp64:  mom[b] = {sx,sy,sz, sxx,sxy,sxz, syy,syz,szz}
@@ -113,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void trunk_bn2_stats_kernel(
 __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
     const float *__restrict__ x, int N, const float *__restrict__ trans, TrainChan P,
     const float *__restrict__ w3sp, int T, int S,
-    float *__restrict__ pmax, int *__restrict__ parg, float *__restrict__ psum) {
+    float *__restrict__ pmax, int *__restrict__ parg, float *__restrict__ psum, float *__restrict__ psh) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *h1 = smem;
     float *h2 = h1 + TP * H1S;
@@ -135,11 +130,14 @@ __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
 #pragma unroll
         for (int i = 0; i < 9; ++i) tm[i] = trans[(size_t)b * 9 + i];
     }
+    float hsum = 0.f;   // sum over this workgroup's valid points of h2[.][wave*32 + j] (rows of this half-wave)
     for (int tile = t0; tile < t1; ++tile) {
         stage_points(xb, N, tile, has_t, tm, xs, nullptr, L.tid);
         __syncthreads();
         layer1_tile(xs, P.w1, P.b1, P.s1c, P.t1c, h1, L);
         __syncthreads();
+        const int nbase = tile * TP;
+        const bool full = nbase + TP <= N;
         {
             f32x16 a0, a1;
             const int cb = L.wave;
@@ -148,13 +146,15 @@ __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mfma_row(r, L.lane);
-                h2[row * H2S + cb * 32 + L.j] = fmaxf(fmaf(a0[r], sc, sh), 0.f);
-                h2[(32 + row) * H2S + cb * 32 + L.j] = fmaxf(fmaf(a1[r], sc, sh), 0.f);
+                const float v0 = fmaxf(fmaf(a0[r], sc, sh), 0.f), v1 = fmaxf(fmaf(a1[r], sc, sh), 0.f);
+                h2[row * H2S + cb * 32 + L.j] = v0;
+                h2[(32 + row) * H2S + cb * 32 + L.j] = v1;
+                // column sums of h2 (the mean of h2 enters cvec of pass D and the closed-form dW3)
+                hsum += (full || nbase + row < N) ? v0 : 0.f;
+                hsum += (full || nbase + 32 + row < N) ? v1 : 0.f;
             }
         }
         __syncthreads();
-        const int nbase = tile * TP;
-        const bool full = nbase + TP <= N;
         // layer-3 weight fragments double-buffered in registers (see trunk_infer_kernel)
         auto reduce_block = [&](int cb, const f32x16 &a0, const f32x16 &a1) {
             // max / argmax over this lane's 32 rows (ascending row order, strict >: first wins)
@@ -197,7 +197,9 @@ __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
             reduce_block(cbB, a0, a1);
         }
     }
+    hsum += __shfl_xor(hsum, 32);
     if (L.h == 0) {
+        psh[(size_t)blockIdx.x * 128 + L.wave * 32 + L.j] = hsum;
 #pragma unroll
         for (int ci = 0; ci < 8; ++ci) {
             const int c = (L.wave + 4 * ci) * 32 + L.j;
@@ -206,92 +208,6 @@ __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
             psum[((size_t)blockIdx.x * 2) * 1024 + c] = ss[c];
             psum[((size_t)blockIdx.x * 2 + 1) * 1024 + c] = sq[c];
         }
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// h-moments pass: S2 = sum h2 h2^T (128x128) and the column sums of h2 (ps1 / psh[128:] are kept in the
-// interface for layout stability and written as zeros: dW2 is contracted directly in pass E).
-// One workgroup per cloud (all its tiles).  Contraction over points on the MFMA:
-//   D[i][j] += A[i][k=point] * B[k=point][j]  with A = B = the LDS tile read column-wise.
-//   ps2 [blk][128][128]  ps1 [blk][64][64]  psh [blk][128+64]
-// ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void trunk_h_moments_kernel(
-    const float *__restrict__ x, int N, const float *__restrict__ trans, TrainChan P, int T, int S,
-    float *__restrict__ ps2, float *__restrict__ ps1, float *__restrict__ psh) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *h1 = smem;
-    float *h2 = h1 + TP * H1S;
-    float *xs = h2 + TP * H2S;
-    const Lane L;
-    const int blk = blockIdx.x, b = blk / S;   // S workgroups per cloud (small batches), each a range of tiles
-    int t0, t1;
-    tile_range(blk - b * S, S, T, t0, t1);
-    const float *xb = x + (size_t)b * 3 * N;
-    float tm[9] = {0};
-    const bool has_t = trans != nullptr;
-    if (has_t) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) tm[i] = trans[(size_t)b * 9 + i];
-    }
-    f32x16 s2a[4];
-    f32x16 s1a;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s2a[q][r] = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s1a[r] = 0.f;
-    float colsum = 0.f;
-    for (int tile = t0; tile < t1; ++tile) {
-        stage_points(xb, N, tile, has_t, tm, xs, nullptr, L.tid);
-        __syncthreads();
-        layer1_tile(xs, P.w1, P.b1, P.s1c, P.t1c, h1, L);
-        __syncthreads();
-        const int nbase = tile * TP;
-        {
-            f32x16 a0, a1;
-            const int cb = L.wave;
-            layer2_mfma(h1, P.w2p, cb, L, a0, a1);
-            const float sc = P.s2c[cb * 32 + L.j], sh = P.t2c[cb * 32 + L.j];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = mfma_row(r, L.lane);
-                h2[row * H2S + cb * 32 + L.j] = (nbase + row < N) ? fmaxf(fmaf(a0[r], sc, sh), 0.f) : 0.f;
-                h2[(32 + row) * H2S + cb * 32 + L.j] = (nbase + 32 + row < N) ? fmaxf(fmaf(a1[r], sc, sh), 0.f) : 0.f;
-            }
-        }
-        __syncthreads();
-        // S2: wave owns row block ib = wave, all four column blocks
-        {
-            const int ib = L.wave;
-#pragma unroll 4
-            for (int st = 0; st < 32; ++st) {
-                const float *rowp = h2 + (2 * st + L.h) * H2S + L.j;
-                const float av = rowp[ib * 32];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) s2a[q] = mfma32(av, rowp[q * 32], s2a[q]);
-            }
-        }
-        // column sums: threads 0..127 -> h2 column, 128..191 -> h1 column
-        if (L.tid < 128) {
-            for (int r = 0; r < TP; ++r) colsum += h2[r * H2S + L.tid];
-        }
-        __syncthreads();
-    }
-    {
-        float *o2 = ps2 + (size_t)blk * 128 * 128;
-        const int ib = L.wave;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                o2[(ib * 32 + mfma_row(r, L.lane)) * 128 + q * 32 + L.j] = s2a[q][r];
-        float *o1 = ps1 + (size_t)blk * 64 * 64;
-        const int i1 = L.wave >> 1, j1 = L.wave & 1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o1[(i1 * 32 + mfma_row(r, L.lane)) * 64 + j1 * 32 + L.j] = s1a[r];
-        if (L.tid < 192) psh[(size_t)blk * 192 + L.tid] = colsum;
     }
 }
 
@@ -362,9 +278,22 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_gather_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
-// backward pass D: g2 = dL/d(bn2 output) per point, written to HBM (B,N,128); accumulates
-//   pa [blk][128][2] = sum g2, sum g2*zhat2
-//   dh2[point][k] = cvec[k] - (h2 Asym)[point][k] + sum_{c: idx[b][c]==point} coef[b][c] W3[c][k]
+// backward pass D: g2 = dL/d(bn2 output) per point; also the 128x128 second moments of h2 (the old separate
+// "h-moments" pass: h2 is in LDS here anyway and this pass has idle MFMA slots).
+//   dh2[point][k] = cvec[k] - (h2 A)[point][k] + sum_{c: idx[b][c]==point} coef[b][c] W3[c][k]
+//   g2 = dh2 * (h2 > 0)
+// Everything is a contraction on the MFMA, the sparse arg-extremum term included: a tile's hits (c, p) are
+// compacted (ballot order = ascending channel, deterministic) into two lists by point half, and the term is
+//   D[p][k] += sum_e  onehot[p][e] * (-coef[c_e]) * W3[c_e][k]
+// i.e. extra k-steps of the SAME accumulators that hold h2 A: lane (row j, k-slot h) supplies
+// A = (p_e == j) ? -coef : 0 for hit e = 2s+h and B = W3[c_e][32 cb + j] (a coalesced 128-B row piece from L2).
+// No LDS scatter, no read-modify-write, no zero-fill.
+//   g2t  [(b*T + tile)][8][256] float4 : lane-major hand-off to pass E (same (row, channel) ownership per lane
+//        in both kernels: value v = 4*rq + e of thread tid is point block v>>4, mfma register v&15) — 8
+//        coalesced 16-B stores per lane here, 8 coalesced 16-B loads there, no transposition through LDS.
+//   pa   [blk][128][2] = sum g2, sum g2*zhat2
+//   ps2  [blk][4 waves][3][16][64] : raw accumulators of the Gram blocks (w,w), (w,w+1 mod 4), (w,w+2 | w<2);
+//        the remaining blocks follow by symmetry (s2_at() in pngpd_train_glue.hip).
 // ---------------------------------------------------------------------------------------
 struct BwdDParams {
     const float *is2, *nm2;     // zhat2 = z2*is2 + nm2
@@ -374,21 +303,20 @@ struct BwdDParams {
     const int *idx;             // (B,1024)
     const float *coef;          // (B,1024)
 };
-// LDS: h2 tile + one tile that is first h1 (dead after layer 2), then the sparse term, then the g2 tile on
-// its way to HBM; the cloud's coef row; parity-split hit lists  ->  76.6 KB, two workgroups per CU.
-#define BWD_D_LDS_FLOATS (2 * TP * H2S + 3 * TP + 1024 + 1024 + 8)
+#define BWD_D_HITS 1032   // per list: up to 1024 hits + read-ahead padding of the 8-hit sparse step
+#define BWD_D_LDS_FLOATS (TP * H2S + TP * H1S + 3 * TP + 1024 + 1024 + BWD_D_HITS + 16)
 
 __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
     const float *__restrict__ x, int N, const float *__restrict__ trans, TrainChan P, BwdDParams D,
-    int T, int S, float *__restrict__ g2buf, float *__restrict__ pa) {
+    int T, int S, f32x4 *__restrict__ g2t, float *__restrict__ pa, float *__restrict__ ps2) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *h2 = smem;
-    float *sp = h2 + TP * H2S;            // h1 during layers 1-2, then the sparse term, then g2
-    float *h1 = sp;
-    float *xs = sp + TP * H2S;
+    float *h2 = smem;                     // [TP][H2S], rows past N zeroed
+    float *h1 = h2 + TP * H2S;            // [TP][H1S]
+    float *xs = h1 + TP * H1S;            // [3][TP]
     float *cfl = xs + 3 * TP;             // [1024] coef row of this cloud
-    unsigned short *hits = (unsigned short *)(cfl + 1024);   // [2 parities][4 waves][256]: (c << 6) | local point
-    int *hcnt = (int *)(hits + 2 * 4 * 256);                 // [2][4]
+    int *idxl = (int *)(cfl + 1024);      // [1024] arg-extremum point of every channel of this cloud
+    unsigned short *hits = (unsigned short *)(idxl + 1024);   // [2 lists][BWD_D_HITS]: (c << 5) | (point & 31)
+    int *hcnt = (int *)(hits + 2 * BWD_D_HITS);               // [2 lists][4 waves]
     const Lane L;
     const int b = blockIdx.x / S, s = blockIdx.x - b * S;
     int t0, t1; tile_range(s, S, T, t0, t1);
@@ -399,115 +327,182 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
 #pragma unroll
         for (int i = 0; i < 9; ++i) tm[i] = trans[(size_t)b * 9 + i];
     }
-    const int *idxb = D.idx + (size_t)b * 1024;
-    for (int i = L.tid; i < 1024; i += 256) cfl[i] = D.coef[(size_t)b * 1024 + i];
+    for (int i = L.tid; i < 1024; i += 256) {
+        cfl[i] = D.coef[(size_t)b * 1024 + i];
+        idxl[i] = D.idx[(size_t)b * 1024 + i];
+    }
     float a1s = 0.f, a2s = 0.f;
     const int cb = L.wave;
     const int c2 = cb * 32 + L.j;
     const float sc2 = P.s2c[c2], sh2 = P.t2c[c2], is2 = D.is2[c2], nm2 = D.nm2[c2], cv = D.cvec[c2];
-    // coalesced hand-off of a finished g2 tile (in sp) to HBM: 8 x 16 B per thread, whole 512-B rows
-    auto flush_tile = [&](int tile) {
-        const int nb = tile * TP;
-        float *gt = g2buf + ((size_t)b * N + nb) * 128;
+    const unsigned long long ltmask = (1ull << L.lane) - 1ull;
+    f32x16 gm0, gm1, gm2;   // Gram blocks (cb,cb), (cb,cb+1 mod 4), (cb,cb+2) [waves 0,1 only]
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int q = L.tid + 256 * i, row = q >> 5, col = (q & 31) * 4;
-            if (nb + row < N) *(f32x4 *)(gt + row * 128 + col) = *(const f32x4 *)(sp + row * H2S + col);
-        }
-    };
+    for (int r = 0; r < 16; ++r) { gm0[r] = 0.f; gm1[r] = 0.f; gm2[r] = 0.f; }
+    __syncthreads();   // cfl / idxl visible
     for (int tile = t0; tile < t1; ++tile) {
         const int nbase = tile * TP;
-        if (tile > t0) flush_tile(tile - 1);   // every wave passed the end-of-tile barrier: sp holds g2(tile-1)
         stage_points(xb, N, tile, has_t, tm, xs, nullptr, L.tid);
+        // hit census of this wave's channel quarter [256 wave, 256 wave + 256): ballots stay in scalar registers
+        {
+            int clo = 0, chi = 0;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int n = idxl[L.wave * 256 + it * 64 + L.lane] - nbase;
+                clo += __popcll(__ballot(n >= 0 && n < 32));
+                chi += __popcll(__ballot(n >= 32 && n < TP));
+            }
+            if (L.lane == 0) { hcnt[L.wave] = clo; hcnt[4 + L.wave] = chi; }
+        }
         __syncthreads();
         layer1_tile(xs, P.w1, P.b1, P.s1c, P.t1c, h1, L);
-        // ordered compaction of this tile's arg-extremum hits, split by the parity of the local point so the
-        // two halves of the workgroup can accumulate without races: wave w scans channels [256w, 256w+256)
-        {
-            int cntE = 0, cntO = 0;
+        int nlo = 0, nhi = 0;
+        {   // ordered compaction at the prefix offsets of the four quarters
+            int olo = 0, ohi = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int a = hcnt[w], c = hcnt[4 + w];
+                if (w < L.wave) { olo += a; ohi += c; }
+                nlo += a; nhi += c;
+            }
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int c = L.wave * 256 + it * 64 + L.lane;
-                const int n = idxb[c];
-                const bool hit = (n >= nbase) && (n < nbase + TP);
-                const bool odd = (n & 1) != 0;
-                const unsigned long long mE = __ballot(hit && !odd), mO = __ballot(hit && odd);
-                const unsigned long long lt = (1ull << L.lane) - 1ull;
-                if (hit) {
-                    const unsigned short v = (unsigned short)((c << 6) | (n - nbase));
-                    if (odd) hits[(4 + L.wave) * 256 + cntO + __popcll(mO & lt)] = v;
-                    else hits[L.wave * 256 + cntE + __popcll(mE & lt)] = v;
-                }
-                cntE += __popcll(mE); cntO += __popcll(mO);
+                const int n = idxl[c] - nbase;
+                const bool lo = n >= 0 && n < 32, hi = n >= 32 && n < TP;
+                const unsigned long long mlo = __ballot(lo), mhi = __ballot(hi);
+                if (lo) hits[olo + __popcll(mlo & ltmask)] = (unsigned short)((c << 5) | n);
+                if (hi) hits[BWD_D_HITS + ohi + __popcll(mhi & ltmask)] = (unsigned short)((c << 5) | (n - 32));
+                olo += __popcll(mlo); ohi += __popcll(mhi);
             }
-            if (L.lane == 0) { hcnt[L.wave] = cntE; hcnt[4 + L.wave] = cntO; }
         }
+        nlo = __builtin_amdgcn_readfirstlane(nlo);
+        nhi = __builtin_amdgcn_readfirstlane(nhi);
         __syncthreads();
-        f32x16 zh0, zh1;   // zhat2 for (points of this lane, channel c2)
-        {
-            f32x16 a0, a1;
-            layer2_mfma(h1, P.w2p, cb, L, a0, a1);
+        f32x16 z0, z1;   // raw z2 of (this lane's rows, channel c2): ReLU mask and zhat2 are derived in the epilogue
+        layer2_mfma(h1, P.w2p, cb, L, z0, z1);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = mfma_row(r, L.lane);
-                h2[row * H2S + c2] = fmaxf(fmaf(a0[r], sc2, sh2), 0.f);
-                h2[(32 + row) * H2S + c2] = fmaxf(fmaf(a1[r], sc2, sh2), 0.f);
-                zh0[r] = fmaf(a0[r], is2, nm2);
-                zh1[r] = fmaf(a1[r], is2, nm2);
-                a0[r] = fmaf(a0[r], sc2, sh2);   // keep the pre-activation sign for the ReLU mask
-                a1[r] = fmaf(a1[r], sc2, sh2);
-            }
-            __syncthreads();   // every wave is done reading h1: its storage becomes the sparse tile
-            for (int i = L.tid; i < TP * H2S; i += 256) sp[i] = 0.f;
-            __syncthreads();
-            // sparse term, deterministic order (waves' lists in order, ascending channel).  thread = (k, parity)
-            {
-                const int k = L.tid & 127, half = L.tid >> 7;
-                for (int w = 0; w < 4; ++w) {
-                    const unsigned short *hl = hits + (half * 4 + w) * 256;
-                    const int n = hcnt[half * 4 + w];
-                    int e = 0;
-                    for (; e + 4 <= n; e += 4) {   // four independent W3 loads in flight
-                        const int v0 = hl[e], v1 = hl[e + 1], v2 = hl[e + 2], v3 = hl[e + 3];
-                        const float w0 = D.w3[(size_t)(v0 >> 6) * 128 + k], w1_ = D.w3[(size_t)(v1 >> 6) * 128 + k];
-                        const float w2_ = D.w3[(size_t)(v2 >> 6) * 128 + k], w3_ = D.w3[(size_t)(v3 >> 6) * 128 + k];
-                        float *q0 = sp + (v0 & 63) * H2S + k; *q0 = fmaf(cfl[v0 >> 6], w0, *q0);
-                        float *q1 = sp + (v1 & 63) * H2S + k; *q1 = fmaf(cfl[v1 >> 6], w1_, *q1);
-                        float *q2 = sp + (v2 & 63) * H2S + k; *q2 = fmaf(cfl[v2 >> 6], w2_, *q2);
-                        float *q3 = sp + (v3 & 63) * H2S + k; *q3 = fmaf(cfl[v3 >> 6], w3_, *q3);
-                    }
-                    for (; e < n; ++e) {
-                        const int v0 = hl[e];
-                        float *q0 = sp + (v0 & 63) * H2S + k;
-                        *q0 = fmaf(cfl[v0 >> 6], D.w3[(size_t)(v0 >> 6) * 128 + k], *q0);
-                    }
+        for (int r = 0; r < 16; ++r) {
+            const int row = mfma_row(r, L.lane);
+            h2[row * H2S + c2] = (nbase + row < N) ? fmaxf(fmaf(z0[r], sc2, sh2), 0.f) : 0.f;
+            h2[(32 + row) * H2S + c2] = (nbase + 32 + row < N) ? fmaxf(fmaf(z1[r], sc2, sh2), 0.f) : 0.f;
+        }
+        __syncthreads();   // h2 and the hit lists are complete
+        f32x16 d0, d1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
+        {   // d = h2 A   (K = 128)
+            const f32x4 *wp = (const f32x4 *)D.Ap + (size_t)(cb * 16) * 64 + L.lane;
+            const float *a0p = h2 + L.j * H2S + L.h * 4;
+            const float *a1p = h2 + (32 + L.j) * H2S + L.h * 4;
+#pragma unroll 4
+            for (int kb = 0; kb < 16; ++kb) {
+                const f32x4 wv = wp[kb * 64];
+                const f32x4 a0 = *(const f32x4 *)(a0p + kb * 8);
+                const f32x4 a1 = *(const f32x4 *)(a1p + kb * 8);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    d0 = mfma32(a0[t], wv[t], d0);
+                    d1 = mfma32(a1[t], wv[t], d1);
                 }
             }
-            __syncthreads();
-            f32x16 d0, d1;
-            k128_mfma(h2, D.Ap, cb, L, d0, d1);
+        }
+        // d -= sparse term: 8 hits (4 k-steps) per iteration, four W3 row pieces in flight
+        {
+            const float *w3c = D.w3 + c2;
+#pragma unroll 1
+            for (int e0 = 0; e0 < nlo; e0 += 8) {
+                float av[4], bv[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = mfma_row(r, L.lane);
-                const bool v0 = nbase + row < N, v1 = nbase + 32 + row < N;
-                float g0 = cv - d0[r] + sp[row * H2S + c2];
-                float g1 = cv - d1[r] + sp[(32 + row) * H2S + c2];
-                g0 = (v0 && a0[r] > 0.f) ? g0 : 0.f;
-                g1 = (v1 && a1[r] > 0.f) ? g1 : 0.f;
-                a1s += g0 + g1;
-                a2s = fmaf(g0, zh0[r], fmaf(g1, zh1[r], a2s));
-                sp[row * H2S + c2] = g0;            // same element this lane just read
-                sp[(32 + row) * H2S + c2] = g1;
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + 2 * u + L.h;
+                    const int v = hits[e];
+                    const int c = (e < nlo) ? (v >> 5) : 0;
+                    const float cf = (e < nlo) ? cfl[c] : 0.f;
+                    bv[u] = w3c[(size_t)c * 128];
+                    av[u] = ((v & 31) == L.j) ? -cf : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) d0 = mfma32(av[u], bv[u], d0);
+            }
+#pragma unroll 1
+            for (int e0 = 0; e0 < nhi; e0 += 8) {
+                float av[4], bv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + 2 * u + L.h;
+                    const int v = hits[BWD_D_HITS + e];
+                    const int c = (e < nhi) ? (v >> 5) : 0;
+                    const float cf = (e < nhi) ? cfl[c] : 0.f;
+                    bv[u] = w3c[(size_t)c * 128];
+                    av[u] = ((v & 31) == L.j) ? -cf : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) d1 = mfma32(av[u], bv[u], d1);
             }
         }
-        __syncthreads();   // g2 tile complete in sp; flushed at the top of the next iteration
+        // Gram of the tile: D[i][j] += A[i][k = point] B[k = point][j], both operands read column-wise from h2
+        {
+            const float *colp = h2 + L.h * H2S + L.j;
+            const int o0 = cb * 32, o1 = ((cb + 1) & 3) * 32;
+            if (cb < 2) {
+                const int o2 = (cb + 2) * 32;
+#pragma unroll 4
+                for (int st = 0; st < 32; ++st) {
+                    const float *rp = colp + 2 * st * H2S;
+                    const float av = rp[o0];
+                    gm0 = mfma32(av, av, gm0);
+                    gm1 = mfma32(av, rp[o1], gm1);
+                    gm2 = mfma32(av, rp[o2], gm2);
+                }
+            } else {
+#pragma unroll 4
+                for (int st = 0; st < 32; ++st) {
+                    const float *rp = colp + 2 * st * H2S;
+                    const float av = rp[o0];
+                    gm0 = mfma32(av, av, gm0);
+                    gm1 = mfma32(av, rp[o1], gm1);
+                }
+            }
+        }
+        // epilogue: g2 = (cvec - d) masked by ReLU(bn2) and validity; running sums; lane-major hand-off
+        {
+            f32x4 *gt = g2t + ((size_t)(b * T + tile) * 8) * 256 + L.tid;
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                f32x4 o0, o1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = rq * 4 + e;
+                    const int row = mfma_row(r, L.lane);
+                    float g0 = cv - d0[r], g1 = cv - d1[r];
+                    g0 = (nbase + row < N && fmaf(z0[r], sc2, sh2) > 0.f) ? g0 : 0.f;
+                    g1 = (nbase + 32 + row < N && fmaf(z1[r], sc2, sh2) > 0.f) ? g1 : 0.f;
+                    a1s += g0 + g1;
+                    a2s = fmaf(g0, fmaf(z0[r], is2, nm2), fmaf(g1, fmaf(z1[r], is2, nm2), a2s));
+                    o0[e] = g0; o1[e] = g1;
+                }
+                gt[(size_t)rq * 256] = o0;
+                gt[(size_t)(4 + rq) * 256] = o1;
+            }
+        }
+        // no end-of-tile barrier: the next tile's stage_points/census touch only xs/hcnt, whose readers all sit
+        // before this tile's second barrier; h1, hits and h2 are rewritten after the next tile's first barrier.
     }
-    flush_tile(t1 - 1);
     a1s += __shfl_xor(a1s, 32);
     a2s += __shfl_xor(a2s, 32);
     if (L.h == 0) {
         float *o = pa + ((size_t)blockIdx.x * 128 + c2) * 2;
         o[0] = a1s; o[1] = a2s;
+    }
+    {
+        float *o = ps2 + ((size_t)blockIdx.x * 12 + cb * 3) * 1024 + L.lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            o[r * 64] = gm0[r];
+            o[1024 + r * 64] = gm1[r];
+            o[2048 + r * 64] = gm2[r];   // zeros for waves 2,3
+        }
     }
 }
 
@@ -515,6 +510,7 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
 // backward pass E: dz2 -> dh1 = W2^T dz2 -> g1 = dL/d(bn1 output); accumulates
 //   pc [blk][64][2] = sum g1, sum g1*zhat1 ;  pR [blk][64][3] = sum_points g1 x^T (original x)
 //   pW2 [blk][128][64] = sum_points dz2 h1^T  (= this workgroup's share of dL/dW2, contracted on the MFMA)
+// g2t: pass D's lane-major hand-off (see there).
 // ---------------------------------------------------------------------------------------
 struct BwdEParams {
     const float *is1, *nm1;       // zhat1 = z1*is1 + nm1
@@ -523,17 +519,16 @@ struct BwdEParams {
     const float *dsc2;            // (128) gamma2/sigma2
     const float *w2tp;            // W2^T as a (64,128) matrix, MFMA_B packed
 };
-#define BWD_E_LDS_FLOATS (TP * H1S + TP * H2S + 6 * TP)
+#define BWD_E_LDS_FLOATS (TP * H1S + TP * H2S + 12 * TP)
 
 __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
     const float *__restrict__ x, int N, const float *__restrict__ trans, TrainChan P, BwdEParams E,
-    int T, int S, const float *__restrict__ g2buf, float *__restrict__ pc, float *__restrict__ pR,
+    int T, int S, const f32x4 *__restrict__ g2t, float *__restrict__ pc, float *__restrict__ pR,
     float *__restrict__ pW2) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *h1 = smem;
     float *dz = h1 + TP * H1S;    // [TP][H2S]
-    float *xs = dz + TP * H2S;    // [3][TP] transformed
-    float *xo = xs + 3 * TP;      // [3][TP] original
+    float *xbuf = dz + TP * H2S;  // 2 x ([3][TP] transformed, [3][TP] original): double-buffered per tile parity
     const Lane L;
     const int b = blockIdx.x / S, s = blockIdx.x - b * S;
     int t0, t1; tile_range(s, S, T, t0, t1);
@@ -556,25 +551,16 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
     for (int r = 0; r < 16; ++r) { pw0[r] = 0.f; pw1[r] = 0.f; }
     for (int tile = t0; tile < t1; ++tile) {
         const int nbase = tile * TP;
-        // the tile's g2 rows (64 x 512 B, contiguous in HBM) are fetched with 8 coalesced 16-B loads per thread
-        // at the top of the iteration and parked in the dz tile; each lane later picks up its own elements there
-        f32x4 gq[8];
+        float *xs = xbuf + ((tile - t0) & 1) * 6 * TP, *xo = xs + 3 * TP;
+        f32x4 gq[8];   // this lane's 32 g2 values of the tile (rows past N hold zeros)
         {
-            const float *gt = g2buf + ((size_t)b * N + nbase) * 128;
+            const f32x4 *gt = g2t + ((size_t)(b * T + tile) * 8) * 256 + L.tid;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int q = L.tid + 256 * i, row = q >> 5, col = (q & 31) * 4;
-                gq[i] = (nbase + row < N) ? *(const f32x4 *)(gt + row * 128 + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            for (int i = 0; i < 8; ++i) gq[i] = gt[(size_t)i * 256];
         }
         stage_points(xb, N, tile, has_t, tm, xs, xo, L.tid);
         __syncthreads();
         layer1_tile(xs, P.w1, P.b1, P.s1c, P.t1c, h1, L);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int q = L.tid + 256 * i, row = q >> 5, col = (q & 31) * 4;
-            *(f32x4 *)(dz + row * H2S + col) = gq[i];
-        }
         __syncthreads();
         {
             f32x16 a0, a1;
@@ -583,7 +569,7 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
             for (int r = 0; r < 16; ++r) {
                 const int row = mfma_row(r, L.lane);
                 const bool v0 = nbase + row < N, v1 = nbase + 32 + row < N;
-                const float g0 = dz[row * H2S + c2], g1 = dz[(32 + row) * H2S + c2];   // rows past N hold zeros
+                const float g0 = gq[r >> 2][r & 3], g1 = gq[4 + (r >> 2)][r & 3];
                 const float z0 = fmaf(a0[r], is2, nm2), z1 = fmaf(a1[r], is2, nm2);
                 dz[row * H2S + c2] = v0 ? dsc * (g0 - a1m - z0 * a2m) : 0.f;
                 dz[(32 + row) * H2S + c2] = v1 ? dsc * (g1 - a1m - z1 * a2m) : 0.f;
@@ -626,7 +612,8 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
             pw0 = mfma32(av, hr[0], pw0);
             pw1 = mfma32(av, hr[32], pw1);
         }
-        __syncthreads();
+        // no end-of-tile barrier: xs/xo are double-buffered; h1 and dz are rewritten only after the next tile's
+        // first barrier, which every wave reaches after finishing this tile.
     }
     {
         float *oW = pW2 + (size_t)blockIdx.x * 128 * 64;
@@ -640,7 +627,8 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
     c1s += __shfl_xor(c1s, 32); c2s += __shfl_xor(c2s, 32);
     r0 += __shfl_xor(r0, 32); r1 += __shfl_xor(r1, 32); r2 += __shfl_xor(r2, 32);
     // two waves (pb1 = 0,1) own the same channel block: combine through LDS
-    float *red = dz;   // safe: every wave passed the loop's final barrier
+    __syncthreads();   // every wave is done with dz
+    float *red = dz;
     if (L.h == 0) {
         float *o = red + (L.wave * 32 + L.j) * 5;
         o[0] = c1s; o[1] = c2s; o[2] = r0; o[3] = r1; o[4] = r2;
@@ -742,14 +730,10 @@ __global__ void log_softmax_bwd_kernel(const float *__restrict__ g, const float 
     for (int k = 0; k < K; ++k) dlogits[(size_t)b * K + k] = g[(size_t)b * K + k] - expf(logp[(size_t)b * K + k]) * s;
 }
 
+
 // ---------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------
-// LDS requests above 64 KB need an explicit opt-in per kernel.
-static void allow_lds(const void *fn, size_t bytes) {
-    if (bytes > 48 * 1024) hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-}
-
 static TrainChan make_chan(const float *w1, const float *b1, const float *s1c, const float *t1c,
                            const float *w2p, const float *s2c, const float *t2c) {
     TrainChan P; P.w1 = w1; P.b1 = b1; P.s1c = s1c; P.t1c = t1c; P.w2p = w2p; P.s2c = s2c; P.t2c = t2c;
@@ -758,11 +742,14 @@ static TrainChan make_chan(const float *w1, const float *b1, const float *s1c, c
 
 extern "C" {
 
-int pngpd_train_set_target_blocks(int v) { g_train_target_blocks = v > 0 ? v : 1; return PNGPD_OK; }
-
-int pngpd_trunk_train_splits(int B, int N) {
+int pngpd_trunk_splits(int B, int N, int target_blocks) {
     if (B <= 0 || N <= 0) return 0;
-    return train_splits(B, (N + TP - 1) / TP);
+    return pngpd_splits_for(B, (N + TP - 1) / TP, target_blocks > 0 ? target_blocks : 1024);
+}
+
+size_t pngpd_trunk_g2t_bytes(int B, int N) {
+    if (B <= 0 || N <= 0) return 0;
+    return (size_t)B * ((N + TP - 1) / TP) * TP * 128 * sizeof(float);
 }
 
 int pngpd_cloud_moments(const float *x, int B, int N, double *mom, void *stream) {
@@ -773,9 +760,10 @@ int pngpd_cloud_moments(const float *x, int B, int N, double *mom, void *stream)
 
 int pngpd_trunk_bn2_stats(const float *x, int B, int N, const float *trans,
                           const float *w1, const float *b1, const float *s1c, const float *t1c,
-                          const float *w2p, float *part, void *stream) {
+                          const float *w2p, int S, float *part, void *stream) {
     if (!x || !w1 || !b1 || !s1c || !t1c || !w2p || !part || B <= 0 || N <= 0) return PNGPD_ERR_INVALID_ARG;
-    const int T = (N + TP - 1) / TP, S = train_splits(B, T);
+    const int T = (N + TP - 1) / TP;
+    if (!splits_ok(S, T)) return PNGPD_ERR_INVALID_ARG;
     TrainChan P = make_chan(w1, b1, s1c, t1c, w2p, nullptr, nullptr);
     const size_t lds = (TP * H1S + 3 * TP) * sizeof(float);
     hipLaunchKernelGGL(trunk_bn2_stats_kernel, dim3((unsigned)B * S), dim3(256), lds, (hipStream_t)stream,
@@ -785,33 +773,19 @@ int pngpd_trunk_bn2_stats(const float *x, int B, int N, const float *trans,
 
 int pngpd_trunk_fwd_train(const float *x, int B, int N, const float *trans,
                           const float *w1, const float *b1, const float *s1c, const float *t1c,
-                          const float *w2p, const float *s2c, const float *t2c, const float *w3sp,
-                          float *pmax, int *parg, float *psum, void *stream) {
-    if (!x || !w1 || !b1 || !s1c || !t1c || !w2p || !s2c || !t2c || !w3sp || !pmax || !parg || !psum ||
+                          const float *w2p, const float *s2c, const float *t2c, const float *w3sp, int S,
+                          float *pmax, int *parg, float *psum, float *psh, void *stream) {
+    if (!x || !w1 || !b1 || !s1c || !t1c || !w2p || !s2c || !t2c || !w3sp || !pmax || !parg || !psum || !psh ||
         B <= 0 || N <= 0)
         return PNGPD_ERR_INVALID_ARG;
-    const int T = (N + TP - 1) / TP, S = train_splits(B, T);
+    const int T = (N + TP - 1) / TP;
+    if (!splits_ok(S, T)) return PNGPD_ERR_INVALID_ARG;
     TrainChan P = make_chan(w1, b1, s1c, t1c, w2p, s2c, t2c);
     const size_t lds = TRAIN_MAIN_LDS_FLOATS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) { allow_lds((const void *)trunk_fwd_train_kernel, lds); attr_set = true; }
+    int st = pngpd_allow_lds((const void *)trunk_fwd_train_kernel, lds);
+    if (st != PNGPD_OK) return st;
     hipLaunchKernelGGL(trunk_fwd_train_kernel, dim3((unsigned)B * S), dim3(256), lds, (hipStream_t)stream,
-                       x, N, trans, P, w3sp, T, S, pmax, parg, psum);
-    return pngpd_launch_status();
-}
-
-int pngpd_trunk_h_moments(const float *x, int B, int N, const float *trans,
-                          const float *w1, const float *b1, const float *s1c, const float *t1c,
-                          const float *w2p, const float *s2c, const float *t2c, int S,
-                          float *ps2, float *ps1, float *psh, void *stream) {
-    if (!x || !w1 || !b1 || !s1c || !t1c || !w2p || !s2c || !t2c || !ps2 || !ps1 || !psh || B <= 0 || N <= 0)
-        return PNGPD_ERR_INVALID_ARG;
-    const int T = (N + TP - 1) / TP;
-    if (S < 1 || S > T) return PNGPD_ERR_INVALID_ARG;
-    TrainChan P = make_chan(w1, b1, s1c, t1c, w2p, s2c, t2c);
-    const size_t lds = (TP * H1S + TP * H2S + 3 * TP) * sizeof(float);
-    hipLaunchKernelGGL(trunk_h_moments_kernel, dim3((unsigned)B * S), dim3(256), lds, (hipStream_t)stream,
-                       x, N, trans, P, T, S, ps2, ps1, psh);
+                       x, N, trans, P, w3sp, T, S, pmax, parg, psum, psh);
     return pngpd_launch_status();
 }
 
@@ -825,6 +799,8 @@ int pngpd_trunk_bwd_gather(const float *x, int B, int N, const float *trans,
     const int R = (B + clouds_per_range - 1) / clouds_per_range;
     TrainChan P = make_chan(w1, b1, s1c, t1c, w2p, s2c, t2c);
     const size_t lds = (TP * H1S + TP * H2S + 3 * TP + 64) * sizeof(float);
+    int st = pngpd_allow_lds((const void *)trunk_bwd_gather_kernel, lds);
+    if (st != PNGPD_OK) return st;
     hipLaunchKernelGGL(trunk_bwd_gather_kernel, dim3((unsigned)R * 16), dim3(256), lds, (hipStream_t)stream,
                        x, B, N, trans, P, idx, coef, clouds_per_range, Gp);
     return pngpd_launch_status();
@@ -834,20 +810,21 @@ int pngpd_trunk_bwd_d(const float *x, int B, int N, const float *trans,
                       const float *w1, const float *b1, const float *s1c, const float *t1c,
                       const float *w2p, const float *s2c, const float *t2c,
                       const float *is2, const float *nm2, const float *Ap, const float *cvec,
-                      const float *w3, const int *idx, const float *coef,
-                      float *g2buf, float *pa, void *stream) {
+                      const float *w3, const int *idx, const float *coef, int S,
+                      float *g2t, float *pa, float *ps2, void *stream) {
     if (!x || !w1 || !b1 || !s1c || !t1c || !w2p || !s2c || !t2c || !is2 || !nm2 || !Ap || !cvec || !w3 ||
-        !idx || !coef || !g2buf || !pa || B <= 0 || N <= 0)
+        !idx || !coef || !g2t || !pa || !ps2 || B <= 0 || N <= 0)
         return PNGPD_ERR_INVALID_ARG;
-    const int T = (N + TP - 1) / TP, S = train_splits(B, T);
+    const int T = (N + TP - 1) / TP;
+    if (!splits_ok(S, T)) return PNGPD_ERR_INVALID_ARG;
+    if (N > (1 << 30)) return PNGPD_ERR_UNSUPPORTED;
     TrainChan P = make_chan(w1, b1, s1c, t1c, w2p, s2c, t2c);
     BwdDParams D; D.is2 = is2; D.nm2 = nm2; D.Ap = Ap; D.cvec = cvec; D.w3 = w3; D.idx = idx; D.coef = coef;
     const size_t lds = BWD_D_LDS_FLOATS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) { allow_lds((const void *)trunk_bwd_d_kernel, lds); attr_set = true; }
-    if (N > (1 << 30)) return PNGPD_ERR_UNSUPPORTED;
+    int st = pngpd_allow_lds((const void *)trunk_bwd_d_kernel, lds);
+    if (st != PNGPD_OK) return st;
     hipLaunchKernelGGL(trunk_bwd_d_kernel, dim3((unsigned)B * S), dim3(256), lds, (hipStream_t)stream,
-                       x, N, trans, P, D, T, S, g2buf, pa);
+                       x, N, trans, P, D, T, S, (f32x4 *)g2t, pa, ps2);
     return pngpd_launch_status();
 }
 
@@ -855,17 +832,20 @@ int pngpd_trunk_bwd_e(const float *x, int B, int N, const float *trans,
                       const float *w1, const float *b1, const float *s1c, const float *t1c,
                       const float *w2p, const float *is1, const float *nm1, const float *is2, const float *nm2,
                       const float *a1m, const float *a2m, const float *dsc2, const float *w2tp,
-                      const float *g2buf, float *pc, float *pR, float *pW2, void *stream) {
+                      const float *g2t, int S, float *pc, float *pR, float *pW2, void *stream) {
     if (!x || !w1 || !b1 || !s1c || !t1c || !w2p || !is1 || !nm1 || !is2 || !nm2 || !a1m || !a2m || !dsc2 ||
-        !w2tp || !g2buf || !pc || !pR || !pW2 || B <= 0 || N <= 0)
+        !w2tp || !g2t || !pc || !pR || !pW2 || B <= 0 || N <= 0)
         return PNGPD_ERR_INVALID_ARG;
-    const int T = (N + TP - 1) / TP, S = train_splits(B, T);
+    const int T = (N + TP - 1) / TP;
+    if (!splits_ok(S, T)) return PNGPD_ERR_INVALID_ARG;
     TrainChan P = make_chan(w1, b1, s1c, t1c, w2p, nullptr, nullptr);
     BwdEParams E; E.is1 = is1; E.nm1 = nm1; E.is2 = is2; E.nm2 = nm2; E.a1m = a1m; E.a2m = a2m; E.dsc2 = dsc2;
     E.w2tp = w2tp;
     const size_t lds = BWD_E_LDS_FLOATS * sizeof(float);
+    int st = pngpd_allow_lds((const void *)trunk_bwd_e_kernel, lds);
+    if (st != PNGPD_OK) return st;
     hipLaunchKernelGGL(trunk_bwd_e_kernel, dim3((unsigned)B * S), dim3(256), lds, (hipStream_t)stream,
-                       x, N, trans, P, E, T, S, g2buf, pc, pR, pW2);
+                       x, N, trans, P, E, T, S, (const f32x4 *)g2t, pc, pR, pW2);
     return pngpd_launch_status();
 }
 

@@ -234,12 +234,58 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float *__re
     }
 }
 
+// Up to four such reductions in ONE launch (the partial buffers of one training pass are reduced together:
+// 4 launches per trunk instead of 9).  Segment g covers blocks [first[g], first[g+1]).
+struct ReduceSeg { const float *in; double *out; int outer, R, n, blocks_per_outer; };
+struct ReduceSegs { ReduceSeg seg[4]; int first[5]; };
+
+__global__ __launch_bounds__(1024) void reduce_partials_multi_kernel(ReduceSegs A) {
+    __shared__ double red[32][33];
+    int g = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) g += ((int)blockIdx.x >= A.first[i]) ? 1 : 0;
+    const ReduceSeg sg = A.seg[g];
+    const int lb = blockIdx.x - A.first[g];
+    const int o = lb / sg.blocks_per_outer, jb = lb - o * sg.blocks_per_outer;
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int j = jb * 32 + cx;
+    double s = 0.0;
+    if (j < sg.n) {
+        const float *p = sg.in + (size_t)o * sg.R * sg.n + j;
+        for (int r = ry; r < sg.R; r += 32) s += (double)p[(size_t)r * sg.n];
+    }
+    red[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && j < sg.n) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) t += red[i][cx];
+        sg.out[(size_t)o * sg.n + j] = t;
+    }
+}
+
+// Element (k, j) of S2 = sum_points h2 h2^T from the 10 accumulator blocks pass D keeps (S2c f64 [12][16][64]:
+// slot 3w+q of wave w = block (w, (w+q) mod 4), q < 3 for w < 2 and q < 2 otherwise, raw MFMA register layout
+// D[i = (r&3) + 8 (r>>2) + 4 (lane>>5)][j = lane & 31]); the other six blocks are transposes.
+__device__ __forceinline__ double s2_at(const double *__restrict__ S2c, int k, int j) {
+    int a = k >> 5, b = j >> 5, i = k & 31, jj = j & 31;
+    const int d = (b - a) & 3;
+    int q = d;
+    if (d == 3 || (d == 2 && a >= 2)) {   // stored as the transposed block (b, a)
+        const int t = a; a = b; b = t;
+        const int u = i; i = jj; jj = u;
+        q = (b - a) & 3;
+    }
+    const int r = (i & 3) + 4 * (i >> 3), h = (i >> 2) & 1;
+    return S2c[((size_t)(a * 3 + q) * 16 + r) * 64 + h * 32 + jj];
+}
+
 // ---------------------------------------------------------------------------------------
 // dW3[c][j] = G[c][j] - s3 (m1 sh[j] + (m2/sig3) (W3 Sc)[c][j]),  Sc = S2 - sh sh^T / M
 // block = one channel c, 128 threads = j
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(128) void dw3_finalize_kernel(
-    const double *__restrict__ G, const double *__restrict__ S2, const double *__restrict__ sh, double M,
+    const double *__restrict__ G, const double *__restrict__ S2c, const double *__restrict__ sh, double M,
     const float *__restrict__ w3, const float *__restrict__ g3, const double *__restrict__ stats,
     const double *__restrict__ m12, double eps, float *__restrict__ dW3) {
     __shared__ double wrow[128];
@@ -251,7 +297,7 @@ __global__ __launch_bounds__(128) void dw3_finalize_kernel(
     for (int s = 64; s > 0; s >>= 1) { if (j < s) red[j] += red[j + s]; __syncthreads(); }
     const double ws = red[0];
     double dot = 0.0;
-    for (int k = 0; k < 128; ++k) dot += wrow[k] * S2[(size_t)k * 128 + j];
+    for (int k = 0; k < 128; ++k) dot += wrow[k] * s2_at(S2c, k, j);
     const double w3sc = dot - ws * sh[j] / M;
     const double sig = sqrt(stats[1024 + c] + eps);
     const double s3 = (double)g3[c] / sig;
@@ -447,17 +493,44 @@ int pngpd_reduce_partials(const float *in, int outer, int R, int n, double *out,
     LAUNCH(reduce_partials_kernel, dim3((n + 31) / 32, outer), dim3(1024), in, R, n, out);
 }
 
-int pngpd_dw3_finalize(const double *G, const double *S2, const double *sh, int B, int N, const float *w3,
+int pngpd_reduce_partials4(const float *in0, int outer0, int R0, int n0, double *out0,
+                           const float *in1, int outer1, int R1, int n1, double *out1,
+                           const float *in2, int outer2, int R2, int n2, double *out2,
+                           const float *in3, int outer3, int R3, int n3, double *out3, void *stream) {
+    const float *in[4] = {in0, in1, in2, in3};
+    double *out[4] = {out0, out1, out2, out3};
+    const int outer[4] = {outer0, outer1, outer2, outer3}, R[4] = {R0, R1, R2, R3}, n[4] = {n0, n1, n2, n3};
+    ReduceSegs A;
+    int total = 0;
+    for (int g = 0; g < 4; ++g) {
+        A.first[g] = total;
+        A.seg[g].in = in[g]; A.seg[g].out = out[g];
+        A.seg[g].outer = 0; A.seg[g].R = 0; A.seg[g].n = 0; A.seg[g].blocks_per_outer = 1;
+        if (!in[g]) continue;   // unused slot
+        if (!out[g] || outer[g] <= 0 || R[g] <= 0 || n[g] <= 0) return PNGPD_ERR_INVALID_ARG;
+        A.seg[g].outer = outer[g]; A.seg[g].R = R[g]; A.seg[g].n = n[g];
+        A.seg[g].blocks_per_outer = (n[g] + 31) / 32;
+        total += outer[g] * A.seg[g].blocks_per_outer;
+    }
+    A.first[4] = total;
+    if (total == 0) return PNGPD_ERR_INVALID_ARG;
+    LAUNCH(reduce_partials_multi_kernel, dim3(total), dim3(1024), A);
+}
+
+int pngpd_a_cvec_finalize(const double *sh, int B, int N, const float *w3, const float *g3, const double *stats,
+                          const double *m12, float eps, float *Ap, float *cvec, void *stream) {
+    if (!sh || !w3 || !g3 || !stats || !m12 || !Ap || !cvec || B <= 0 || N <= 0) return PNGPD_ERR_INVALID_ARG;
+    LAUNCH(a_cvec_finalize_kernel, dim3(128), dim3(512), w3, g3, stats, m12, sh, (double)B * N, (double)eps, Ap,
+           cvec);
+}
+
+int pngpd_dw3_finalize(const double *G, const double *S2c, const double *sh, int B, int N, const float *w3,
                        const float *g3, const double *stats, const double *m12, float eps, float *dW3,
-                       float *Ap, float *cvec, void *stream) {
-    if (!G || !S2 || !sh || !w3 || !g3 || !stats || !m12 || !dW3 || !Ap || !cvec || B <= 0 || N <= 0)
+                       void *stream) {
+    if (!G || !S2c || !sh || !w3 || !g3 || !stats || !m12 || !dW3 || B <= 0 || N <= 0)
         return PNGPD_ERR_INVALID_ARG;
-    const double M = (double)B * N;
-    hipLaunchKernelGGL(dw3_finalize_kernel, dim3(1024), dim3(128), 0, (hipStream_t)stream, G, S2, sh, M, w3, g3,
-                       stats, m12, (double)eps, dW3);
-    int st = pngpd_launch_status();
-    if (st != PNGPD_OK) return st;
-    LAUNCH(a_cvec_finalize_kernel, dim3(128), dim3(512), w3, g3, stats, m12, sh, M, (double)eps, Ap, cvec);
+    LAUNCH(dw3_finalize_kernel, dim3(1024), dim3(128), G, S2c, sh, (double)B * N, w3, g3, stats, m12,
+           (double)eps, dW3);
 }
 
 int pngpd_bwd_e_prep(const double *a12, int B, int N, const float *g2, const double *stats2, float eps,

@@ -181,49 +181,46 @@ __global__ void pool_reduce_kernel(const float *__restrict__ part, int S, float 
     out[idx] = m;
 }
 
-static int g_trunk_target_blocks = 2048;
+#define TRUNK_DEFAULT_TARGET_BLOCKS 2048   // 8 per CU; measured flat between 1024 and 4096 at B = N = 1024
 
-static int trunk_splits(int B, int T) {
-    int S = (g_trunk_target_blocks + B - 1) / B;
-    if (S < 1) S = 1;
-    if (S > T) S = T;
-    return S;
+static int resolve_splits(int B, int T, int splits) {
+    return (splits > 0) ? (splits > T ? T : splits) : pngpd_splits_for(B, T, TRUNK_DEFAULT_TARGET_BLOCKS);
 }
 
 extern "C" {
 
-int pngpd_set_option(const char *name, int value) {
-    if (!name) return PNGPD_ERR_INVALID_ARG;
-    if (!strcmp(name, "trunk_target_blocks")) { g_trunk_target_blocks = value > 0 ? value : 1; return PNGPD_OK; }
-    return PNGPD_ERR_INVALID_ARG;
+int pngpd_trunk_infer_splits(int B, int N, int target_blocks) {
+    if (B <= 0 || N <= 0) return 0;
+    return pngpd_splits_for(B, (N + TP - 1) / TP, target_blocks > 0 ? target_blocks : TRUNK_DEFAULT_TARGET_BLOCKS);
 }
 
-size_t pngpd_trunk_workspace_bytes(int B, int N) {
+size_t pngpd_trunk_workspace_bytes(int B, int N, int splits) {
     if (B <= 0 || N <= 0) return 0;
-    int T = (N + TP - 1) / TP;
-    // sized for the largest split count any option setting can choose (S <= T)
-    return (size_t)B * T * 1024 * sizeof(float);
+    const int S = resolve_splits(B, (N + TP - 1) / TP, splits);
+    return S > 1 ? (size_t)B * S * 1024 * sizeof(float) : 0;   // partial maxima of the S workgroups of a cloud
 }
 
 int pngpd_trunk_fwd_infer(const float *x, int B, int N, const float *trans,
                           const float *w1, const float *b1, const float *w2p, const float *b2,
-                          const float *w3p, const float *b3, int relu_last,
+                          const float *w3p, const float *b3, int relu_last, int splits,
                           float *out_pool, void *workspace, size_t workspace_bytes, void *stream) {
     if (!x || !w1 || !b1 || !w2p || !b2 || !w3p || !b3 || !out_pool || B <= 0 || N <= 0)
         return PNGPD_ERR_INVALID_ARG;
     const int T = (N + TP - 1) / TP;
-    const int S = trunk_splits(B, T);
+    const int S = resolve_splits(B, T, splits);
     float *dst = out_pool;
     if (S > 1) {
         if (!workspace || workspace_bytes < (size_t)B * S * 1024 * sizeof(float)) return PNGPD_ERR_WORKSPACE;
         dst = (float *)workspace;
     }
     const size_t lds = TRUNK_LDS_FLOATS * sizeof(float);
+    int st = pngpd_allow_lds((const void *)trunk_infer_kernel, lds);
+    if (st != PNGPD_OK) return st;
     int CS = 1;
     if (B * S <= 128) CS = 4; else if (B * S <= 256) CS = 2;
     hipLaunchKernelGGL(trunk_infer_kernel, dim3((unsigned)B * S * CS), dim3(256), lds, (hipStream_t)stream,
                        x, N, trans, w1, b1, w2p, b2, w3p, b3, relu_last, T, S, CS, dst);
-    int st = pngpd_launch_status();
+    st = pngpd_launch_status();
     if (st != PNGPD_OK) return st;
     if (S > 1) {
         int total = B * 1024;

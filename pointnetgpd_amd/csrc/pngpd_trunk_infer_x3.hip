@@ -220,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void trunk_fwd_train_x3_kernel(
     const float *__restrict__ w1, const float *__restrict__ b1, const float *__restrict__ s1c,
     const float *__restrict__ t1c, const u16 *__restrict__ w2x, const float *__restrict__ s2c,
     const float *__restrict__ t2c, const u16 *__restrict__ w3x, int T, int S,
-    float *__restrict__ pmax, int *__restrict__ parg, float *__restrict__ psum) {
+    float *__restrict__ pmax, int *__restrict__ parg, float *__restrict__ psum, float *__restrict__ psh) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16 *h1h = (u16 *)smem_raw;
     u16 *h1l = h1h + XP * X1S;
@@ -228,6 +228,7 @@ __global__ __launch_bounds__(512, 2) void trunk_fwd_train_x3_kernel(
     u16 *h2l = h2h + XP * X2S;
     float *xs = (float *)(h2l + XP * X2S);
     float *rm = xs + 3 * XP;
+    float hsum = 0.f;   // sum of h2[.][(wave&3)*32 + j] over this wave's valid rows
     int *ri = (int *)(rm + 1024);
     float *ss = (float *)(ri + 1024);
     float *sq = ss + 1024;
@@ -303,10 +304,13 @@ __global__ __launch_bounds__(512, 2) void trunk_fwd_train_x3_kernel(
             for (int r = 0; r < 16; ++r) {
                 const int row = mfma_row(r, lane);
                 u16 hi, lo;
-                split2(fmaxf(fmaf(a0[r], sc, sh), 0.f), hi, lo);
+                const float v0 = fmaxf(fmaf(a0[r], sc, sh), 0.f), v1 = fmaxf(fmaf(a1[r], sc, sh), 0.f);
+                split2(v0, hi, lo);
                 h2h[(pb0 * 32 + row) * X2S + cb * 32 + j] = hi; h2l[(pb0 * 32 + row) * X2S + cb * 32 + j] = lo;
-                split2(fmaxf(fmaf(a1[r], sc, sh), 0.f), hi, lo);
+                split2(v1, hi, lo);
                 h2h[((pb0 + 1) * 32 + row) * X2S + cb * 32 + j] = hi; h2l[((pb0 + 1) * 32 + row) * X2S + cb * 32 + j] = lo;
+                hsum += (nbase + pb0 * 32 + row < N) ? v0 : 0.f;
+                hsum += (nbase + (pb0 + 1) * 32 + row < N) ? v1 : 0.f;
             }
         }
         __syncthreads();
@@ -377,7 +381,9 @@ __global__ __launch_bounds__(512, 2) void trunk_fwd_train_x3_kernel(
             }
         }
     }
+    hsum += __shfl_xor(hsum, 32);
     if (h == 0) {
+        psh[((size_t)blockIdx.x * 2 + (wave >> 2)) * 128 + (wave & 3) * 32 + j] = hsum;
 #pragma unroll
         for (int ci = 0; ci < 4; ++ci) {
             const int c = (wave + 8 * ci) * 32 + j;
@@ -399,9 +405,14 @@ __global__ void pool_reduce_x3_kernel(const float *__restrict__ part, int S, flo
     out[idx] = m;
 }
 
-static int g_x3_target_blocks = 1024;
+#define X3_DEFAULT_TARGET_BLOCKS 1024
 
 extern "C" {
+
+int pngpd_trunk_infer_x3_splits(int B, int N, int target_blocks) {
+    if (B <= 0 || N <= 0) return 0;
+    return pngpd_splits_for(B, (N + XP - 1) / XP, target_blocks > 0 ? target_blocks : X3_DEFAULT_TARGET_BLOCKS);
+}
 
 int pngpd_split_pack_bf16(const float *W, int C, int K, void *out, void *stream) {
     if (!W || !out || C <= 0 || K <= 0 || (C & 31) || (K & 15)) return PNGPD_ERR_INVALID_ARG;
@@ -413,27 +424,22 @@ int pngpd_split_pack_bf16(const float *W, int C, int K, void *out, void *stream)
 
 int pngpd_trunk_fwd_infer_x3(const float *x, int B, int N, const float *trans,
                              const float *w1, const float *b1, const void *w2x, const float *b2,
-                             const void *w3x, const float *b3, int relu_last,
+                             const void *w3x, const float *b3, int relu_last, int splits,
                              float *out_pool, void *workspace, size_t workspace_bytes, void *stream) {
     if (!x || !w1 || !b1 || !w2x || !b2 || !w3x || !b3 || !out_pool || B <= 0 || N <= 0)
         return PNGPD_ERR_INVALID_ARG;
     const int T = (N + XP - 1) / XP;
-    int S = (g_x3_target_blocks + B - 1) / B;
-    if (S < 1) S = 1;
-    if (S > T) S = T;
+    const int S = (splits > 0) ? (splits > T ? T : splits) : pngpd_splits_for(B, T, X3_DEFAULT_TARGET_BLOCKS);
     float *dst = out_pool;
     if (S > 1) {
         if (!workspace || workspace_bytes < (size_t)B * S * 1024 * sizeof(float)) return PNGPD_ERR_WORKSPACE;
         dst = (float *)workspace;
     }
-    static bool attr = false;
-    if (!attr) {
-        hipFuncSetAttribute((const void *)trunk_infer_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
-        attr = true;
-    }
+    int st = pngpd_allow_lds((const void *)trunk_infer_x3_kernel, X3_LDS_BYTES);
+    if (st != PNGPD_OK) return st;
     hipLaunchKernelGGL(trunk_infer_x3_kernel, dim3((unsigned)B * S), dim3(512), X3_LDS_BYTES, (hipStream_t)stream,
                        x, N, trans, w1, b1, (const u16 *)w2x, b2, (const u16 *)w3x, b3, relu_last, T, S, dst);
-    int st = pngpd_launch_status();
+    st = pngpd_launch_status();
     if (st != PNGPD_OK) return st;
     if (S > 1) {
         const int total = B * 1024;
@@ -447,20 +453,17 @@ int pngpd_trunk_fwd_infer_x3(const float *x, int B, int N, const float *trans,
 int pngpd_trunk_fwd_train_x3(const float *x, int B, int N, const float *trans,
                              const float *w1, const float *b1, const float *s1c, const float *t1c,
                              const void *w2x, const float *s2c, const float *t2c, const void *w3sx, int S,
-                             float *pmax, int *parg, float *psum, void *stream) {
-    if (!x || !w1 || !b1 || !s1c || !t1c || !w2x || !s2c || !t2c || !w3sx || !pmax || !parg || !psum ||
+                             float *pmax, int *parg, float *psum, float *psh, void *stream) {
+    if (!x || !w1 || !b1 || !s1c || !t1c || !w2x || !s2c || !t2c || !w3sx || !pmax || !parg || !psum || !psh ||
         B <= 0 || N <= 0)
         return PNGPD_ERR_INVALID_ARG;
     const int T = (N + XP - 1) / XP;
     if (S < 1 || S > T) return PNGPD_ERR_INVALID_ARG;   // S: the split count the caller sized pmax/parg/psum for
-    static bool attr = false;
-    if (!attr) {
-        hipFuncSetAttribute((const void *)trunk_fwd_train_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, X3T_LDS_BYTES);
-        attr = true;
-    }
+    int st = pngpd_allow_lds((const void *)trunk_fwd_train_x3_kernel, X3T_LDS_BYTES);
+    if (st != PNGPD_OK) return st;
     hipLaunchKernelGGL(trunk_fwd_train_x3_kernel, dim3((unsigned)B * S), dim3(512), X3T_LDS_BYTES, (hipStream_t)stream,
                        x, N, trans, w1, b1, s1c, t1c, (const u16 *)w2x, s2c, t2c, (const u16 *)w3sx, T, S,
-                       pmax, parg, psum);
+                       pmax, parg, psum, psh);
     return pngpd_launch_status();
 }
 

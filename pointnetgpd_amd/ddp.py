@@ -31,7 +31,10 @@ class GradAverager:
         """Rank 0's parameters and buffers become everyone's (done once, and after a checkpoint load)."""
         with torch.no_grad():
             for t in list(self.model.parameters()) + list(self.model.buffers()):
-                dist.broadcast(t.data, src=0, group=self.group)
+                dist.broadcast(t, src=0, group=self.group)
+                # a collective rewrites the storage without touching the autograd version counter; the eval-mode
+                # fold cache (model/pointnet.py) is keyed by (data_ptr, _version), so bump it explicitly
+                torch.autograd.graph.increment_version(t)
 
     def sync_buffers(self):
         """Rank 0's BatchNorm buffers become everyone's: ONE broadcast of the 7,936 running statistics (flattened)

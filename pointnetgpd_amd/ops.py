@@ -36,10 +36,6 @@ def _req(t, name, shape=None):
     return t
 
 
-def set_option(name, value):
-    _lib.check(_lib.load().pngpd_set_option(name.encode(), int(value)), "set_option")
-
-
 def fold_conv_bn(weight, bias, bn_weight=None, bn_bias=None, running_mean=None, running_var=None,
                  eps=BN_EPS, layout=LAYOUT_ROWMAJOR):
     """(C,K[,1]) weight + eval-mode BatchNorm1d -> folded (Wf, bf).  gamma=None: no BN."""
@@ -62,8 +58,24 @@ def fold_conv_bn(weight, bias, bn_weight=None, bn_bias=None, running_mean=None, 
     return (wf.view(C, K) if layout == LAYOUT_ROWMAJOR else wf), bf
 
 
-def trunk_fwd_infer(x, trans, w1, b1, w2p, b2, w3p, b3, relu_last):
-    """x (B,3,N) -> pooled (B,1024).  See pngpd_trunk_fwd_infer in include/pngpd.h."""
+_WS_CACHE = {}
+
+
+def _workspace(dev, nbytes):
+    """Scratch for the per-workgroup partial maxima, cached per (device, stream) and grown on demand — the launches
+    that use it are ordered on that stream, so one buffer per stream is enough (no per-call allocation)."""
+    if nbytes == 0:
+        return None
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _WS_CACHE.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = _WS_CACHE[key] = torch.empty((nbytes + 3) // 4, device=dev, dtype=torch.float32)
+    return ws
+
+
+def trunk_fwd_infer(x, trans, w1, b1, w2p, b2, w3p, b3, relu_last, splits=0):
+    """x (B,3,N) -> pooled (B,1024).  See pngpd_trunk_fwd_infer in include/pngpd.h.  ``splits``: workgroups per
+    cloud (0 = the library's default rule); the workspace is sized for exactly the value passed to the launch."""
     lib = _lib.load()
     _req(x, "x")
     if x.dim() != 3 or x.shape[1] != 3:
@@ -75,11 +87,12 @@ def trunk_fwd_infer(x, trans, w1, b1, w2p, b2, w3p, b3, relu_last):
     _req(w2p, "w2p", (128 * 64,)); _req(b2, "b2", (128,))
     _req(w3p, "w3p", (1024 * 128,)); _req(b3, "b3", (1024,))
     out = torch.empty(B, 1024, device=x.device, dtype=torch.float32)
-    nbytes = lib.pngpd_trunk_workspace_bytes(B, N)
-    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+    S = int(splits) if splits and splits > 0 else lib.pngpd_trunk_infer_splits(B, N, 0)
+    nbytes = lib.pngpd_trunk_workspace_bytes(B, N, S)
+    ws = _workspace(x.device, nbytes)
     with _lib.device_guard(x.device):
         _lib.check(lib.pngpd_trunk_fwd_infer(_ptr(x), B, N, _ptr(trans), _ptr(w1), _ptr(b1), _ptr(w2p), _ptr(b2),
-                                             _ptr(w3p), _ptr(b3), int(bool(relu_last)), _ptr(out), _ptr(ws),
+                                             _ptr(w3p), _ptr(b3), int(bool(relu_last)), S, _ptr(out), _ptr(ws),
                                              nbytes, _stream(x)), "trunk_fwd_infer")
     return out
 
@@ -95,7 +108,7 @@ def split_pack_bf16(Wf):
     return out
 
 
-def trunk_fwd_infer_x3(x, trans, w1, b1, w2x, b2, w3x, b3, relu_last):
+def trunk_fwd_infer_x3(x, trans, w1, b1, w2x, b2, w3x, b3, relu_last, splits=0):
     """bf16x3 variant of trunk_fwd_infer (see include/pngpd.h)."""
     lib = _lib.load()
     _req(x, "x")
@@ -108,11 +121,12 @@ def trunk_fwd_infer_x3(x, trans, w1, b1, w2x, b2, w3x, b3, relu_last):
     if w2x.dtype != torch.int16 or w2x.numel() != 2 * 128 * 64 or w3x.dtype != torch.int16 or w3x.numel() != 2 * 1024 * 128:
         raise RuntimeError("w2x/w3x: expected split_pack_bf16 outputs")
     out = torch.empty(B, 1024, device=x.device, dtype=torch.float32)
-    nbytes = lib.pngpd_trunk_workspace_bytes(B, N)
-    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+    S = int(splits) if splits and splits > 0 else lib.pngpd_trunk_infer_x3_splits(B, N, 0)
+    nbytes = B * S * 1024 * 4 if S > 1 else 0
+    ws = _workspace(x.device, nbytes)
     with _lib.device_guard(x.device):
         _lib.check(lib.pngpd_trunk_fwd_infer_x3(_ptr(x), B, N, _ptr(trans), _ptr(w1), _ptr(b1), _ptr(w2x), _ptr(b2),
-                                                _ptr(w3x), _ptr(b3), int(bool(relu_last)), _ptr(out), _ptr(ws),
+                                                _ptr(w3x), _ptr(b3), int(bool(relu_last)), S, _ptr(out), _ptr(ws),
                                                 nbytes, _stream(x)), "trunk_fwd_infer_x3")
     return out
 
@@ -167,12 +181,13 @@ def _f32(t, name, shape=None):
     return _req(t, name, shape)
 
 
-def train_splits(B, N):
-    return _lib.load().pngpd_trunk_train_splits(int(B), int(N))
+TRAIN_TARGET_BLOCKS = 1024     # host-side default for the training passes (two resident rounds of 2 workgroups per CU)
 
 
-def set_train_target_blocks(v):
-    _lib.check(_lib.load().pngpd_train_set_target_blocks(int(v)), "train_set_target_blocks")
+def train_splits(B, N, target_blocks=None):
+    """Workgroups per cloud for the training passes.  A pure function of its arguments: the caller passes the
+    result to every pass AND sizes the partial buffers with it (the library keeps no tuning state)."""
+    return _lib.load().pngpd_trunk_splits(int(B), int(N), int(target_blocks or TRAIN_TARGET_BLOCKS))
 
 
 def pack_mfma_b(W, scale=None):
@@ -203,51 +218,37 @@ def cloud_moments(x):
     return mom
 
 
-def trunk_bn2_stats(x, trans, w1, b1, s1c, t1c, w2p):
+def trunk_bn2_stats(x, trans, w1, b1, s1c, t1c, w2p, S):
     B, _, N = x.shape
-    blk = B * train_splits(B, N)
-    part = torch.empty(blk, 128, 2, device=x.device, dtype=torch.float32)
-    _call("pngpd_trunk_bn2_stats", x, x, B, N, trans, w1, b1, s1c, t1c, w2p, part)
+    part = torch.empty(B * S, 128, 2, device=x.device, dtype=torch.float32)
+    _call("pngpd_trunk_bn2_stats", x, x, B, N, trans, w1, b1, s1c, t1c, w2p, int(S), part)
     return part
 
 
-def trunk_fwd_train(x, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, w3sp):
+def trunk_fwd_train(x, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, w3sp, S):
+    """-> pmax (B,S,1024), parg, psum (B*S,2,1024), psh (B*S,128)."""
     B, _, N = x.shape
-    S = train_splits(B, N)
     pmax = torch.empty(B, S, 1024, device=x.device, dtype=torch.float32)
     parg = torch.empty(B, S, 1024, device=x.device, dtype=torch.int32)
     psum = torch.empty(B * S, 2, 1024, device=x.device, dtype=torch.float32)
-    _call("pngpd_trunk_fwd_train", x, x, B, N, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, w3sp, pmax, parg, psum)
-    return pmax, parg, psum
+    psh = torch.empty(B * S, 128, device=x.device, dtype=torch.float32)
+    _call("pngpd_trunk_fwd_train", x, x, B, N, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, w3sp, int(S), pmax, parg,
+          psum, psh)
+    return pmax, parg, psum, psh
 
 
-def trunk_fwd_train_x3(x, trans, w1, b1, s1c, t1c, w2x, s2c, t2c, w3sx):
-    """bf16x3 variant of trunk_fwd_train; returns (pmax (B,S,1024), parg, psum (B*S,2,1024), S)."""
+def trunk_fwd_train_x3(x, trans, w1, b1, s1c, t1c, w2x, s2c, t2c, w3sx, S):
+    """bf16x3 variant of trunk_fwd_train; returns (pmax (B,Sx,1024), parg, psum (B*Sx,2,1024), psh (B*Sx*2,128), Sx)
+    with Sx = min(S, ceil(N/128)) (128-point tiles)."""
     B, _, N = x.shape
-    S = max(1, min(train_splits(B, N), (N + 127) // 128))
+    S = max(1, min(int(S), (N + 127) // 128))
     pmax = torch.empty(B, S, 1024, device=x.device, dtype=torch.float32)
     parg = torch.empty(B, S, 1024, device=x.device, dtype=torch.int32)
     psum = torch.empty(B * S, 2, 1024, device=x.device, dtype=torch.float32)
+    psh = torch.empty(B * S * 2, 128, device=x.device, dtype=torch.float32)
     _call("pngpd_trunk_fwd_train_x3", x, x, B, N, trans, w1, b1, s1c, t1c, w2x, s2c, t2c, w3sx, int(S), pmax, parg,
-          psum)
-    return pmax, parg, psum, S
-
-
-def h_moments_splits(B, N):
-    """Workgroups per cloud for the h-moments pass: 1 once B alone fills the 256 CUs, else enough to reach them."""
-    T = (N + 63) // 64
-    return 1 if B >= 256 else max(1, min(T, (256 + B - 1) // B))
-
-
-def trunk_h_moments(x, trans, w1, b1, s1c, t1c, w2p, s2c, t2c):
-    """-> per-workgroup partials ps2 (B*S,128,128), ps1 (B*S,64,64), psh (B*S,192); reduce over dim 0."""
-    B, _, N = x.shape
-    S = h_moments_splits(B, N)
-    ps2 = torch.empty(B * S, 128, 128, device=x.device, dtype=torch.float32)
-    ps1 = torch.empty(B * S, 64, 64, device=x.device, dtype=torch.float32)
-    psh = torch.empty(B * S, 192, device=x.device, dtype=torch.float32)
-    _call("pngpd_trunk_h_moments", x, x, B, N, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, int(S), ps2, ps1, psh)
-    return ps2, ps1, psh
+          psum, psh)
+    return pmax, parg, psum, psh, S
 
 
 def trunk_bwd_gather(x, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, idx, coef, clouds_per_range=None):
@@ -261,25 +262,54 @@ def trunk_bwd_gather(x, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, idx, coef, cloud
     return Gp
 
 
-def trunk_bwd_d(x, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, is2, nm2, Ap, cvec, w3, idx, coef):
+def trunk_bwd_d(x, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, is2, nm2, Ap, cvec, w3, idx, coef, S):
+    """-> g2t (pass D -> pass E hand-off, opaque tile layout), pa (B*S,128,2), ps2 (B*S,12,16,64)."""
     B, _, N = x.shape
-    blk = B * train_splits(B, N)
-    g2buf = torch.empty(B, N, 128, device=x.device, dtype=torch.float32)
-    pa = torch.empty(blk, 128, 2, device=x.device, dtype=torch.float32)
+    g2t = torch.empty(_lib.load().pngpd_trunk_g2t_bytes(B, N) // 4, device=x.device, dtype=torch.float32)
+    pa = torch.empty(B * S, 128, 2, device=x.device, dtype=torch.float32)
+    ps2 = torch.empty(B * S, 12 * 1024, device=x.device, dtype=torch.float32)
     _call("pngpd_trunk_bwd_d", x, x, B, N, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, is2, nm2, Ap, cvec, w3,
-          idx, coef, g2buf, pa)
-    return g2buf, pa
+          idx, coef, int(S), g2t, pa, ps2)
+    return g2t, pa, ps2
 
 
-def trunk_bwd_e(x, trans, w1, b1, s1c, t1c, w2p, is1, nm1, is2, nm2, a1m, a2m, dsc2, w2tp, g2buf):
+def g2t_to_rows(g2t, B, N):
+    """Pass D's lane-major hand-off -> (B,N,128) rows (tests / debugging only)."""
+    T = (N + 63) // 64
+    t = g2t.view(B, T, 8, 4, 2, 32, 4)                    # [b][tile][q][wave][h][j][e], value v = 4q+e
+    t = t.permute(0, 1, 3, 5, 4, 2, 6).reshape(B, T, 4, 32, 2, 32)          # [b][tile][wave][j][h][v]
+    v = torch.arange(32, device=g2t.device)
+    r = v & 15
+    row0 = (r & 3) + 8 * (r >> 2) + 32 * (v >> 4)                            # + 4*h
+    out = torch.empty(B, T, 64, 128, device=g2t.device, dtype=g2t.dtype)
+    for h in range(2):
+        out[:, :, row0 + 4 * h, :] = t[:, :, :, :, h, :].permute(0, 1, 4, 2, 3).reshape(B, T, 32, 128)
+    return out.reshape(B, T * 64, 128)[:, :N].contiguous()
+
+
+def trunk_bwd_e(x, trans, w1, b1, s1c, t1c, w2p, is1, nm1, is2, nm2, a1m, a2m, dsc2, w2tp, g2t, S):
     B, _, N = x.shape
-    S = train_splits(B, N)
     pc = torch.empty(B * S, 64, 2, device=x.device, dtype=torch.float32)
     pR = torch.empty(B, S, 64, 3, device=x.device, dtype=torch.float32)
     pW2 = torch.empty(B * S, 128, 64, device=x.device, dtype=torch.float32)
     _call("pngpd_trunk_bwd_e", x, x, B, N, trans, w1, b1, s1c, t1c, w2p, is1, nm1, is2, nm2, a1m, a2m, dsc2,
-          w2tp, g2buf, pc, pR, pW2)
+          w2tp, g2t, int(S), pc, pR, pW2)
     return pc, pR, pW2
+
+
+def reduce4(*segs):
+    """Up to four (tensor, outer, R, n) partial reductions in ONE launch -> list of (outer,n) fp64 tensors."""
+    assert 1 <= len(segs) <= 4
+    outs, args = [], []
+    ref = segs[0][0]
+    for t, outer, R, n in segs:
+        o = torch.empty(int(outer), int(n), device=t.device, dtype=torch.float64)
+        outs.append(o)
+        args += [t, int(outer), int(R), int(n), o]
+    for _ in range(4 - len(segs)):
+        args += [None, 0, 0, 0, None]
+    _call("pngpd_reduce_partials4", ref, *args)
+    return outs
 
 
 def bn1d_fwd_train(z, gamma, beta, eps, relu):

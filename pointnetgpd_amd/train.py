@@ -82,7 +82,7 @@ class TrunkTrainFn(torch.autograd.Function):
         s1c, t1c, is1, nm1 = chan1[0], chan1[1], chan1[2], chan1[3]
         # ---- pass B + BN2
         w2p = ops.pack_mfma_b(w2)
-        part = ops.trunk_bn2_stats(x, T, w1, b1c, s1c, t1c, w2p)
+        part = ops.trunk_bn2_stats(x, T, w1, b1c, s1c, t1c, w2p, S)
         chan2, stats2 = _e(dev, 4, 128), _e(dev, 256, dtype=F64)
         rm, rv, nbt = _bufs3(bufs2)
         tot2 = _reduce(part, 1, blk, 256)
@@ -95,14 +95,15 @@ class TrunkTrainFn(torch.autograd.Function):
         Sc = S
         if _TRAIN_PRECISION == "bf16x3":
             w3s = (w3 * sgn[:, None]).contiguous()
-            pmax, parg, psum, Sc = ops.trunk_fwd_train_x3(x, T, w1, b1c, s1c, t1c, ops.split_pack_bf16(w2), s2c, t2c,
-                                                          ops.split_pack_bf16(w3s))
+            pmax, parg, psum, psh, Sc = ops.trunk_fwd_train_x3(x, T, w1, b1c, s1c, t1c, ops.split_pack_bf16(w2), s2c,
+                                                               t2c, ops.split_pack_bf16(w3s), S)
         else:
             w3sp = ops.pack_mfma_b(w3, scale=sgn)
-            pmax, parg, psum = ops.trunk_fwd_train(x, T, w1, b1c, s1c, t1c, w2p, s2c, t2c, w3sp)
+            pmax, parg, psum, psh = ops.trunk_fwd_train(x, T, w1, b1c, s1c, t1c, w2p, s2c, t2c, w3sp, S)
         stats3 = _e(dev, 2048, dtype=F64)
         rm, rv, nbt = _bufs3(bufs3)
-        tot3 = _reduce(psum, 1, B * Sc, 2048)
+        # the pass's two partial buffers in one launch: sum / sum of squares of z3s, and the column sums of h2
+        tot3, sh = ops.reduce4((psum, 1, B * Sc, 2048), (psh, 1, psh.shape[0], 128))
         _call("pngpd_bn3_finalize", x, tot3, B, N, b3c, g3c, float(momentum), rm, rv, nbt, stats3)
         _bump(bufs3)
         pooled, idx, zhat = _e(dev, B, 1024), _e(dev, B, 1024, dtype=torch.int32), _e(dev, B, 1024)
@@ -110,13 +111,13 @@ class TrunkTrainFn(torch.autograd.Function):
               idx, zhat)
         ctx.relu_last, ctx.eps, ctx.has_t, ctx.S = relu_last, eps, T is not None, S
         ctx.save_for_backward(x, T if T is not None else x.new_empty(0), w1, b1c, g1c, w2, g2c, w3, g3c, mom,
-                              chan1, stats1, chan2, stats2, stats3, pooled, idx, zhat, w2p)
+                              chan1, stats1, chan2, stats2, stats3, pooled, idx, zhat, w2p, sh)
         return pooled
 
     @staticmethod
     def backward(ctx, dp):
         (x, T, w1, b1c, g1c, w2, g2c, w3, g3c, mom, chan1, stats1, chan2, stats2, stats3, pooled, idx, zhat,
-         w2p) = ctx.saved_tensors
+         w2p, sh) = ctx.saved_tensors
         T = T if ctx.has_t else None
         eps, S = float(ctx.eps), ctx.S
         B, _, N = x.shape
@@ -124,40 +125,39 @@ class TrunkTrainFn(torch.autograd.Function):
         blk = B * S
         s1c, t1c, is1, nm1 = chan1[0], chan1[1], chan1[2], chan1[3]
         s2c, t2c, is2, nm2 = chan2[0], chan2[1], chan2[2], chan2[3]
-        # ---- BN3 affine grads, sparse-term weights, dense-correction scalars
+        # ---- BN3 affine grads, sparse-term weights, dense-correction scalars, pass-D operands
         dp = dp.contiguous()
         coef, dg3, dbe3, m12 = _e(dev, B, 1024), _e(dev, 1024), _e(dev, 1024), _e(dev, 2048, dtype=F64)
         _call("pngpd_bn3_bwd_prep", x, dp, pooled, zhat, B, N, g3c, stats3, eps, int(ctx.relu_last), coef, dg3,
               dbe3, m12)
-        # ---- hidden-activation moments + arg-extremum gather, reduced in fp64
-        ps2, ps1, psh = ops.trunk_h_moments(x, T, w1, b1c, s1c, t1c, w2p, s2c, t2c)
-        S2 = _reduce(ps2, 1, ps2.shape[0], 128 * 128)[0]
-        sh = _reduce(psh, 1, psh.shape[0], 192)[0][:128]
+        Ap, cvec = _e(dev, 128 * 128), _e(dev, 128)
+        _call("pngpd_a_cvec_finalize", x, sh, B, N, w3, g3c, stats3, m12, eps, Ap, cvec)
+        # ---- arg-extremum gather (sparse term of dW3) and pass D (g2, its BN2 sums, and the Gram of h2)
         Gp = ops.trunk_bwd_gather(x, T, w1, b1c, s1c, t1c, w2p, s2c, t2c, idx, coef)
-        G = _reduce(Gp, 1, Gp.shape[0], 1024 * 128)[0]
-        dW3, Ap, cvec = _e(dev, 1024, 128), _e(dev, 128 * 128), _e(dev, 128)
-        _call("pngpd_dw3_finalize", x, G, S2, sh, B, N, w3, g3c, stats3, m12, eps, dW3, Ap, cvec)
-        # ---- pass D
-        g2buf, pa = ops.trunk_bwd_d(x, T, w1, b1c, s1c, t1c, w2p, s2c, t2c, is2, nm2, Ap, cvec, w3, idx, coef)
-        a12 = _reduce(pa, 1, blk, 256)[0]
+        g2t, pa, ps2 = ops.trunk_bwd_d(x, T, w1, b1c, s1c, t1c, w2p, s2c, t2c, is2, nm2, Ap, cvec, w3, idx, coef, S)
+        G, a12, S2c = ops.reduce4((Gp, 1, Gp.shape[0], 1024 * 128), (pa, 1, blk, 256), (ps2, 1, blk, 12 * 1024))
+        dW3 = _e(dev, 1024, 128)
+        _call("pngpd_dw3_finalize", x, G, S2c, sh, B, N, w3, g3c, stats3, m12, eps, dW3)
         dg2, dbe2, evec = _e(dev, 128), _e(dev, 128), _e(dev, 3, 128)
         _call("pngpd_bwd_e_prep", x, a12, B, N, g2c, stats2, eps, dg2, dbe2, evec)
         # ---- pass E (also contracts dW2 = sum_points dz2 h1^T on the MFMA)
         w2tp = ops.pack_mfma_b(w2.t().contiguous())
         pc, pR, pW2 = ops.trunk_bwd_e(x, T, w1, b1c, s1c, t1c, w2p, is1, nm1, is2, nm2, evec[0], evec[1], evec[2],
-                                      w2tp, g2buf)
-        dW2 = _reduce(pW2, 1, blk, 128 * 64)[0].to(torch.float32)
-        c12 = _reduce(pc, 1, blk, 128)[0]
-        Rb = _reduce(pR, B, S, 192)
+                                      w2tp, g2t, S)
+        dW2_64, c12, Rb = ops.reduce4((pW2, 1, blk, 128 * 64), (pc, 1, blk, 128), (pR, B, S, 192))
+        dW2 = dW2_64[0].to(torch.float32)
         dW1, dg1, dbe1 = _e(dev, 64, 3), _e(dev, 64), _e(dev, 64)
         dT = _e(dev, B, 3, 3) if (T is not None and ctx.needs_input_grad[1]) else None
         _call("pngpd_dw1_finalize", x, Rb, T, mom, B, N, c12, stats1, w1, b1c, g1c, eps, dW1, dg1, dbe1, dT)
         if DEBUG_STASH is not None:
-            DEBUG_STASH.update(dict(dp=dp.to(F64), dg3=dg3, dbe3=dbe3, S2=S2.view(128, 128), sh=sh,
-                                    G=G.view(1024, 128), cvec=cvec, a1=a12.view(128, 2)[:, 0],
-                                    a2=a12.view(128, 2)[:, 1], c1=c12.view(64, 2)[:, 0],
-                                    c2=c12.view(64, 2)[:, 1], Rb=Rb.view(B, 64, 3), dW1=dW1, dW2=dW2, dW3=dW3, dT=dT,
-                                    g2buf=g2buf, idx=idx, coef=coef,
+            from .ops import g2t_to_rows
+            S2full = _s2_full(S2c[0], dev)
+            a12v, c12v = a12[0], c12[0]
+            DEBUG_STASH.update(dict(dp=dp.to(F64), dg3=dg3, dbe3=dbe3, S2=S2full, sh=sh[0],
+                                    G=G[0].view(1024, 128), cvec=cvec, a1=a12v.view(128, 2)[:, 0],
+                                    a2=a12v.view(128, 2)[:, 1], c1=c12v.view(64, 2)[:, 0],
+                                    c2=c12v.view(64, 2)[:, 1], Rb=Rb.view(B, 64, 3), dW1=dW1, dW2=dW2, dW3=dW3, dT=dT,
+                                    g2buf=g2t_to_rows(g2t, B, N), idx=idx, coef=coef,
                                     A=Ap.view(4, 16, 2, 32, 4).permute(0, 3, 1, 2, 4).reshape(128, 128)))
         z = lambda n: torch.zeros(n, device=dev, dtype=torch.float32)
         return (None, dT,
@@ -165,6 +165,23 @@ class TrunkTrainFn(torch.autograd.Function):
                 dW2.view(128, 64, 1), z(128), dg2, dbe2,
                 dW3.view(1024, 128, 1), z(1024), dg3, dbe3,
                 None, None, None, None, None, None)
+
+
+def _s2_full(S2c, dev):
+    """The 12 accumulator blocks pass D keeps -> the full symmetric 128x128 second-moment matrix (debug/tests)."""
+    blocks = S2c.view(4, 3, 16, 2, 32)                          # [wave][q][r][h][j]
+    r = torch.arange(16, device=dev)
+    out = torch.zeros(128, 128, device=dev, dtype=S2c.dtype)
+    for w in range(4):
+        for q in range(3 if w < 2 else 2):
+            a, b = w, (w + q) % 4
+            blk = torch.empty(32, 32, device=dev, dtype=S2c.dtype)
+            for h in range(2):
+                rows = (r & 3) + 8 * (r >> 2) + 4 * h
+                blk[rows] = blocks[w, q, :, h, :]
+            out[a * 32:(a + 1) * 32, b * 32:(b + 1) * 32] = blk
+            out[b * 32:(b + 1) * 32, a * 32:(a + 1) * 32] = blk.t()
+    return out
 
 
 def _pad_cols(t, mult=8):

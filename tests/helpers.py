@@ -59,3 +59,24 @@ def grad_tol(batch, r32):
     plus the size of ONE such flip.  Tight kernel-level checks (1e-4..2e-3, no flip ambiguity) live in
     test_trunk_train_vs_prototype / test_trunk_backward_intermediates."""
     return 4 * r32 + 2e-3 + 2.5 / (batch * 512) ** 0.5
+
+
+def oracle_train_step_on_device(sd, x, y, dtype, device):
+    """The oracle's train step (``oracle.pointnet_oracle.train_step_torch`` — autograd over the reference's op
+    sequence) executed through ATen ON THE GPU, for cases too large for the host (B = N = 1024 in fp64 holds
+    ~90 GB of activations; it fits the 288 GB of HBM).  Test-only checker.  1x1 convolutions are dispatched as
+    matmuls there (MIOpen has no fp64 convolution); see ``_conv1x1_torch``."""
+    from oracle import pointnet_oracle as po
+    old = po.CONV_AS_MATMUL
+    po.CONV_AS_MATMUL = True
+    try:
+        sdd = {k: v.to(device) for k, v in sd.items()}
+        loss, logp, trans, grads, stats = po.train_step_torch(sdd, x.to(device), y.to(device), dtype=dtype)
+    finally:
+        po.CONV_AS_MATMUL = old
+    torch.cuda.synchronize()
+    out = (loss.cpu(), logp.cpu(), trans.cpu(), {k: v.cpu() for k, v in grads.items()},
+           {k: v.cpu() for k, v in stats.items()})
+    del sdd, loss, logp, trans, grads, stats
+    torch.cuda.empty_cache()
+    return out

@@ -35,6 +35,24 @@ def test_ctypes_table_matches_header():
     assert sorted(_lib.SIGNATURES) == header_functions()
 
 
+def header_arity():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for name, params in re.findall(r"\b(pngpd_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", src):
+        params = params.strip()
+        out[name] = 0 if params in ("", "void") else params.count(",") + 1
+    return out
+
+
+def test_ctypes_arity_matches_header():
+    """Every ctypes argtypes list has exactly as many entries as the C prototype has parameters."""
+    from pointnetgpd_amd import _lib
+    ar = header_arity()
+    bad = {n: (len(a), ar.get(n)) for n, (_, a) in _lib.SIGNATURES.items() if len(a) != ar.get(n)}
+    assert not bad, bad
+
+
 def test_library_loads_and_reports_abi():
     from pointnetgpd_amd import _lib
     lib = _lib.load()
@@ -42,9 +60,17 @@ def test_library_loads_and_reports_abi():
     assert lib.pngpd_strerror(0) == b"ok"
     assert lib.pngpd_strerror(1) == b"invalid argument"
     # argument validation happens before any launch, so it is testable without a GPU
-    assert lib.pngpd_trunk_fwd_infer(None, 1, 1, None, None, None, None, None, None, None, 0, None, None, 0, None) == 1
+    assert lib.pngpd_trunk_fwd_infer(None, 1, 1, None, None, None, None, None, None, None, 0, 0, None, None, 0, None) == 1
     assert lib.pngpd_fc_fwd(None, 1, 8, None, None, 1, 0, None, None) == 1
-    assert lib.pngpd_trunk_workspace_bytes(4, 100) == 4 * 2 * 1024 * 4
+    # splits are pure functions of their arguments (no process-global tuning state) and size the workspace
+    assert lib.pngpd_trunk_infer_splits(4, 100, 0) == 2                    # ceil(100/64) tiles bound the default
+    assert lib.pngpd_trunk_infer_splits(1024, 1024, 0) == 2 and lib.pngpd_trunk_infer_splits(1024, 1024, 1024) == 1
+    assert lib.pngpd_trunk_workspace_bytes(4, 100, 2) == 4 * 2 * 1024 * 4
+    assert lib.pngpd_trunk_workspace_bytes(4, 100, 0) == 4 * 2 * 1024 * 4   # 0 -> the default rule
+    assert lib.pngpd_trunk_workspace_bytes(4, 100, 1) == 0                  # one workgroup per cloud: no scratch
+    assert lib.pngpd_trunk_splits(1024, 1024, 0) == 1 and lib.pngpd_trunk_splits(16, 1024, 0) == 16
+    assert lib.pngpd_trunk_splits(320, 64, 0) == 1 and lib.pngpd_trunk_splits(256, 128, 2048) == 2
+    assert lib.pngpd_trunk_g2t_bytes(3, 100) == 3 * 2 * 64 * 128 * 4
 
 
 def test_cuda_ops_refuse_cpu_tensors():
@@ -83,8 +109,13 @@ def test_argument_validation_of_every_family():
     assert lib.pngpd_crop_resample(p, 0, p, 1, p, p, 16, 8, 2, 20, 0, None, p, p, None) == INV     # mode not in {0,1}
     assert lib.pngpd_crop_resample(p, 0, p, 1, p, p, 1 << 20, 8, 1, 20, 0, None, p, p, None) == UNSUP  # LDS bound
     # training passes
-    assert lib.pngpd_trunk_h_moments(p, 4, 100, None, p, p, p, p, p, p, p, 0, p, p, p, None) == INV    # S < 1
-    assert lib.pngpd_trunk_h_moments(p, 4, 100, None, p, p, p, p, p, p, p, 3, p, p, p, None) == INV    # S > ceil(N/64)
+    assert lib.pngpd_trunk_bn2_stats(p, 4, 100, None, p, p, p, p, p, 0, p, None) == INV               # S < 1
+    assert lib.pngpd_trunk_bn2_stats(p, 4, 100, None, p, p, p, p, p, 3, p, None) == INV               # S > ceil(N/64)
+    assert lib.pngpd_trunk_fwd_train(p, 4, 100, None, p, p, p, p, p, p, p, p, 3, p, p, p, p, None) == INV
+    assert lib.pngpd_trunk_bwd_d(p, 4, 100, None, *([p] * 14), 3, p, p, p, None) == INV
+    assert lib.pngpd_trunk_bwd_e(p, 4, 100, None, *([p] * 14), 0, p, p, p, None) == INV
+    assert lib.pngpd_reduce_partials4(*([None, 0, 0, 0, None] * 4), None) == INV                   # no segment
+    assert lib.pngpd_reduce_partials4(p, 1, 0, 8, p, *([None, 0, 0, 0, None] * 3), None) == INV    # R == 0
     assert lib.pngpd_fold_conv_bn(p, p, None, None, None, None, 1e-5, 30, 8, 1, p, p, None) == INV      # MFMA_B needs C % 32 == 0
     assert lib.pngpd_fc_fwd(p, 4, 12, p, p, 3, 0, p, None) == INV                                  # K % 8 != 0
     assert lib.pngpd_fc_fwd(p, 4, 16, p, p, 40, 3, p, None) == INV                                 # log_softmax needs Nout <= 32

@@ -1,0 +1,122 @@
+"""Data-parallel training on the HIP path with world_size 2 (SURVEY.md §8e parity recipe).
+
+A 1-GPU box is all the test tier has, so both ranks run on cuda:0 and the collectives go over gloo (which stages
+CUDA tensors through the host).  What is exercised is everything except the RCCL transport itself: process-group
+setup from torchrun-style environment variables, rank-0 parameter broadcast, per-replica BatchNorm statistics, the
+flat gradient bucket, and the HIP kernels running concurrently in two processes.
+
+Checks (per §8e): each rank's local gradient vs the fp64 oracle run on THAT rank's shard; the all-reduced gradient
+vs the mean of the oracle's per-shard gradients; identical averaged gradients and parameters on both ranks; and a
+2-rank launch of ``bench.py --gpus 2`` through its own spawner.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, out_dir, B_per, N, k):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    import torch.nn.functional as F
+    from pointnetgpd_amd import ddp
+    from tests.helpers import build_model, synth_cloud
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo")
+    m = build_model(N, k, 500 + rank, 5200 + rank).train().to(dev)      # different replicas on purpose
+    avg = ddp.GradAverager(m)                                            # -> rank 0's replica everywhere
+    x_all = synth_cloud(world * B_per, N, 4242, "box")
+    y_all = (torch.arange(world * B_per) * 5 % k).long()
+    xs, ys = x_all[rank * B_per:(rank + 1) * B_per].to(dev), y_all[rank * B_per:(rank + 1) * B_per].to(dev)
+    avg.sync_buffers()
+    sd0 = {n: t.detach().cpu().clone() for n, t in m.state_dict().items()}   # the synced replica
+    logp, _ = m(xs)
+    loss = F.nll_loss(logp, ys)
+    loss.backward()
+    assert "libpngpd.so" in open("/proc/self/maps").read()
+    local = {n: p.grad.detach().cpu().clone() for n, p in m.named_parameters()}
+    avg.average_gradients()
+    torch.cuda.synchronize()
+    torch.save(dict(local=local, avg={n: p.grad.detach().cpu().clone() for n, p in m.named_parameters()}, sd0=sd0,
+                    loss=loss.item(), logp=logp.detach().cpu()), os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _rel(a, b):
+    a = a.double().flatten(); b = b.double().flatten()
+    return (a - b).norm().item() / max(b.norm().item(), 1e-30)
+
+
+def test_two_ranks_hip_path_vs_oracle(tmp_path, cuda_device):
+    from oracle import pointnet_oracle as po
+    from tests.helpers import synth_cloud, grad_tol
+    world, port, B_per, N, k = 2, _free_port(), 12, 200, 3
+    mp.start_processes(_worker, args=(world, port, str(tmp_path), B_per, N, k), nprocs=world, join=True,
+                       start_method="spawn")
+    res = [torch.load(tmp_path / f"r{r}.pt") for r in range(world)]
+    for n in res[0]["sd0"]:
+        assert torch.equal(res[0]["sd0"][n], res[1]["sd0"][n]), n          # rank 0's replica was broadcast
+    x_all = synth_cloud(world * B_per, N, 4242, "box")
+    y_all = (torch.arange(world * B_per) * 5 % k).long()
+    g64, tols = [], []
+    for r in range(world):
+        xs, ys = x_all[r * B_per:(r + 1) * B_per], y_all[r * B_per:(r + 1) * B_per]
+        loss_ref, logp_ref, _, grads, _ = po.train_step_torch(res[r]["sd0"], xs, ys, dtype=torch.float64)
+        _, _, _, grads32, _ = po.train_step_torch(res[r]["sd0"], xs, ys, dtype=torch.float32)
+        g64.append(grads)
+        tols.append({n: grad_tol(B_per, _rel(grads32[n], grads[n])) for n in grads if grads[n].norm().item() >= 1e-9})
+        assert abs(res[r]["loss"] - loss_ref.item()) < 1e-3
+        assert (res[r]["logp"].double() - logp_ref).abs().max().item() < 1e-3
+        for n, g in res[r]["local"].items():                                # each rank vs the oracle on ITS shard
+            if grads[n].norm().item() < 1e-9:
+                assert g.abs().max().item() < 1e-4, n
+                continue
+            assert _rel(g, grads[n]) < tols[r][n], (r, n)
+    for n in res[0]["avg"]:
+        assert torch.equal(res[0]["avg"][n], res[1]["avg"][n]), n          # identical after the all-reduce
+        mean_local = (res[0]["local"][n] + res[1]["local"][n]) / 2
+        assert torch.allclose(res[0]["avg"][n], mean_local, atol=1e-6, rtol=1e-5), n
+        ref = (g64[0][n] + g64[1][n]) / 2                                   # mean of the oracle's per-shard gradients
+        if n not in tols[0] or n not in tols[1]:
+            continue
+        # the error of the mean is at most the mean of the per-shard errors (absolute bound)
+        bound = 0.5 * sum(tols[r][n] * g64[r][n].double().norm().item() for r in range(world))
+        err = (res[0]["avg"][n].double() - ref).norm().item()
+        assert err <= bound, (n, err, bound)
+    # per-replica BatchNorm statistics: the two shards' local gradients are genuinely different
+    assert _rel(res[0]["local"]["fc1.weight"], res[1]["local"]["fc1.weight"]) > 1e-3
+
+
+def test_bench_self_spawns_two_ranks(cuda_device):
+    """``python bench.py --gpus 2`` from a plain shell (no torchrun): bench.py launches its own ranks.  On this 1-GPU
+    box the debug switch maps both ranks to cuda:0 over gloo; the JSON line must still report 2 ranks and carry the
+    inference and training legs."""
+    env = dict(os.environ, PNGPD_BENCH_DEBUG_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--batch", "64", "--num-points", "256", "--no-cpu-baseline", "--no-fast", "--min-seconds", "0"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["collective_ranks"] == 2
+    assert res["config"]["batch_per_gpu"] == 64 and res["value"] > 0
+    assert res["train"]["weak"]["value"] > 0 and res["train"]["strong"]["value"] > 0
+    assert "all-reduce" in res["train"]["step"]
