@@ -139,6 +139,109 @@ __device__ __forceinline__ void k128_compute(const float *tile, const f32x4 (&wf
     }
 }
 
+// Alternative tile layout (inference trunk, training pass C): LDS tiles UNPADDED and XOR-swizzled at float4 granularity instead of using the
+// +4-float row pad of pngpd_tile.h: element (row, col) lives at row*W + (((col>>2) ^ (row&15))<<2) + (col&3).
+// A wave's ds_read_b128 A-fragment read (lane i -> row i, one float4 column) then hits 16 distinct 16-B
+// slots per 16-lane group (conflict-free) and the footprint drops to 54,016 B -> 3 workgroups per CU.
+#define I1S 64
+#define I2S 128
+
+__device__ __forceinline__ int swz(int row, int col, int width) {
+    return row * width + ((((col >> 2) ^ (row & 15)) << 2) | (col & 3));
+}
+
+// K-contraction of a swizzled [64][W] tile against register-resident MFMA_B fragments (NKB k-blocks).
+template <int W, int NKB>
+__device__ __forceinline__ void swz_compute(const float *tile, const f32x4 (&wf)[NKB], const Lane &L,
+                                            f32x16 &acc0, f32x16 &acc1) {
+    const float *r0 = tile + L.j * W, *r1 = tile + (32 + L.j) * W;
+    const int sx = L.j & 15;   // (32 + j) & 15 == j & 15
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    // A fragments double-buffered in registers: the two ds_read_b128 of k-block kb+1 are in flight while the
+    // eight MFMAs of k-block kb issue (hipcc otherwise re-uses the registers and waits lgkmcnt(0) every block)
+    f32x4 a0 = *(const f32x4 *)(r0 + (((0 * 2 + L.h) ^ sx) << 2));
+    f32x4 a1 = *(const f32x4 *)(r1 + (((0 * 2 + L.h) ^ sx) << 2));
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        f32x4 n0 = a0, n1 = a1;
+        if (kb + 1 < NKB) {
+            const int c4 = (((kb + 1) * 2 + L.h) ^ sx) << 2;
+            n0 = *(const f32x4 *)(r0 + c4);
+            n1 = *(const f32x4 *)(r1 + c4);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            acc0 = mfma32(a0[t], wf[kb][t], acc0);
+            acc1 = mfma32(a1[t], wf[kb][t], acc1);
+        }
+        a0 = n0; a1 = n1;
+    }
+}
+
+
+// ---- software-pipelined variants for the padded layout (training passes B, D, E, gather) -------------------
+// Layer-2 weight fragments of channel block cb (8 coalesced 1-KiB loads); issue early, consume after the barrier.
+__device__ __forceinline__ void load_w2frag(f32x4 (&wf)[8], const float *__restrict__ w2p, int cb, const Lane &L) {
+    const f32x4 *wp = (const f32x4 *)w2p + (size_t)(cb * 8) * 64 + L.lane;
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) wf[kb] = wp[kb * 64];
+}
+
+// Layer 2 on register-resident weights with the A fragments double-buffered (the ds_read_b128 pair of k-block
+// kb+1 is in flight while the eight MFMAs of k-block kb issue).
+__device__ __forceinline__ void layer2_compute(const float *h1, const f32x4 (&wf)[8], const Lane &L,
+                                               f32x16 &acc0, f32x16 &acc1) {
+    const float *a0p = h1 + L.j * H1S + L.h * 4;
+    const float *a1p = h1 + (32 + L.j) * H1S + L.h * 4;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    f32x4 a0 = *(const f32x4 *)a0p, a1 = *(const f32x4 *)a1p;
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+        f32x4 n0 = a0, n1 = a1;
+        if (kb + 1 < 8) { n0 = *(const f32x4 *)(a0p + (kb + 1) * 8); n1 = *(const f32x4 *)(a1p + (kb + 1) * 8); }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            acc0 = mfma32(a0[t], wf[kb][t], acc0);
+            acc1 = mfma32(a1[t], wf[kb][t], acc1);
+        }
+        a0 = n0; a1 = n1;
+    }
+}
+
+// K = 128 product accumulated INTO acc0/acc1 (not zeroed here), weights streamed from L2 through a 4-deep register
+// ring (fragment kb+4 is requested when fragment kb is consumed: ~2,000 MFMA cycles of cover) and the A fragments
+// double-buffered.  Both point blocks (NPB = 2) or only block pb (NPB = 1, acc1 unused).
+template <int NPB>
+__device__ __forceinline__ void k128_stream(const float *tile, const float *__restrict__ wp128, int cb, int pb,
+                                            const Lane &L, f32x16 &acc0, f32x16 &acc1) {
+    const f32x4 *wp = (const f32x4 *)wp128 + (size_t)(cb * 16) * 64 + L.lane;
+    const float *a0p = tile + (pb * 32 + L.j) * H2S + L.h * 4;
+    const float *a1p = tile + (32 + L.j) * H2S + L.h * 4;
+    f32x4 wq[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wq[i] = wp[i * 64];
+    f32x4 a0 = *(const f32x4 *)a0p, a1 = a0;
+    if (NPB == 2) a1 = *(const f32x4 *)a1p;
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) {
+        f32x4 n0 = a0, n1 = a1;
+        if (kb + 1 < 16) {
+            n0 = *(const f32x4 *)(a0p + (kb + 1) * 8);
+            if (NPB == 2) n1 = *(const f32x4 *)(a1p + (kb + 1) * 8);
+        }
+        const f32x4 wv = wq[kb & 3];
+        if (kb + 4 < 16) wq[kb & 3] = wp[(kb + 4) * 64];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            acc0 = mfma32(a0[t], wv[t], acc0);
+            if (NPB == 2) acc1 = mfma32(a1[t], wv[t], acc1);
+        }
+        a0 = n0; a1 = n1;
+    }
+}
+
 // Split of a cloud's T tiles over S workgroups.
 __device__ __forceinline__ void tile_range(int s, int S, int T, int &t0, int &t1) {
     t0 = (int)(((long)s * T) / S);

@@ -72,13 +72,15 @@ __global__ __launch_bounds__(256, 2) void trunk_bn2_stats_kernel(
         for (int i = 0; i < 9; ++i) tm[i] = trans[(size_t)b * 9 + i];
     }
     float sum = 0.f, sq = 0.f;
+    f32x4 w2f[8];   // this wave's layer-2 weight fragments stay in registers for the whole kernel
+    load_w2frag(w2f, P.w2p, L.wave, L);
     for (int tile = t0; tile < t1; ++tile) {
         stage_points(xb, N, tile, has_t, tm, xs, nullptr, L.tid);
         __syncthreads();
         layer1_tile(xs, P.w1, P.b1, P.s1c, P.t1c, h1, L);
         __syncthreads();
         f32x16 a0, a1;
-        layer2_mfma(h1, P.w2p, L.wave, L, a0, a1);
+        layer2_compute(h1, w2f, L, a0, a1);
         const int nbase = tile * TP;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -103,16 +105,18 @@ __global__ __launch_bounds__(256, 2) void trunk_bn2_stats_kernel(
 // argmax over the workgroup's tiles; per channel sum / sum of squares over valid points.
 //   pmax/parg : [blk][1024]      psum : [blk][2][1024]
 // ---------------------------------------------------------------------------------------
-#define TRAIN_MAIN_LDS_FLOATS (TP * H1S + TP * H2S + 3 * TP + 4 * 1024)
+#define TRAIN_MAIN_LDS_FLOATS (TP * I1S + TP * I2S + 3 * TP + 4 * 1024)
 
+// Same skeleton as trunk_infer_kernel (pngpd_trunk_infer.hip): unpadded XOR-swizzled LDS tiles, A fragments and
+// layer-3 weight fragments double-buffered in registers, the tile's points fetched one tile ahead.
 __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
     const float *__restrict__ x, int N, const float *__restrict__ trans, TrainChan P,
     const float *__restrict__ w3sp, int T, int S,
     float *__restrict__ pmax, int *__restrict__ parg, float *__restrict__ psum, float *__restrict__ psh) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *h1 = smem;
-    float *h2 = h1 + TP * H1S;
-    float *xs = h2 + TP * H2S;
+    float *h1 = smem;                 // [TP][I1S] swizzled
+    float *h2 = h1 + TP * I1S;        // [TP][I2S] swizzled
+    float *xs = h2 + TP * I2S;
     float *rm = xs + 3 * TP;          // [1024] running max
     int *ri = (int *)(rm + 1024);     // [1024] running argmax (point index)
     float *ss = (float *)(ri + 1024); // [1024] sum
@@ -130,32 +134,64 @@ __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
 #pragma unroll
         for (int i = 0; i < 9; ++i) tm[i] = trans[(size_t)b * 9 + i];
     }
-    float hsum = 0.f;   // sum over this workgroup's valid points of h2[.][wave*32 + j] (rows of this half-wave)
+    float px0 = 0.f, px1 = 0.f, px2 = 0.f;
+    if (L.tid < TP) {
+        int n = t0 * TP + L.tid; n = n < N ? n : N - 1;
+        px0 = xb[n]; px1 = xb[N + n]; px2 = xb[2 * N + n];
+    }
+    const int cb2 = L.wave, c2 = cb2 * 32 + L.j;
+    const float sc2 = P.s2c[c2], sh2 = P.t2c[c2];
+    float hsum = 0.f;   // sum over this workgroup's valid points of h2[.][c2] (rows of this half-wave)
     for (int tile = t0; tile < t1; ++tile) {
-        stage_points(xb, N, tile, has_t, tm, xs, nullptr, L.tid);
+        if (L.tid < TP) {
+            float x0 = px0, x1 = px1, x2 = px2;
+            if (has_t) {
+                x0 = fmaf(px2, tm[6], fmaf(px1, tm[3], px0 * tm[0]));
+                x1 = fmaf(px2, tm[7], fmaf(px1, tm[4], px0 * tm[1]));
+                x2 = fmaf(px2, tm[8], fmaf(px1, tm[5], px0 * tm[2]));
+            }
+            xs[L.tid] = x0; xs[TP + L.tid] = x1; xs[2 * TP + L.tid] = x2;
+            if (tile + 1 < t1) {
+                int n = (tile + 1) * TP + L.tid; n = n < N ? n : N - 1;
+                px0 = xb[n]; px1 = xb[N + n]; px2 = xb[2 * N + n];
+            }
+        }
         __syncthreads();
-        layer1_tile(xs, P.w1, P.b1, P.s1c, P.t1c, h1, L);
+        {   // layer 1 (3 -> 64) + batch-stat BN affine + ReLU, VALU: thread = (point = lane, 16-channel group = wave)
+            const int p = L.lane;
+            const float x0 = xs[p], x1 = xs[TP + p], x2 = xs[2 * TP + p];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = L.wave * 16 + g * 4 + e;   // wave-uniform -> scalar loads
+                    const float z = fmaf(P.w1[c * 3 + 2], x2, fmaf(P.w1[c * 3 + 1], x1, fmaf(P.w1[c * 3], x0, P.b1[c])));
+                    v[e] = fmaxf(fmaf(z, P.s1c[c], P.t1c[c]), 0.f);
+                }
+                *(f32x4 *)(h1 + swz(p, L.wave * 16 + g * 4, I1S)) = v;
+            }
+        }
         __syncthreads();
         const int nbase = tile * TP;
         const bool full = nbase + TP <= N;
-        {
+        {   // layer 2 (64 -> 128), MFMA
             f32x16 a0, a1;
-            const int cb = L.wave;
-            layer2_mfma(h1, P.w2p, cb, L, a0, a1);
-            const float sc = P.s2c[cb * 32 + L.j], sh = P.t2c[cb * 32 + L.j];
+            f32x4 w2f[8];
+            load_w2frag(w2f, P.w2p, cb2, L);
+            swz_compute<I1S, 8>(h1, w2f, L, a0, a1);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mfma_row(r, L.lane);
-                const float v0 = fmaxf(fmaf(a0[r], sc, sh), 0.f), v1 = fmaxf(fmaf(a1[r], sc, sh), 0.f);
-                h2[row * H2S + cb * 32 + L.j] = v0;
-                h2[(32 + row) * H2S + cb * 32 + L.j] = v1;
+                const float v0 = fmaxf(fmaf(a0[r], sc2, sh2), 0.f), v1 = fmaxf(fmaf(a1[r], sc2, sh2), 0.f);
+                h2[swz(row, c2, I2S)] = v0;
+                h2[swz(32 + row, c2, I2S)] = v1;
                 // column sums of h2 (the mean of h2 enters cvec of pass D and the closed-form dW3)
                 hsum += (full || nbase + row < N) ? v0 : 0.f;
                 hsum += (full || nbase + 32 + row < N) ? v1 : 0.f;
             }
         }
         __syncthreads();
-        // layer-3 weight fragments double-buffered in registers (see trunk_infer_kernel)
         auto reduce_block = [&](int cb, const f32x16 &a0, const f32x16 &a1) {
             // max / argmax over this lane's 32 rows (ascending row order, strict >: first wins)
             float m = a0[0]; int am = mfma_row(0, L.lane);
@@ -190,16 +226,18 @@ __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
             const int cbA = L.wave + 8 * cp, cbB = cbA + 4, cbN = L.wave + ((8 * cp + 8) & 31);
             f32x16 a0, a1;
             load_wfrag(wb, w3sp, cbB, L);
-            k128_compute(h2, wa, L, a0, a1);
+            swz_compute<I2S, 16>(h2, wa, L, a0, a1);
             reduce_block(cbA, a0, a1);
             load_wfrag(wa, w3sp, cbN, L);
-            k128_compute(h2, wb, L, a0, a1);
+            swz_compute<I2S, 16>(h2, wb, L, a0, a1);
             reduce_block(cbB, a0, a1);
         }
+        // no end-of-tile barrier: the next tile's xs/h1 writes do not alias h2, and the barrier before its layer 2
+        // orders the h2 rewrite after every wave's layer-3 reads (as in trunk_infer_kernel).
     }
     hsum += __shfl_xor(hsum, 32);
     if (L.h == 0) {
-        psh[(size_t)blockIdx.x * 128 + L.wave * 32 + L.j] = hsum;
+        psh[(size_t)blockIdx.x * 128 + c2] = hsum;
 #pragma unroll
         for (int ci = 0; ci < 8; ++ci) {
             const int c = (L.wave + 4 * ci) * 32 + L.j;
@@ -233,12 +271,25 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_gather_kernel(
 #pragma unroll
     for (int i = 0; i < 32; ++i) g[i] = 0.f;
     const int k = L.tid & 127, rh = L.tid >> 7;
-    for (int b = b0; b < b1; ++b) {
-        if (L.tid < TP) {
+    f32x4 w2f[8];
+    load_w2frag(w2f, P.w2p, L.wave, L);
+    // the arg-max points of cloud b+1 (a dependent idx -> x gather) are fetched while cloud b is processed
+    float nx0 = 0.f, nx1 = 0.f, nx2 = 0.f, ncf = 0.f;
+    auto fetch = [&](int b) {
+        if (L.tid < TP && b < b1) {
             const int c = cc * 64 + L.tid;
             const int n = idx[(size_t)b * 1024 + c];
             const float *xb = x + (size_t)b * 3 * N;
-            float x0 = xb[n], x1 = xb[N + n], x2 = xb[2 * N + n];
+            nx0 = xb[n]; nx1 = xb[N + n]; nx2 = xb[2 * N + n];
+            ncf = coef[(size_t)b * 1024 + c];
+        }
+    };
+    fetch(b0);
+    for (int b = b0; b < b1; ++b) {
+        if (L.tid < TP) {
+            float x0 = nx0, x1 = nx1, x2 = nx2;
+            const float cfv = ncf;
+            fetch(b + 1);
             if (has_t) {
                 const float *tm = trans + (size_t)b * 9;
                 float y0 = fmaf(x2, tm[6], fmaf(x1, tm[3], x0 * tm[0]));
@@ -247,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_gather_kernel(
                 x0 = y0; x1 = y1; x2 = y2;
             }
             xs[L.tid] = x0; xs[TP + L.tid] = x1; xs[2 * TP + L.tid] = x2;
-            cf[L.tid] = coef[(size_t)b * 1024 + c];
+            cf[L.tid] = cfv;
         }
         __syncthreads();
         layer1_tile(xs, P.w1, P.b1, P.s1c, P.t1c, h1, L);
@@ -255,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_gather_kernel(
         {
             f32x16 a0, a1;
             const int cb = L.wave;
-            layer2_mfma(h1, P.w2p, cb, L, a0, a1);
+            layer2_compute(h1, w2f, L, a0, a1);
             const float sc = P.s2c[cb * 32 + L.j], sh = P.t2c[cb * 32 + L.j];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -355,6 +406,8 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
             if (L.lane == 0) { hcnt[L.wave] = clo; hcnt[4 + L.wave] = chi; }
         }
         __syncthreads();
+        f32x4 w2f[8];   // requested a phase ahead of layer 2 (not kept across the long MFMA phase: register budget)
+        load_w2frag(w2f, P.w2p, cb, L);
         layer1_tile(xs, P.w1, P.b1, P.s1c, P.t1c, h1, L);
         int nlo = 0, nhi = 0;
         {   // ordered compaction at the prefix offsets of the four quarters
@@ -380,7 +433,7 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
         nhi = __builtin_amdgcn_readfirstlane(nhi);
         __syncthreads();
         f32x16 z0, z1;   // raw z2 of (this lane's rows, channel c2): ReLU mask and zhat2 are derived in the epilogue
-        layer2_mfma(h1, P.w2p, cb, L, z0, z1);
+        layer2_compute(h1, w2f, L, z0, z1);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = mfma_row(r, L.lane);
@@ -391,7 +444,8 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
         f32x16 d0, d1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
-        {   // d = h2 A   (K = 128)
+        {   // d = h2 A (K = 128).  (Explicitly software-pipelined variants of this loop, of the sparse loop and of the
+            // Gram loop were measured: no gain, this pass is bound by its phase structure, not by operand latency.)
             const f32x4 *wp = (const f32x4 *)D.Ap + (size_t)(cb * 16) * 64 + L.lane;
             const float *a0p = h2 + L.j * H2S + L.h * 4;
             const float *a1p = h2 + (32 + L.j) * H2S + L.h * 4;
@@ -401,67 +455,49 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
                 const f32x4 a0 = *(const f32x4 *)(a0p + kb * 8);
                 const f32x4 a1 = *(const f32x4 *)(a1p + kb * 8);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    d0 = mfma32(a0[t], wv[t], d0);
-                    d1 = mfma32(a1[t], wv[t], d1);
-                }
+                for (int t = 0; t < 4; ++t) { d0 = mfma32(a0[t], wv[t], d0); d1 = mfma32(a1[t], wv[t], d1); }
             }
         }
         // d -= sparse term: 8 hits (4 k-steps) per iteration, four W3 row pieces in flight
         {
             const float *w3c = D.w3 + c2;
+            auto sparse = [&](const unsigned short *hl, int n, f32x16 &d) {
 #pragma unroll 1
-            for (int e0 = 0; e0 < nlo; e0 += 8) {
-                float av[4], bv[4];
+                for (int e0 = 0; e0 < n; e0 += 8) {
+                    float av[4], bv[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int e = e0 + 2 * u + L.h;
-                    const int v = hits[e];
-                    const int c = (e < nlo) ? (v >> 5) : 0;
-                    const float cf = (e < nlo) ? cfl[c] : 0.f;
-                    bv[u] = w3c[(size_t)c * 128];
-                    av[u] = ((v & 31) == L.j) ? -cf : 0.f;
+                    for (int u = 0; u < 4; ++u) {
+                        const int e = e0 + 2 * u + L.h;
+                        const int v = hl[e];
+                        const int c = (e < n) ? (v >> 5) : 0;
+                        const float cf = (e < n) ? cfl[c] : 0.f;
+                        bv[u] = w3c[(size_t)c * 128];
+                        av[u] = ((v & 31) == L.j) ? -cf : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) d = mfma32(av[u], bv[u], d);
                 }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) d0 = mfma32(av[u], bv[u], d0);
-            }
-#pragma unroll 1
-            for (int e0 = 0; e0 < nhi; e0 += 8) {
-                float av[4], bv[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int e = e0 + 2 * u + L.h;
-                    const int v = hits[BWD_D_HITS + e];
-                    const int c = (e < nhi) ? (v >> 5) : 0;
-                    const float cf = (e < nhi) ? cfl[c] : 0.f;
-                    bv[u] = w3c[(size_t)c * 128];
-                    av[u] = ((v & 31) == L.j) ? -cf : 0.f;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) d1 = mfma32(av[u], bv[u], d1);
-            }
+            };
+            sparse(hits, nlo, d0);
+            sparse(hits + BWD_D_HITS, nhi, d1);
         }
         // Gram of the tile: D[i][j] += A[i][k = point] B[k = point][j], both operands read column-wise from h2
         {
             const float *colp = h2 + L.h * H2S + L.j;
-            const int o0 = cb * 32, o1 = ((cb + 1) & 3) * 32;
+            const int o0 = cb * 32, o1 = ((cb + 1) & 3) * 32, o2 = ((cb + 2) & 3) * 32;
             if (cb < 2) {
-                const int o2 = (cb + 2) * 32;
 #pragma unroll 4
                 for (int st = 0; st < 32; ++st) {
                     const float *rp = colp + 2 * st * H2S;
                     const float av = rp[o0];
-                    gm0 = mfma32(av, av, gm0);
-                    gm1 = mfma32(av, rp[o1], gm1);
-                    gm2 = mfma32(av, rp[o2], gm2);
+                    gm0 = mfma32(av, av, gm0); gm1 = mfma32(av, rp[o1], gm1); gm2 = mfma32(av, rp[o2], gm2);
                 }
             } else {
 #pragma unroll 4
                 for (int st = 0; st < 32; ++st) {
                     const float *rp = colp + 2 * st * H2S;
                     const float av = rp[o0];
-                    gm0 = mfma32(av, av, gm0);
-                    gm1 = mfma32(av, rp[o1], gm1);
+                    gm0 = mfma32(av, av, gm0); gm1 = mfma32(av, rp[o1], gm1);
                 }
             }
         }
@@ -549,6 +585,8 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
     f32x16 pw0, pw1;   // dW2 rows o = cb*32 + i, columns {0,1}*32 + j
 #pragma unroll
     for (int r = 0; r < 16; ++r) { pw0[r] = 0.f; pw1[r] = 0.f; }
+    f32x4 w2f[8];   // this wave's layer-2 weight fragments stay in registers for the whole kernel
+    load_w2frag(w2f, P.w2p, cb, L);
     for (int tile = t0; tile < t1; ++tile) {
         const int nbase = tile * TP;
         float *xs = xbuf + ((tile - t0) & 1) * 6 * TP, *xo = xs + 3 * TP;
@@ -564,7 +602,7 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
         __syncthreads();
         {
             f32x16 a0, a1;
-            layer2_mfma(h1, P.w2p, cb, L, a0, a1);
+            layer2_compute(h1, w2f, L, a0, a1);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mfma_row(r, L.lane);
@@ -578,18 +616,10 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
         __syncthreads();
         {
             // dh1[point][c1] = sum_o dz[point][o] * W2[o][c1]   (K = 128), one 32x32 tile per wave
-            const f32x4 *wp = (const f32x4 *)E.w2tp + (size_t)(cb1 * 16) * 64 + L.lane;
-            const float *ap = dz + (pb1 * 32 + L.j) * H2S + L.h * 4;
-            f32x16 acc;
+            f32x16 acc, unused;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll 4
-            for (int kb = 0; kb < 16; ++kb) {
-                f32x4 wv = wp[kb * 64];
-                f32x4 av = *(const f32x4 *)(ap + kb * 8);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) acc = mfma32(av[t], wv[t], acc);
-            }
+            k128_stream<1>(dz, E.w2tp, cb1, pb1, L, acc, unused);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int pt = pb1 * 32 + mfma_row(r, L.lane);
@@ -604,13 +634,30 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
             }
         }
         // dW2 += dz^T h1 : contraction over the tile's 64 points (rows past N carry dz == 0)
-#pragma unroll 4
-        for (int st = 0; st < 32; ++st) {
-            const int pt = 2 * st + L.h;
-            const float av = dz[pt * H2S + cb * 32 + L.j];
-            const float *hr = h1 + pt * H1S + L.j;
-            pw0 = mfma32(av, hr[0], pw0);
-            pw1 = mfma32(av, hr[32], pw1);
+        {
+            const float *dzc = dz + L.h * H2S + cb * 32 + L.j, *h1c = h1 + L.h * H1S + L.j;
+            float ca[4], c0[4], c1v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { ca[u] = dzc[2 * u * H2S]; c0[u] = h1c[2 * u * H1S]; c1v[u] = h1c[2 * u * H1S + 32]; }
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                float na[4], n0[4], n1[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    na[u] = ca[u]; n0[u] = c0[u]; n1[u] = c1v[u];
+                    if (g + 1 < 8) {
+                        const int st = (g + 1) * 4 + u;
+                        na[u] = dzc[2 * st * H2S]; n0[u] = h1c[2 * st * H1S]; n1[u] = h1c[2 * st * H1S + 32];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    pw0 = mfma32(ca[u], c0[u], pw0);
+                    pw1 = mfma32(ca[u], c1v[u], pw1);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { ca[u] = na[u]; c0[u] = n0[u]; c1v[u] = n1[u]; }
+            }
         }
         // no end-of-tile barrier: xs/xo are double-buffered; h1 and dz are rewritten only after the next tile's
         // first barrier, which every wave reaches after finishing this tile.

@@ -13,46 +13,7 @@
 // Bias (+ReLU) of layer 3 commute with the max and are applied once at the end.
 #include "pngpd_tile.h"
 
-// LDS tiles of this kernel are UNPADDED and XOR-swizzled at float4 granularity instead of using the
-// +4-float row pad of pngpd_tile.h: element (row, col) lives at row*W + (((col>>2) ^ (row&15))<<2) + (col&3).
-// A wave's ds_read_b128 A-fragment read (lane i -> row i, one float4 column) then hits 16 distinct 16-B
-// slots per 16-lane group (conflict-free) and the footprint drops to 54,016 B -> 3 workgroups per CU.
-#define I1S 64
-#define I2S 128
 #define TRUNK_LDS_FLOATS (TP * I1S + TP * I2S + 3 * TP + 1024)
-
-__device__ __forceinline__ int swz(int row, int col, int width) {
-    return row * width + ((((col >> 2) ^ (row & 15)) << 2) | (col & 3));
-}
-
-// K-contraction of a swizzled [64][W] tile against register-resident MFMA_B fragments (NKB k-blocks).
-template <int W, int NKB>
-__device__ __forceinline__ void swz_compute(const float *tile, const f32x4 (&wf)[NKB], const Lane &L,
-                                            f32x16 &acc0, f32x16 &acc1) {
-    const float *r0 = tile + L.j * W, *r1 = tile + (32 + L.j) * W;
-    const int sx = L.j & 15;   // (32 + j) & 15 == j & 15
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    // A fragments double-buffered in registers: the two ds_read_b128 of k-block kb+1 are in flight while the
-    // eight MFMAs of k-block kb issue (hipcc otherwise re-uses the registers and waits lgkmcnt(0) every block)
-    f32x4 a0 = *(const f32x4 *)(r0 + (((0 * 2 + L.h) ^ sx) << 2));
-    f32x4 a1 = *(const f32x4 *)(r1 + (((0 * 2 + L.h) ^ sx) << 2));
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-        f32x4 n0 = a0, n1 = a1;
-        if (kb + 1 < NKB) {
-            const int c4 = (((kb + 1) * 2 + L.h) ^ sx) << 2;
-            n0 = *(const f32x4 *)(r0 + c4);
-            n1 = *(const f32x4 *)(r1 + c4);
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            acc0 = mfma32(a0[t], wf[kb][t], acc0);
-            acc1 = mfma32(a1[t], wf[kb][t], acc1);
-        }
-        a0 = n0; a1 = n1;
-    }
-}
 
 __global__ __launch_bounds__(256, 2) void trunk_infer_kernel(
     const float *__restrict__ x, int N, const float *__restrict__ trans,

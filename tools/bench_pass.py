@@ -22,7 +22,12 @@ coef = r(B, 1024) * 1e-3
 A = r(128, 128) * 1e-3; Ap = ops.pack_mfma_b(((A + A.t()) / 2).contiguous()); cvec = r(128) * 1e-3
 ev = r(3, 128)
 
+ONLY = [t for t in os.environ.get("PNGPD_PASSES", "").split(",") if t]
+
+
 def timeit(name, fn, reps=10):
+    if ONLY and not any(name.startswith(t) for t in ONLY):
+        return fn()
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

@@ -1,13 +1,18 @@
-# Round-end evidence run (on the GPU box): kernel-trace summaries -> gpurun_out/*.md (copy into profiles/).
+# Kernel-trace evidence (on the GPU box): usage  bash tools/prof_round.sh TAG [gpg]
+#   -> gpurun_out/TAG_bench_trace.md (+ TAG_gpg_trace.md); copy into profiles/.
 # Every profiler invocation is bounded by its own timeout: a hung rocprofv3 must not eat the GPU budget.
+TAG=${1:-r02}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-( cd /tmp && timeout 240 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > /tmp/kt.log 2>&1; echo "kt rc=$?" )
+rm -rf /tmp/prof_kt /tmp/prof_gpg
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --min-seconds 0.4 > /tmp/kt.log 2>&1; echo "kt rc=$?" )
 KT=$(find /tmp/prof_kt -name "*.db" | head -1)
-[ -n "$KT" ] && python tools/rocprof_summary.py gpurun_out/r01_final2_bench_trace.md "bench.py kernel trace (infer fp32 + bf16x3 + train legs)=$KT" > /dev/null
+[ -n "$KT" ] && python tools/rocprof_summary.py gpurun_out/${TAG}_bench_trace.md "bench.py kernel trace (infer fp32 + bf16x3 + train legs)=$KT" > /dev/null
+if [ "$2" = "gpg" ]; then
 ( cd /tmp && timeout 180 rocprofv3 --kernel-trace --stats -d /tmp/prof_gpg -o gpg -- python $GRAFT_REPO_ROOT/tools/bench_gpg.py --P 20000 --cpu-draws 1 --reps 3 > /tmp/gpg.log 2>&1; echo "gpg rc=$?" )
 GP=$(find /tmp/prof_gpg -name "*.db" | head -1)
-[ -n "$GP" ] && python tools/rocprof_summary.py gpurun_out/r01_final2_gpg_trace.md "tools/bench_gpg.py kernel trace, P 20000, 150 sample points=$GP" > /dev/null
+[ -n "$GP" ] && python tools/rocprof_summary.py gpurun_out/${TAG}_gpg_trace.md "tools/bench_gpg.py kernel trace, P 20000, 150 sample points=$GP" > /dev/null
 tail -n 3 /tmp/gpg.log
-ls -la gpurun_out/
+fi
+ls -la gpurun_out/ | tail -5

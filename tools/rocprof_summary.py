@@ -19,7 +19,10 @@ def short(name):
 
 
 def main():
-    out, items = sys.argv[1], sys.argv[2:]
+    args = sys.argv[1:]
+    show_all = "--all" in args          # list foreign (torch / rocclr) kernels individually too
+    args = [a for a in args if a != "--all"]
+    out, items = args[0], args[1:]
     lines = []
     for it in items:
         label, path = it.split("=", 1)
@@ -30,7 +33,7 @@ def main():
             lines.append("| kernel | calls | total_us | avg_us | % |\n|---|---|---|---|---|")
             other = [0, 0.0, 0.0]
             for n, c, t, a, p in rows:
-                if short(n).startswith(OURS):
+                if show_all or short(n).startswith(OURS):
                     lines.append(f"| {short(n)} | {c} | {t:.1f} | {a:.3f} | {p:.2f} |")
                 else:
                     other[0] += c; other[1] += t; other[2] += p

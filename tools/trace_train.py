@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""N eager training steps at the bench shape (B = N = 1024) and nothing else — the workload of the per-step kernel
+trace (profiles/*_train_step_trace.md: every kernel of a step, torch's own included)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn.functional as F
+import bench
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+dev = torch.device("cuda:0")
+B, N, k = 1024, 1024, 2
+m = bench.build_model(N, k, dev).train()
+opt = torch.optim.Adam(m.parameters(), lr=0.005, fused=True)
+x = bench.synth_clouds(B, N, 1234, dev)
+y = (torch.arange(B, device=dev) % k).long()
+for _ in range(steps):
+    opt.zero_grad(set_to_none=True)
+    lp, _ = m(x)
+    F.nll_loss(lp, y).backward()
+    opt.step()
+torch.cuda.synchronize()
+print("steps", steps)

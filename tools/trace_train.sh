@@ -1,0 +1,8 @@
+# usage: bash tools/trace_train.sh TAG   -> gpurun_out/TAG_train_step_trace.md (10 steps, every kernel listed)
+TAG=${1:-r02}
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+rm -rf /tmp/prof_tr
+( cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/prof_tr -o tr -- python $GRAFT_REPO_ROOT/tools/trace_train.py 10 > /tmp/tr.log 2>&1; echo "tr rc=$?" )
+DB=$(find /tmp/prof_tr -name "*.db" | head -1)
+[ -n "$DB" ] && python tools/rocprof_summary.py --all gpurun_out/${TAG}_train_step_trace.md "10 eager training steps, B=N=1024, k=2 (tools/trace_train.py)=$DB" > /dev/null
