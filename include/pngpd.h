@@ -186,10 +186,18 @@ int pngpd_trunk_bwd_e(const float *x, int B, int N, const float *trans,
                       const float *a1m, const float *a2m, const float *dsc2, const float *w2tp,
                       const float *g2t, int S, float *pc, float *pR, float *pW2, void *stream);
 
-/* BatchNorm1d over the batch dimension for the FC stacks (pointnet.py:35-36,191-192, train mode),
- * optional fused ReLU; biased variance returned (the caller updates running stats). */
+/* Backward of a Linear layer y = x W^T + b (pointnet.py:35-37,191-193; loss.backward() of main_1v.py:75) in one
+ * launch, operands read in place: g (B,Nout) upstream gradient, x (B,K) the layer input, W (Nout,K) ->
+ * dW (Nout,K) = g^T x, db (Nout) = sum_b g, dx (B,K) = g W (dx may be NULL).                                */
+int pngpd_fc_bwd(const float *g, const float *x, const float *W, int B, int K, int Nout,
+                 float *dW, float *dx, float *db, void *stream);
+
+/* BatchNorm1d over the batch dimension for the FC stacks (pointnet.py:35-36,191-192, train mode), optional fused
+ * ReLU; biased batch mean/var returned; running_mean / running_var / num_batches_tracked (nullable) updated in
+ * place like nn.BatchNorm1d (momentum, unbiased variance). */
 int pngpd_bn1d_fwd_train(const float *z, int B, int C, const float *gamma, const float *beta, float eps,
-                         int relu, float *y, float *mean, float *var, void *stream);
+                         int relu, float *y, float *mean, float *var, float momentum, float *rm, float *rv,
+                         long long *nbt, void *stream);
 int pngpd_bn1d_bwd(const float *dy, const float *z, const float *y, int B, int C, const float *gamma,
                    const float *mean, const float *var, float eps, int relu,
                    float *dz, float *dgamma, float *dbeta, void *stream);

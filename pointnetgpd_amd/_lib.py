@@ -49,8 +49,11 @@ SIGNATURES = {
                           [c_f32p] * 3 + [c_void]),
     "pngpd_trunk_bwd_e": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 15 + [ctypes.c_int] +
                           [c_f32p] * 3 + [c_void]),
+    "pngpd_fc_bwd": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p,
+                                    c_f32p, c_void]),
     "pngpd_bn1d_fwd_train": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, ctypes.c_float,
-                                            ctypes.c_int, c_f32p, c_f32p, c_f32p, c_void]),
+                                            ctypes.c_int, c_f32p, c_f32p, c_f32p, ctypes.c_float, c_f32p, c_f32p,
+                                            c_void, c_void]),
     "pngpd_bn1d_bwd": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, c_f32p,
                                       ctypes.c_float, ctypes.c_int, c_f32p, c_f32p, c_f32p, c_void]),
     "pngpd_log_softmax_bwd": (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, c_f32p, c_void]),

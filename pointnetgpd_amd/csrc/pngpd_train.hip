@@ -699,7 +699,8 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
 __global__ __launch_bounds__(1024) void bn1d_fwd_train_kernel(
     const float *__restrict__ z, int B, int C, const float *__restrict__ gamma,
     const float *__restrict__ beta, float eps, int relu, float *__restrict__ y,
-    float *__restrict__ mean_out, float *__restrict__ var_out) {
+    float *__restrict__ mean_out, float *__restrict__ var_out,
+    float momentum, float *rm, float *rv, long long *nbt) {
     __shared__ float red[32][33];
     const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cx;
@@ -729,7 +730,14 @@ __global__ __launch_bounds__(1024) void bn1d_fwd_train_kernel(
         if (relu) v = fmaxf(v, 0.f);
         y[(size_t)b * C + c] = v;
     }
-    if (ry == 0) { mean_out[c] = mean; var_out[c] = var; }
+    if (ry == 0) {
+        mean_out[c] = mean; var_out[c] = var;
+        if (rm) {   // nn.BatchNorm1d running statistics: momentum, unbiased variance
+            rm[c] = (1.f - momentum) * rm[c] + momentum * mean;
+            rv[c] = (1.f - momentum) * rv[c] + momentum * var * ((float)B / (float)(B > 1 ? B - 1 : 1));
+        }
+        if (nbt && c == 0) *nbt += 1;
+    }
 }
 
 // dy: gradient wrt the (post-ReLU if relu) output y.  dz, dgamma, dbeta out.
@@ -777,6 +785,102 @@ __global__ void log_softmax_bwd_kernel(const float *__restrict__ g, const float 
     for (int k = 0; k < K; ++k) dlogits[(size_t)b * K + k] = g[(size_t)b * K + k] - expf(logp[(size_t)b * K + k]) * s;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Backward of a Linear layer y = x W^T + b (pointnet.py:35-37,191-193) in ONE launch, operands read in place
+// (no transposed copies): for upstream g (B,Nout)
+//   dW (Nout,K) = g^T x   contraction over the batch   — A[i = n][kk = b] = g[b][n], B[kk = b][j = k] = x[b][k]:
+//                         both operands are read along rows, i.e. coalesced exactly as the MFMA wants them
+//   dx (B,K)    = g W     contraction over Nout        — A[i = b][kk = n] = g[b][n] (float4 along n when
+//                         Nout % 8 == 0), B[kk = n][j = k] = W[n][k]
+//   db (Nout)   = sum_b g — falls out of the dW tiles of k-block 0 (the A operand IS g)
+// One wave = one 32x32 output tile; tiles [0, tilesW) are dW, the rest dx.
+// ---------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(256) void fc_bwd_kernel(const float *__restrict__ g, const float *__restrict__ x,
+                                                     const float *__restrict__ W, int B, int K, int Nout,
+                                                     int tilesW, int tilesX, float *__restrict__ dW,
+                                                     float *__restrict__ dx, float *__restrict__ db) {
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const int wid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kblocks = (K + 31) >> 5;
+    f32x16 acc = {0};
+    if (wid < tilesW) {
+        const int nb = wid / kblocks, kbk = wid - nb * kblocks;
+        const int n = nb * 32 + j, kc = kbk * 32 + j;
+        const bool nv = n < Nout, kv = kc < K;
+        const float *gp = g + (nv ? n : 0), *xp = x + (kv ? kc : 0);
+        float dbs = 0.f;
+        for (int b0 = 0; b0 < B; b0 += 16) {   // 8 k-steps: 16 loads in flight per lane
+            float av[8], bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int b = b0 + 2 * u + h;
+                const bool ok = b < B;
+                av[u] = (ok && nv) ? gp[(size_t)b * Nout] : 0.f;
+                bv[u] = (ok && kv) ? xp[(size_t)b * K] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc = mfma32(av[u], bv[u], acc); dbs += av[u]; }
+        }
+        if (kv) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = nb * 32 + mfma_row(r, lane);
+                if (row < Nout) dW[(size_t)row * K + kc] = acc[r];
+            }
+        }
+        dbs += __shfl_xor(dbs, 32);
+        if (kbk == 0 && h == 0 && nv) db[n] = dbs;
+    } else if (wid - tilesW < tilesX && dx) {
+        const int t = wid - tilesW;
+        const int rb = t / kblocks, kbk = t - rb * kblocks;
+        int row = rb * 32 + j; row = row < B ? row : B - 1;
+        const int kc = kbk * 32 + j;
+        const bool kv = kc < K;
+        const float *wp = W + (kv ? kc : 0);
+        const float *gr = g + (size_t)row * Nout;
+        if (VEC) {   // Nout % 8 == 0: k-block = 8 values of n, lane (j,h) holds n = 8kb + 4h .. +3
+            const f32x4 *ap = (const f32x4 *)gr + h;
+            const int KB = Nout >> 3;
+            for (int kb = 0; kb < KB; kb += 2) {
+                f32x4 a[2]; float w[2][4];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int kk = kb + u < KB ? kb + u : KB - 1;
+                    a[u] = ap[kk * 2];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[u][e] = kv ? wp[(size_t)(kk * 8 + 4 * h + e) * K] : 0.f;
+                    if (kb + u >= KB) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = mfma32(a[u][e], w[u][e], acc);
+            }
+        } else {
+            for (int n0 = 0; n0 < Nout; n0 += 8) {
+                float av[4], bv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int n = n0 + 2 * u + h;
+                    const bool ok = n < Nout;
+                    av[u] = ok ? gr[n] : 0.f;
+                    bv[u] = (ok && kv) ? wp[(size_t)n * K] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = mfma32(av[u], bv[u], acc);
+            }
+        }
+        if (kv) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int orow = rb * 32 + mfma_row(r, lane);
+                if (orow < B) dx[(size_t)orow * K + kc] = acc[r];
+            }
+        }
+    }
+}
 
 // ---------------------------------------------------------------------------------------
 // C ABI
@@ -896,11 +1000,27 @@ int pngpd_trunk_bwd_e(const float *x, int B, int N, const float *trans,
     return pngpd_launch_status();
 }
 
+int pngpd_fc_bwd(const float *g, const float *x, const float *W, int B, int K, int Nout,
+                 float *dW, float *dx, float *db, void *stream) {
+    if (!g || !x || !W || !dW || !db || B <= 0 || K <= 0 || Nout <= 0) return PNGPD_ERR_INVALID_ARG;
+    const int kblocks = (K + 31) / 32;
+    const int tilesW = ((Nout + 31) / 32) * kblocks, tilesX = dx ? ((B + 31) / 32) * kblocks : 0;
+    const unsigned grid = (unsigned)((tilesW + tilesX + 3) / 4);
+    if ((Nout & 7) == 0)
+        hipLaunchKernelGGL(fc_bwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, x, W, B, K, Nout,
+                           tilesW, tilesX, dW, dx, db);
+    else
+        hipLaunchKernelGGL(fc_bwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, x, W, B, K, Nout,
+                           tilesW, tilesX, dW, dx, db);
+    return pngpd_launch_status();
+}
+
 int pngpd_bn1d_fwd_train(const float *z, int B, int C, const float *gamma, const float *beta, float eps,
-                         int relu, float *y, float *mean, float *var, void *stream) {
-    if (!z || !gamma || !beta || !y || !mean || !var || B <= 0 || C <= 0) return PNGPD_ERR_INVALID_ARG;
+                         int relu, float *y, float *mean, float *var, float momentum, float *rm, float *rv,
+                         long long *nbt, void *stream) {
+    if (!z || !gamma || !beta || !y || !mean || !var || B <= 0 || C <= 0 || (rm && !rv)) return PNGPD_ERR_INVALID_ARG;
     hipLaunchKernelGGL(bn1d_fwd_train_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream,
-                       z, B, C, gamma, beta, eps, relu, y, mean, var);
+                       z, B, C, gamma, beta, eps, relu, y, mean, var, momentum, rm, rv, nbt);
     return pngpd_launch_status();
 }
 

@@ -312,13 +312,28 @@ def reduce4(*segs):
     return outs
 
 
-def bn1d_fwd_train(z, gamma, beta, eps, relu):
+def fc_bwd(g, inp, W):
+    """Backward of ``inp @ W^T + b``: -> (dinp (B,K), dW (Nout,K), db (Nout)) in one launch, no transposed copies."""
+    B, K = inp.shape
+    Nout = W.shape[0]
+    _f32(g, "g", (B, Nout)); _f32(inp, "inp", (B, K)); _f32(W, "W", (Nout, K))
+    dinp = torch.empty(B, K, device=g.device, dtype=torch.float32)
+    dW = torch.empty(Nout, K, device=g.device, dtype=torch.float32)
+    db = torch.empty(Nout, device=g.device, dtype=torch.float32)
+    _call("pngpd_fc_bwd", g, g, inp, W, B, K, Nout, dW, dinp, db)
+    return dinp, dW, db
+
+
+def bn1d_fwd_train(z, gamma, beta, eps, relu, momentum=0.1, bufs=None):
+    """Batch-statistics BatchNorm1d (+ReLU) over (B,C); ``bufs`` = (running_mean, running_var, num_batches_tracked)
+    are updated in place by the same kernel."""
     B, C = z.shape
     y = torch.empty_like(z)
     mean = torch.empty(C, device=z.device, dtype=torch.float32)
     var = torch.empty(C, device=z.device, dtype=torch.float32)
+    rm, rv, nbt = bufs if bufs is not None else (None, None, None)
     _call("pngpd_bn1d_fwd_train", z, _f32(z, "z"), B, C, _f32(gamma, "gamma", (C,)), _f32(beta, "beta", (C,)),
-          float(eps), int(relu), y, mean, var)
+          float(eps), int(relu), y, mean, var, float(momentum), rm, rv, nbt)
     return y, mean, var
 
 

@@ -159,7 +159,7 @@ class TrunkTrainFn(torch.autograd.Function):
                                     c2=c12v.view(64, 2)[:, 1], Rb=Rb.view(B, 64, 3), dW1=dW1, dW2=dW2, dW3=dW3, dT=dT,
                                     g2buf=g2t_to_rows(g2t, B, N), idx=idx, coef=coef,
                                     A=Ap.view(4, 16, 2, 32, 4).permute(0, 3, 1, 2, 4).reshape(128, 128)))
-        z = lambda n: torch.zeros(n, device=dev, dtype=torch.float32)
+        z = lambda n: torch.zeros(n, device=dev, dtype=torch.float32)   # conv bias ahead of train-mode BN: exactly 0
         return (None, dT,
                 dW1.view(64, 3, 1), z(64), dg1, dbe1,
                 dW2.view(128, 64, 1), z(128), dg2, dbe2,
@@ -184,40 +184,9 @@ def _s2_full(S2c, dev):
     return out
 
 
-def _pad_cols(t, mult=8):
-    """Zero-pad the last dim to a multiple of ``mult`` (fc kernel contracts K % 8 == 0)."""
-    k = t.shape[-1]
-    pad = (-k) % mult
-    if pad == 0:
-        return t.contiguous()
-    return torch.nn.functional.pad(t, (0, pad)).contiguous()
-
-
 def _linear_bwd(g, inp, W):
-    """g (B,Nout) -> (dinp (B,K), dW (Nout,K), db (Nout)) with the MFMA FC kernel:
-    dW = g^T inp (contraction over the batch), dinp = g W (contraction over Nout)."""
-    Nout, K = W.shape
-    zero_k = torch.zeros(K, device=g.device, dtype=torch.float32)
-    gt = _pad_cols(g.t())                      # (Nout, B')
-    it = _pad_cols(inp.t())                    # (K, B')
-    dW = ops.fc_fwd(gt, it, zero_k, ops.EPI_NONE)          # (Nout, K)
-    gp = _pad_cols(g)                          # (B, Nout')
-    wt = _pad_cols(W.t())                      # (K, Nout')
-    dinp = ops.fc_fwd(gp, wt, zero_k, ops.EPI_NONE)        # (B, K)
-    db = _reduce(g.contiguous(), 1, g.shape[0], Nout)[0].to(torch.float32)
-    return dinp, dW, db
-
-
-def _update_running(buffers, mean, var_biased, count, momentum):
-    """nn.BatchNorm1d running-stat update for the (B,C) FC BatchNorms (tiny (C,) tensors)."""
-    if buffers is None:
-        return
-    rm, rv, nbt = buffers
-    with torch.no_grad():
-        rm.mul_(1 - momentum).add_(mean, alpha=momentum)
-        rv.mul_(1 - momentum).add_(var_biased, alpha=momentum * count / max(count - 1, 1))
-        if nbt is not None:
-            nbt.add_(1)
+    """g (B,Nout) -> (dinp (B,K), dW (Nout,K), db (Nout)): pngpd_fc_bwd, operands read in place."""
+    return ops.fc_bwd(g.contiguous(), inp, W)
 
 
 class LinearBnReluFn(torch.autograd.Function):
@@ -228,8 +197,9 @@ class LinearBnReluFn(torch.autograd.Function):
         inp = inp.contiguous()
         Wd, bd = W.detach().contiguous(), b.detach().contiguous()
         z = ops.fc_fwd(inp, Wd, bd, ops.EPI_NONE)
-        y, mean, var = ops.bn1d_fwd_train(z, gamma.detach().contiguous(), beta.detach().contiguous(), eps, 1)
-        _update_running(bufs, mean, var, inp.shape[0], momentum)
+        y, mean, var = ops.bn1d_fwd_train(z, gamma.detach().contiguous(), beta.detach().contiguous(), eps, 1,
+                                          momentum, bufs)
+        _bump(bufs)
         ctx.eps = eps
         ctx.save_for_backward(inp, Wd, gamma.detach().contiguous(), z, y, mean, var)
         return y

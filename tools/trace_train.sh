@@ -5,4 +5,4 @@ export TMPDIR=/tmp
 rm -rf /tmp/prof_tr
 ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/prof_tr -o tr -- python $GRAFT_REPO_ROOT/tools/trace_train.py 10 > /tmp/tr.log 2>&1; echo "tr rc=$?" )
 DB=$(find /tmp/prof_tr -name "*.db" | head -1)
-[ -n "$DB" ] && python tools/rocprof_summary.py --all gpurun_out/${TAG}_train_step_trace.md "10 eager training steps, B=N=1024, k=2 (tools/trace_train.py)=$DB" > /dev/null
+[ -n "$DB" ] && python tools/rocprof_summary.py --all gpurun_out/${TAG}_train_step_trace.md "10 eager training steps at B 1024 N 1024 k 2 (tools/trace_train.py)=$DB" > /dev/null
