@@ -100,26 +100,30 @@ int pngpd_fc_fwd(const float *in, int B, int K, const float *W, const float *bia
                  int epilogue, float *out, void *stream);
 
 /*
- * OPT-IN fast inference trunk ("bf16x3"): same contract as pngpd_trunk_fwd_infer, but the two GEMM layers run
- * as 3-term split-bf16 products on v_mfma_f32_32x32x16_bf16 (a*w ~= a_hi*w_hi + a_hi*w_lo + a_lo*w_hi, fp32
- * accumulate; relative product error <= ~2^-16).  Not bit-identical to fp32 arithmetic; log-probs stay within
- * 1e-4 of the fp32 path.  w2x / w3x = pngpd_split_pack_bf16 of the BN-folded ROWMAJOR (128,64) / (1024,128)
- * weights (2*C*K halfwords each).
+ * OPT-IN reduced-precision trunks on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulate): same
+ * contract as pngpd_trunk_fwd_infer, the two GEMM layers evaluated with `nterms` bf16 products per fp32 product:
+ *   nterms = 3 ("bf16x3"): a*w ~= a_hi*w_hi + a_hi*w_lo + a_lo*w_hi — relative product error <= ~2^-16; log-probs
+ *                          stay within 1e-4 of the fp32 path (inside the 1e-3 contract), not bit-identical;
+ *   nterms = 1 ("bf16"):   a_hi*w_hi only — plain bf16 operands (BASELINE configs[2]); error ~2^-8 per product,
+ *                          does NOT meet 1e-3 on log-probs in general (measured bounds in tests/test_gpu_bf16.py).
+ * x: (B,3,N) clouds, fp32 or — x_is_bf16 — bf16 storage (6 B/point).  Layer 1 (K = 3) stays fp32 on the VALU.
+ * w2x / w3x = pngpd_split_pack_bf16 of the BN-folded ROWMAJOR (128,64) / (1024,128) weights (2*C*K halfwords each;
+ * nterms = 1 reads only the hi halves).  splits over 128-point tiles (pngpd_trunk_infer_bf_splits; default target
+ * 1024 workgroups); workspace >= B*S*1024*4 bytes when S > 1.
  */
 int pngpd_split_pack_bf16(const float *W, int C, int K, void *out, void *stream);
-/* splits as above but over 128-point tiles (pngpd_trunk_infer_x3_splits; default target 1024 workgroups);
- * workspace >= B*S*1024*4 bytes when S > 1. */
-int pngpd_trunk_infer_x3_splits(int B, int N, int target_blocks);
-int pngpd_trunk_fwd_infer_x3(const float *x, int B, int N, const float *trans,
+int pngpd_trunk_infer_bf_splits(int B, int N, int target_blocks);
+int pngpd_trunk_fwd_infer_bf(const void *x, int x_is_bf16, int B, int N, const float *trans,
                              const float *w1, const float *b1, const void *w2x, const float *b2,
-                             const void *w3x, const float *b3, int relu_last, int splits,
+                             const void *w3x, const float *b3, int relu_last, int nterms, int splits,
                              float *out_pool, void *workspace, size_t workspace_bytes, void *stream);
-/* OPT-IN bf16x3 variant of pass C (pngpd_trunk_fwd_train below): identical outputs/semantics, GEMM layers on
- * split-bf16 products.  w2x = split_pack_bf16(raw W2), w3sx = split_pack_bf16(sign(gamma3)*W3).  S = number of
- * workgroups per cloud (1 <= S <= ceil(N/128)); pmax/parg (B*S,1024), psum (B*S,2,1024), psh (B*S*2,128).   */
-int pngpd_trunk_fwd_train_x3(const float *x, int B, int N, const float *trans,
+/* the same arithmetic for pass C of the training path (pngpd_trunk_fwd_train below): identical outputs/semantics.
+ * w2x = split_pack_bf16(raw W2), w3sx = split_pack_bf16(sign(gamma3)*W3).  S = workgroups per cloud
+ * (1 <= S <= ceil(N/128)); pmax/parg (B*S,1024), psum (B*S,2,1024), psh (B*S*2,128).  BatchNorm statistics and every
+ * accumulator stay fp32/fp64.                                                                                  */
+int pngpd_trunk_fwd_train_bf(const float *x, int B, int N, const float *trans,
                              const float *w1, const float *b1, const float *s1c, const float *t1c,
-                             const void *w2x, const float *s2c, const float *t2c, const void *w3sx, int S,
+                             const void *w2x, const float *s2c, const float *t2c, const void *w3sx, int nterms, int S,
                              float *pmax, int *parg, float *psum, float *psh, void *stream);
 
 /* =======================================================================================

@@ -30,11 +30,11 @@ SIGNATURES = {
     "pngpd_fc_fwd": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, ctypes.c_int,
                                     ctypes.c_int, c_f32p, c_void]),
     "pngpd_split_pack_bf16": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, c_void]),
-    "pngpd_trunk_infer_x3_splits": (ctypes.c_int, [ctypes.c_int] * 3),
-    "pngpd_trunk_fwd_infer_x3": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, c_f32p] + [c_f32p] * 6 +
-                                 [ctypes.c_int, ctypes.c_int, c_f32p, c_void, ctypes.c_size_t, c_void]),
-    "pngpd_trunk_fwd_train_x3": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 9 +
-                                 [ctypes.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_void]),
+    "pngpd_trunk_infer_bf_splits": (ctypes.c_int, [ctypes.c_int] * 3),
+    "pngpd_trunk_fwd_infer_bf": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p] + [c_f32p] * 6 +
+                                 [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, c_void, ctypes.c_size_t, c_void]),
+    "pngpd_trunk_fwd_train_bf": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 9 +
+                                 [ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_void]),
     # ---- training passes (S = workgroups per cloud is an explicit argument everywhere)
     "pngpd_trunk_splits": (ctypes.c_int, [ctypes.c_int] * 3),
     "pngpd_trunk_g2t_bytes": (ctypes.c_size_t, [ctypes.c_int] * 2),

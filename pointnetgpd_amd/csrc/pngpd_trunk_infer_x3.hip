@@ -47,15 +47,27 @@ __global__ void split_pack_bf16_kernel(const float *__restrict__ W, int C, int K
     out[base + 64 * 8] = lo;
 }
 
-template <int KS>
+// NT = number of product terms: 3 = bf16x3 (hi*hi + hi*lo + lo*hi), 1 = plain bf16 (hi*hi only; the lo halves of
+// the packed weights and the lo activation tiles are neither loaded nor written).
+template <int KS, int NT>
 __device__ __forceinline__ void load_wx(f32x4 (&wh)[KS], f32x4 (&wl)[KS], const u16 *__restrict__ wx, int cb, int lane) {
     const f32x4 *p = (const f32x4 *)wx + (size_t)(cb * KS) * 2 * 64 + lane;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) { wh[ks] = p[(ks * 2) * 64]; wl[ks] = p[(ks * 2 + 1) * 64]; }
+    for (int ks = 0; ks < KS; ++ks) {
+        wh[ks] = p[(ks * 2) * 64];
+        if (NT == 3) wl[ks] = p[(ks * 2 + 1) * 64]; else wl[ks] = wh[ks];
+    }
 }
 
+// one cloud coordinate from fp32 or bf16 storage
+template <bool XBF>
+__device__ __forceinline__ float ldx(const void *__restrict__ base, size_t i) {
+    return XBF ? bf16_val(((const u16 *)base)[i]) : ((const float *)base)[i];
+}
+
+template <int NT, bool XBF>
 __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
-    const float *__restrict__ x, int N, const float *__restrict__ trans,
+    const void *__restrict__ x, int N, const float *__restrict__ trans,
     const float *__restrict__ w1, const float *__restrict__ b1,
     const u16 *__restrict__ w2x, const float *__restrict__ b2,
     const u16 *__restrict__ w3x, const float *__restrict__ b3,
@@ -73,7 +85,7 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
     const int j = lane & 31, h = lane >> 5;
     const int b = blockIdx.x / S, s = blockIdx.x - b * S;
     const int t0 = (int)(((long)s * T) / S), t1 = (int)(((long)(s + 1) * T) / S);
-    const float *xb = x + (size_t)b * 3 * N;
+    const size_t xo = (size_t)b * 3 * N;   // element offset of this cloud
     float tm[9] = {0};
     const bool has_t = trans != nullptr;
     if (has_t) {
@@ -88,7 +100,7 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
     float px0 = 0.f, px1 = 0.f, px2 = 0.f;
     if (tid < XP) {
         int n = t0 * XP + tid; n = n < N ? n : N - 1;
-        px0 = xb[n]; px1 = xb[N + n]; px2 = xb[2 * N + n];
+        px0 = ldx<XBF>(x, xo + n); px1 = ldx<XBF>(x, xo + N + n); px2 = ldx<XBF>(x, xo + 2 * (size_t)N + n);
     }
 
     for (int tile = t0; tile < t1; ++tile) {
@@ -102,7 +114,7 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
             xs[tid] = x0; xs[XP + tid] = x1; xs[2 * XP + tid] = x2;
             if (tile + 1 < t1) {
                 int n = (tile + 1) * XP + tid; n = n < N ? n : N - 1;
-                px0 = xb[n]; px1 = xb[N + n]; px2 = xb[2 * N + n];
+                px0 = ldx<XBF>(x, xo + n); px1 = ldx<XBF>(x, xo + N + n); px2 = ldx<XBF>(x, xo + 2 * (size_t)N + n);
             }
         }
         __syncthreads();
@@ -124,23 +136,26 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
                 vh.z = hv[q * 8 + 4] | ((unsigned)hv[q * 8 + 5] << 16); vh.w = hv[q * 8 + 6] | ((unsigned)hv[q * 8 + 7] << 16);
                 vl.x = lv[q * 8 + 0] | ((unsigned)lv[q * 8 + 1] << 16); vl.y = lv[q * 8 + 2] | ((unsigned)lv[q * 8 + 3] << 16);
                 vl.z = lv[q * 8 + 4] | ((unsigned)lv[q * 8 + 5] << 16); vl.w = lv[q * 8 + 6] | ((unsigned)lv[q * 8 + 7] << 16);
-                dh[q] = vh; dl[q] = vl;
+                dh[q] = vh;
+                if (NT == 3) dl[q] = vl;
             }
         }
         __syncthreads();
         {   // layer 2 (64 -> 128), bf16x3: wave owns channel block cb = wave & 3 and point blocks 2q, 2q+1
             const int cb = wave & 3, pb0 = (wave >> 2) * 2;
             f32x4 w2h[4], w2l[4];
-            load_wx<4>(w2h, w2l, w2x, cb, lane);
+            load_wx<4, NT>(w2h, w2l, w2x, cb, lane);
             f32x16 a0 = {0}, a1 = {0};
             const int r0 = (pb0 * 32 + j) * X1S + h * 8, r1 = ((pb0 + 1) * 32 + j) * X1S + h * 8;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const f32x4 ah0 = *(const f32x4 *)(h1h + r0 + ks * 16), al0 = *(const f32x4 *)(h1l + r0 + ks * 16);
-                const f32x4 ah1 = *(const f32x4 *)(h1h + r1 + ks * 16), al1 = *(const f32x4 *)(h1l + r1 + ks * 16);
+                const f32x4 ah0 = *(const f32x4 *)(h1h + r0 + ks * 16), ah1 = *(const f32x4 *)(h1h + r1 + ks * 16);
                 a0 = mfma_bf(ah0, w2h[ks], a0); a1 = mfma_bf(ah1, w2h[ks], a1);
-                a0 = mfma_bf(ah0, w2l[ks], a0); a1 = mfma_bf(ah1, w2l[ks], a1);
-                a0 = mfma_bf(al0, w2h[ks], a0); a1 = mfma_bf(al1, w2h[ks], a1);
+                if (NT == 3) {
+                    const f32x4 al0 = *(const f32x4 *)(h1l + r0 + ks * 16), al1 = *(const f32x4 *)(h1l + r1 + ks * 16);
+                    a0 = mfma_bf(ah0, w2l[ks], a0); a1 = mfma_bf(ah1, w2l[ks], a1);
+                    a0 = mfma_bf(al0, w2h[ks], a0); a1 = mfma_bf(al1, w2h[ks], a1);
+                }
             }
             const float bias = b2[cb * 32 + j];
 #pragma unroll
@@ -148,9 +163,11 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
                 const int row = mfma_row(r, lane);
                 u16 hi, lo;
                 split2(fmaxf(a0[r] + bias, 0.f), hi, lo);
-                h2h[(pb0 * 32 + row) * X2S + cb * 32 + j] = hi; h2l[(pb0 * 32 + row) * X2S + cb * 32 + j] = lo;
+                h2h[(pb0 * 32 + row) * X2S + cb * 32 + j] = hi;
+                if (NT == 3) h2l[(pb0 * 32 + row) * X2S + cb * 32 + j] = lo;
                 split2(fmaxf(a1[r] + bias, 0.f), hi, lo);
-                h2h[((pb0 + 1) * 32 + row) * X2S + cb * 32 + j] = hi; h2l[((pb0 + 1) * 32 + row) * X2S + cb * 32 + j] = lo;
+                h2h[((pb0 + 1) * 32 + row) * X2S + cb * 32 + j] = hi;
+                if (NT == 3) h2l[((pb0 + 1) * 32 + row) * X2S + cb * 32 + j] = lo;
             }
         }
         __syncthreads();
@@ -158,12 +175,15 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
         // One channel block x all four point blocks per step: 4 independent accumulator chains (an accumulator is
         // re-used every 4th MFMA) and the A fragments of k-step ks+1 in flight while k-step ks issues.
         auto block4 = [&](int cb) {
-            load_wx<8>(wah, wal, w3x, cb, lane);
+            load_wx<8, NT>(wah, wal, w3x, cb, lane);
             f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
             const int ro = j * X2S + h * 8;
             f32x4 ah[4], al[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { ah[q] = *(const f32x4 *)(h2h + ro + q * 32 * X2S); al[q] = *(const f32x4 *)(h2l + ro + q * 32 * X2S); }
+            for (int q = 0; q < 4; ++q) {
+                ah[q] = *(const f32x4 *)(h2h + ro + q * 32 * X2S);
+                al[q] = (NT == 3) ? *(const f32x4 *)(h2l + ro + q * 32 * X2S) : ah[q];
+            }
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
                 f32x4 nh[4], nl[4];
@@ -172,15 +192,17 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
                     nh[q] = ah[q]; nl[q] = al[q];
                     if (ks < 7) {
                         nh[q] = *(const f32x4 *)(h2h + ro + q * 32 * X2S + (ks + 1) * 16);
-                        nl[q] = *(const f32x4 *)(h2l + ro + q * 32 * X2S + (ks + 1) * 16);
+                        if (NT == 3) nl[q] = *(const f32x4 *)(h2l + ro + q * 32 * X2S + (ks + 1) * 16);
                     }
                 }
                 c0 = mfma_bf(ah[0], wah[ks], c0); c1 = mfma_bf(ah[1], wah[ks], c1);
                 c2 = mfma_bf(ah[2], wah[ks], c2); c3 = mfma_bf(ah[3], wah[ks], c3);
-                c0 = mfma_bf(ah[0], wal[ks], c0); c1 = mfma_bf(ah[1], wal[ks], c1);
-                c2 = mfma_bf(ah[2], wal[ks], c2); c3 = mfma_bf(ah[3], wal[ks], c3);
-                c0 = mfma_bf(al[0], wah[ks], c0); c1 = mfma_bf(al[1], wah[ks], c1);
-                c2 = mfma_bf(al[2], wah[ks], c2); c3 = mfma_bf(al[3], wah[ks], c3);
+                if (NT == 3) {
+                    c0 = mfma_bf(ah[0], wal[ks], c0); c1 = mfma_bf(ah[1], wal[ks], c1);
+                    c2 = mfma_bf(ah[2], wal[ks], c2); c3 = mfma_bf(ah[3], wal[ks], c3);
+                    c0 = mfma_bf(al[0], wah[ks], c0); c1 = mfma_bf(al[1], wah[ks], c1);
+                    c2 = mfma_bf(al[2], wah[ks], c2); c3 = mfma_bf(al[3], wah[ks], c3);
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { ah[q] = nh[q]; al[q] = nl[q]; }
             }
@@ -215,6 +237,7 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
 // ---------------------------------------------------------------------------------------
 #define X3T_LDS_BYTES (X3_LDS_BYTES + 3 * 1024 * 4)
 
+template <int NT>
 __global__ __launch_bounds__(512, 2) void trunk_fwd_train_x3_kernel(
     const float *__restrict__ x, int N, const float *__restrict__ trans,
     const float *__restrict__ w1, const float *__restrict__ b1, const float *__restrict__ s1c,
@@ -281,23 +304,26 @@ __global__ __launch_bounds__(512, 2) void trunk_fwd_train_x3_kernel(
                 vh.z = hv[q * 8 + 4] | ((unsigned)hv[q * 8 + 5] << 16); vh.w = hv[q * 8 + 6] | ((unsigned)hv[q * 8 + 7] << 16);
                 vl.x = lv[q * 8 + 0] | ((unsigned)lv[q * 8 + 1] << 16); vl.y = lv[q * 8 + 2] | ((unsigned)lv[q * 8 + 3] << 16);
                 vl.z = lv[q * 8 + 4] | ((unsigned)lv[q * 8 + 5] << 16); vl.w = lv[q * 8 + 6] | ((unsigned)lv[q * 8 + 7] << 16);
-                dh[q] = vh; dl[q] = vl;
+                dh[q] = vh;
+                if (NT == 3) dl[q] = vl;
             }
         }
         __syncthreads();
         {
             const int cb = wave & 3, pb0 = (wave >> 2) * 2;
             f32x4 w2h[4], w2l[4];
-            load_wx<4>(w2h, w2l, w2x, cb, lane);
+            load_wx<4, NT>(w2h, w2l, w2x, cb, lane);
             f32x16 a0 = {0}, a1 = {0};
             const int r0 = (pb0 * 32 + j) * X1S + h * 8, r1 = ((pb0 + 1) * 32 + j) * X1S + h * 8;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const f32x4 ah0 = *(const f32x4 *)(h1h + r0 + ks * 16), al0 = *(const f32x4 *)(h1l + r0 + ks * 16);
-                const f32x4 ah1 = *(const f32x4 *)(h1h + r1 + ks * 16), al1 = *(const f32x4 *)(h1l + r1 + ks * 16);
+                const f32x4 ah0 = *(const f32x4 *)(h1h + r0 + ks * 16), ah1 = *(const f32x4 *)(h1h + r1 + ks * 16);
                 a0 = mfma_bf(ah0, w2h[ks], a0); a1 = mfma_bf(ah1, w2h[ks], a1);
-                a0 = mfma_bf(ah0, w2l[ks], a0); a1 = mfma_bf(ah1, w2l[ks], a1);
-                a0 = mfma_bf(al0, w2h[ks], a0); a1 = mfma_bf(al1, w2h[ks], a1);
+                if (NT == 3) {
+                    const f32x4 al0 = *(const f32x4 *)(h1l + r0 + ks * 16), al1 = *(const f32x4 *)(h1l + r1 + ks * 16);
+                    a0 = mfma_bf(ah0, w2l[ks], a0); a1 = mfma_bf(ah1, w2l[ks], a1);
+                    a0 = mfma_bf(al0, w2h[ks], a0); a1 = mfma_bf(al1, w2h[ks], a1);
+                }
             }
             const float sc = s2c[cb * 32 + j], sh = t2c[cb * 32 + j];
 #pragma unroll
@@ -306,9 +332,11 @@ __global__ __launch_bounds__(512, 2) void trunk_fwd_train_x3_kernel(
                 u16 hi, lo;
                 const float v0 = fmaxf(fmaf(a0[r], sc, sh), 0.f), v1 = fmaxf(fmaf(a1[r], sc, sh), 0.f);
                 split2(v0, hi, lo);
-                h2h[(pb0 * 32 + row) * X2S + cb * 32 + j] = hi; h2l[(pb0 * 32 + row) * X2S + cb * 32 + j] = lo;
+                h2h[(pb0 * 32 + row) * X2S + cb * 32 + j] = hi;
+                if (NT == 3) h2l[(pb0 * 32 + row) * X2S + cb * 32 + j] = lo;
                 split2(v1, hi, lo);
-                h2h[((pb0 + 1) * 32 + row) * X2S + cb * 32 + j] = hi; h2l[((pb0 + 1) * 32 + row) * X2S + cb * 32 + j] = lo;
+                h2h[((pb0 + 1) * 32 + row) * X2S + cb * 32 + j] = hi;
+                if (NT == 3) h2l[((pb0 + 1) * 32 + row) * X2S + cb * 32 + j] = lo;
                 hsum += (nbase + pb0 * 32 + row < N) ? v0 : 0.f;
                 hsum += (nbase + (pb0 + 1) * 32 + row < N) ? v1 : 0.f;
             }
@@ -318,7 +346,7 @@ __global__ __launch_bounds__(512, 2) void trunk_fwd_train_x3_kernel(
 #pragma unroll 1
         for (int ci = 0; ci < 4; ++ci) {
             const int cb = wave + 8 * ci;
-            load_wx<8>(wah, wal, w3x, cb, lane);
+            load_wx<8, NT>(wah, wal, w3x, cb, lane);
             float m = -INFINITY, su = 0.f, qu = 0.f;
             int am = 0;
             // all four point blocks at once: 4 independent accumulator chains, A fragments of k-step ks+1 in flight
@@ -328,7 +356,10 @@ __global__ __launch_bounds__(512, 2) void trunk_fwd_train_x3_kernel(
                 const int ro = j * X2S + h * 8;
                 f32x4 ah[4], al[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { ah[q] = *(const f32x4 *)(h2h + ro + q * 32 * X2S); al[q] = *(const f32x4 *)(h2l + ro + q * 32 * X2S); }
+                for (int q = 0; q < 4; ++q) {
+                    ah[q] = *(const f32x4 *)(h2h + ro + q * 32 * X2S);
+                    al[q] = (NT == 3) ? *(const f32x4 *)(h2l + ro + q * 32 * X2S) : ah[q];
+                }
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
                     f32x4 nh[4], nl[4];
@@ -337,15 +368,17 @@ __global__ __launch_bounds__(512, 2) void trunk_fwd_train_x3_kernel(
                         nh[q] = ah[q]; nl[q] = al[q];
                         if (ks < 7) {
                             nh[q] = *(const f32x4 *)(h2h + ro + q * 32 * X2S + (ks + 1) * 16);
-                            nl[q] = *(const f32x4 *)(h2l + ro + q * 32 * X2S + (ks + 1) * 16);
+                            if (NT == 3) nl[q] = *(const f32x4 *)(h2l + ro + q * 32 * X2S + (ks + 1) * 16);
                         }
                     }
                     c0 = mfma_bf(ah[0], wah[ks], c0); c1 = mfma_bf(ah[1], wah[ks], c1);
                     c2 = mfma_bf(ah[2], wah[ks], c2); c3 = mfma_bf(ah[3], wah[ks], c3);
-                    c0 = mfma_bf(ah[0], wal[ks], c0); c1 = mfma_bf(ah[1], wal[ks], c1);
-                    c2 = mfma_bf(ah[2], wal[ks], c2); c3 = mfma_bf(ah[3], wal[ks], c3);
-                    c0 = mfma_bf(al[0], wah[ks], c0); c1 = mfma_bf(al[1], wah[ks], c1);
-                    c2 = mfma_bf(al[2], wah[ks], c2); c3 = mfma_bf(al[3], wah[ks], c3);
+                    if (NT == 3) {
+                        c0 = mfma_bf(ah[0], wal[ks], c0); c1 = mfma_bf(ah[1], wal[ks], c1);
+                        c2 = mfma_bf(ah[2], wal[ks], c2); c3 = mfma_bf(ah[3], wal[ks], c3);
+                        c0 = mfma_bf(al[0], wah[ks], c0); c1 = mfma_bf(al[1], wah[ks], c1);
+                        c2 = mfma_bf(al[2], wah[ks], c2); c3 = mfma_bf(al[3], wah[ks], c3);
+                    }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { ah[q] = nh[q]; al[q] = nl[q]; }
                 }
@@ -407,9 +440,32 @@ __global__ void pool_reduce_x3_kernel(const float *__restrict__ part, int S, flo
 
 #define X3_DEFAULT_TARGET_BLOCKS 1024
 
+template <int NT, bool XBF>
+static int launch_infer_bf(const void *x, int B, int N, const float *trans, const float *w1, const float *b1,
+                           const u16 *w2x, const float *b2, const u16 *w3x, const float *b3, int relu_last, int T,
+                           int S, float *dst, hipStream_t stream) {
+    int st = pngpd_allow_lds((const void *)trunk_infer_x3_kernel<NT, XBF>, X3_LDS_BYTES);
+    if (st != PNGPD_OK) return st;
+    hipLaunchKernelGGL((trunk_infer_x3_kernel<NT, XBF>), dim3((unsigned)B * S), dim3(512), X3_LDS_BYTES, stream,
+                       x, N, trans, w1, b1, w2x, b2, w3x, b3, relu_last, T, S, dst);
+    return pngpd_launch_status();
+}
+
+template <int NT>
+static int launch_train_bf(const float *x, int B, int N, const float *trans, const float *w1, const float *b1,
+                           const float *s1c, const float *t1c, const u16 *w2x, const float *s2c, const float *t2c,
+                           const u16 *w3sx, int T, int S, float *pmax, int *parg, float *psum, float *psh,
+                           hipStream_t stream) {
+    int st = pngpd_allow_lds((const void *)trunk_fwd_train_x3_kernel<NT>, X3T_LDS_BYTES);
+    if (st != PNGPD_OK) return st;
+    hipLaunchKernelGGL((trunk_fwd_train_x3_kernel<NT>), dim3((unsigned)B * S), dim3(512), X3T_LDS_BYTES, stream,
+                       x, N, trans, w1, b1, s1c, t1c, w2x, s2c, t2c, w3sx, T, S, pmax, parg, psum, psh);
+    return pngpd_launch_status();
+}
+
 extern "C" {
 
-int pngpd_trunk_infer_x3_splits(int B, int N, int target_blocks) {
+int pngpd_trunk_infer_bf_splits(int B, int N, int target_blocks) {
     if (B <= 0 || N <= 0) return 0;
     return pngpd_splits_for(B, (N + XP - 1) / XP, target_blocks > 0 ? target_blocks : X3_DEFAULT_TARGET_BLOCKS);
 }
@@ -422,11 +478,12 @@ int pngpd_split_pack_bf16(const float *W, int C, int K, void *out, void *stream)
     return pngpd_launch_status();
 }
 
-int pngpd_trunk_fwd_infer_x3(const float *x, int B, int N, const float *trans,
+int pngpd_trunk_fwd_infer_bf(const void *x, int x_is_bf16, int B, int N, const float *trans,
                              const float *w1, const float *b1, const void *w2x, const float *b2,
-                             const void *w3x, const float *b3, int relu_last, int splits,
+                             const void *w3x, const float *b3, int relu_last, int nterms, int splits,
                              float *out_pool, void *workspace, size_t workspace_bytes, void *stream) {
-    if (!x || !w1 || !b1 || !w2x || !b2 || !w3x || !b3 || !out_pool || B <= 0 || N <= 0)
+    if (!x || !w1 || !b1 || !w2x || !b2 || !w3x || !b3 || !out_pool || B <= 0 || N <= 0 ||
+        (nterms != 1 && nterms != 3))
         return PNGPD_ERR_INVALID_ARG;
     const int T = (N + XP - 1) / XP;
     const int S = (splits > 0) ? (splits > T ? T : splits) : pngpd_splits_for(B, T, X3_DEFAULT_TARGET_BLOCKS);
@@ -435,36 +492,39 @@ int pngpd_trunk_fwd_infer_x3(const float *x, int B, int N, const float *trans,
         if (!workspace || workspace_bytes < (size_t)B * S * 1024 * sizeof(float)) return PNGPD_ERR_WORKSPACE;
         dst = (float *)workspace;
     }
-    int st = pngpd_allow_lds((const void *)trunk_infer_x3_kernel, X3_LDS_BYTES);
-    if (st != PNGPD_OK) return st;
-    hipLaunchKernelGGL(trunk_infer_x3_kernel, dim3((unsigned)B * S), dim3(512), X3_LDS_BYTES, (hipStream_t)stream,
-                       x, N, trans, w1, b1, (const u16 *)w2x, b2, (const u16 *)w3x, b3, relu_last, T, S, dst);
-    st = pngpd_launch_status();
+    const u16 *w2 = (const u16 *)w2x, *w3 = (const u16 *)w3x;
+    hipStream_t sm = (hipStream_t)stream;
+    int st;
+    if (nterms == 3)
+        st = x_is_bf16 ? launch_infer_bf<3, true>(x, B, N, trans, w1, b1, w2, b2, w3, b3, relu_last, T, S, dst, sm)
+                       : launch_infer_bf<3, false>(x, B, N, trans, w1, b1, w2, b2, w3, b3, relu_last, T, S, dst, sm);
+    else
+        st = x_is_bf16 ? launch_infer_bf<1, true>(x, B, N, trans, w1, b1, w2, b2, w3, b3, relu_last, T, S, dst, sm)
+                       : launch_infer_bf<1, false>(x, B, N, trans, w1, b1, w2, b2, w3, b3, relu_last, T, S, dst, sm);
     if (st != PNGPD_OK) return st;
     if (S > 1) {
         const int total = B * 1024;
-        hipLaunchKernelGGL(pool_reduce_x3_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(pool_reduce_x3_kernel, dim3((total + 255) / 256), dim3(256), 0, sm,
                            (const float *)workspace, S, out_pool, total);
         st = pngpd_launch_status();
     }
     return st;
 }
 
-int pngpd_trunk_fwd_train_x3(const float *x, int B, int N, const float *trans,
+int pngpd_trunk_fwd_train_bf(const float *x, int B, int N, const float *trans,
                              const float *w1, const float *b1, const float *s1c, const float *t1c,
-                             const void *w2x, const float *s2c, const float *t2c, const void *w3sx, int S,
+                             const void *w2x, const float *s2c, const float *t2c, const void *w3sx, int nterms, int S,
                              float *pmax, int *parg, float *psum, float *psh, void *stream) {
     if (!x || !w1 || !b1 || !s1c || !t1c || !w2x || !s2c || !t2c || !w3sx || !pmax || !parg || !psum || !psh ||
-        B <= 0 || N <= 0)
+        B <= 0 || N <= 0 || (nterms != 1 && nterms != 3))
         return PNGPD_ERR_INVALID_ARG;
     const int T = (N + XP - 1) / XP;
     if (S < 1 || S > T) return PNGPD_ERR_INVALID_ARG;   // S: the split count the caller sized pmax/parg/psum for
-    int st = pngpd_allow_lds((const void *)trunk_fwd_train_x3_kernel, X3T_LDS_BYTES);
-    if (st != PNGPD_OK) return st;
-    hipLaunchKernelGGL(trunk_fwd_train_x3_kernel, dim3((unsigned)B * S), dim3(512), X3T_LDS_BYTES, (hipStream_t)stream,
-                       x, N, trans, w1, b1, s1c, t1c, (const u16 *)w2x, s2c, t2c, (const u16 *)w3sx, T, S,
-                       pmax, parg, psum, psh);
-    return pngpd_launch_status();
+    return nterms == 3
+        ? launch_train_bf<3>(x, B, N, trans, w1, b1, s1c, t1c, (const u16 *)w2x, s2c, t2c, (const u16 *)w3sx, T, S,
+                             pmax, parg, psum, psh, (hipStream_t)stream)
+        : launch_train_bf<1>(x, B, N, trans, w1, b1, s1c, t1c, (const u16 *)w2x, s2c, t2c, (const u16 *)w3sx, T, S,
+                             pmax, parg, psum, psh, (hipStream_t)stream);
 }
 
 }  // extern "C"

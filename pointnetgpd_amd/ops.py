@@ -108,10 +108,13 @@ def split_pack_bf16(Wf):
     return out
 
 
-def trunk_fwd_infer_x3(x, trans, w1, b1, w2x, b2, w3x, b3, relu_last, splits=0):
-    """bf16x3 variant of trunk_fwd_infer (see include/pngpd.h)."""
+def trunk_fwd_infer_bf(x, trans, w1, b1, w2x, b2, w3x, b3, relu_last, nterms=3, splits=0):
+    """Reduced-precision trunk on the bf16 matrix cores (pngpd_trunk_fwd_infer_bf): nterms = 3 "bf16x3" split
+    products, nterms = 1 plain bf16.  x (B,3,N) float32 or bfloat16 (bf16 cloud storage)."""
     lib = _lib.load()
-    _req(x, "x")
+    if not isinstance(x, torch.Tensor) or not x.is_cuda or x.dtype not in (torch.float32, torch.bfloat16) or \
+            not x.is_contiguous():
+        raise RuntimeError("x: expected a contiguous CUDA float32 or bfloat16 tensor")
     if x.dim() != 3 or x.shape[1] != 3:
         raise RuntimeError(f"x: expected (B,3,N), got {tuple(x.shape)}")
     B, _, N = x.shape
@@ -121,13 +124,14 @@ def trunk_fwd_infer_x3(x, trans, w1, b1, w2x, b2, w3x, b3, relu_last, splits=0):
     if w2x.dtype != torch.int16 or w2x.numel() != 2 * 128 * 64 or w3x.dtype != torch.int16 or w3x.numel() != 2 * 1024 * 128:
         raise RuntimeError("w2x/w3x: expected split_pack_bf16 outputs")
     out = torch.empty(B, 1024, device=x.device, dtype=torch.float32)
-    S = int(splits) if splits and splits > 0 else lib.pngpd_trunk_infer_x3_splits(B, N, 0)
+    S = int(splits) if splits and splits > 0 else lib.pngpd_trunk_infer_bf_splits(B, N, 0)
     nbytes = B * S * 1024 * 4 if S > 1 else 0
     ws = _workspace(x.device, nbytes)
     with _lib.device_guard(x.device):
-        _lib.check(lib.pngpd_trunk_fwd_infer_x3(_ptr(x), B, N, _ptr(trans), _ptr(w1), _ptr(b1), _ptr(w2x), _ptr(b2),
-                                                _ptr(w3x), _ptr(b3), int(bool(relu_last)), S, _ptr(out), _ptr(ws),
-                                                nbytes, _stream(x)), "trunk_fwd_infer_x3")
+        _lib.check(lib.pngpd_trunk_fwd_infer_bf(_ptr(x), int(x.dtype == torch.bfloat16), B, N, _ptr(trans), _ptr(w1),
+                                                _ptr(b1), _ptr(w2x), _ptr(b2), _ptr(w3x), _ptr(b3),
+                                                int(bool(relu_last)), int(nterms), S, _ptr(out), _ptr(ws), nbytes,
+                                                _stream(x)), "trunk_fwd_infer_bf")
     return out
 
 
@@ -237,17 +241,17 @@ def trunk_fwd_train(x, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, w3sp, S):
     return pmax, parg, psum, psh
 
 
-def trunk_fwd_train_x3(x, trans, w1, b1, s1c, t1c, w2x, s2c, t2c, w3sx, S):
-    """bf16x3 variant of trunk_fwd_train; returns (pmax (B,Sx,1024), parg, psum (B*Sx,2,1024), psh (B*Sx*2,128), Sx)
-    with Sx = min(S, ceil(N/128)) (128-point tiles)."""
+def trunk_fwd_train_bf(x, trans, w1, b1, s1c, t1c, w2x, s2c, t2c, w3sx, S, nterms=3):
+    """bf16 matrix-core variant of trunk_fwd_train (nterms 3 = bf16x3, 1 = plain bf16); returns (pmax (B,Sx,1024),
+    parg, psum (B*Sx,2,1024), psh (B*Sx*2,128), Sx) with Sx = min(S, ceil(N/128)) (128-point tiles)."""
     B, _, N = x.shape
     S = max(1, min(int(S), (N + 127) // 128))
     pmax = torch.empty(B, S, 1024, device=x.device, dtype=torch.float32)
     parg = torch.empty(B, S, 1024, device=x.device, dtype=torch.int32)
     psum = torch.empty(B * S, 2, 1024, device=x.device, dtype=torch.float32)
     psh = torch.empty(B * S * 2, 128, device=x.device, dtype=torch.float32)
-    _call("pngpd_trunk_fwd_train_x3", x, x, B, N, trans, w1, b1, s1c, t1c, w2x, s2c, t2c, w3sx, int(S), pmax, parg,
-          psum, psh)
+    _call("pngpd_trunk_fwd_train_bf", x, x, B, N, trans, w1, b1, s1c, t1c, w2x, s2c, t2c, w3sx, int(nterms), int(S),
+          pmax, parg, psum, psh)
     return pmax, parg, psum, psh, S
 
 

@@ -18,13 +18,19 @@ from . import ops
 from .ops import _call
 
 F64 = torch.float64
-_TRAIN_PRECISION = "fp32"   # "bf16x3": opt-in split-bf16 products for the main forward pass (pass C)
+# Arithmetic of the main forward pass (pass C, 60 % of a step's matrix FLOPs): "fp32" exact; "bf16x3" opt-in 3-term
+# split-bf16 products (same parity bars as fp32); "bf16" opt-in plain bf16 operands (BASELINE configs[2]; errors
+# measured in tests/test_gpu_bf16.py).  BatchNorm statistics, the closed-form backward and every accumulator stay
+# fp32/fp64 in all modes; the backward passes D/E contract over POINTS and would need transposed bf16 tiles — they
+# run fp32.
+_TRAIN_PRECISION = "fp32"
+_NTERMS = {"bf16x3": 3, "bf16": 1}
 
 
 def set_train_precision(mode):
     global _TRAIN_PRECISION
-    if mode not in ("fp32", "bf16x3"):
-        raise ValueError("precision must be 'fp32' or 'bf16x3'")
+    if mode not in ("fp32", "bf16x3", "bf16"):
+        raise ValueError("precision must be 'fp32', 'bf16x3' or 'bf16'")
     _TRAIN_PRECISION = mode
 DEBUG_STASH = None   # set to a dict to capture backward intermediates (tests/test_gpu_train.py::test_trunk_backward_intermediates)
 
@@ -93,10 +99,11 @@ class TrunkTrainFn(torch.autograd.Function):
         # ---- pass C + BN3 + pool
         sgn = torch.where(g3c >= 0, 1.0, -1.0).to(torch.float32)
         Sc = S
-        if _TRAIN_PRECISION == "bf16x3":
+        if _TRAIN_PRECISION != "fp32":
             w3s = (w3 * sgn[:, None]).contiguous()
-            pmax, parg, psum, psh, Sc = ops.trunk_fwd_train_x3(x, T, w1, b1c, s1c, t1c, ops.split_pack_bf16(w2), s2c,
-                                                               t2c, ops.split_pack_bf16(w3s), S)
+            pmax, parg, psum, psh, Sc = ops.trunk_fwd_train_bf(x, T, w1, b1c, s1c, t1c, ops.split_pack_bf16(w2), s2c,
+                                                               t2c, ops.split_pack_bf16(w3s), S,
+                                                               nterms=_NTERMS[_TRAIN_PRECISION])
         else:
             w3sp = ops.pack_mfma_b(w3, scale=sgn)
             pmax, parg, psum, psh = ops.trunk_fwd_train(x, T, w1, b1c, s1c, t1c, w2p, s2c, t2c, w3sp, S)

@@ -42,6 +42,26 @@ def synth_cloud(b, n, seed, kind="box"):
         return (u * torch.tensor([w / 2, w, w / 2]).view(1, 3, 1)).float().contiguous()
     if kind == "gauss":
         return (torch.randn(b, 3, n, generator=g) * 0.02).float().contiguous()
+    if kind == "diverse":
+        # clouds that differ from each other (per-cloud anisotropic scale, rotation, offset, box / gaussian / shell
+        # mix): with iid box clouds the pooled features are almost identical across the batch, the FC BatchNorms
+        # divide by a vanishing batch variance and ANY arithmetic noise is amplified — not representative of crops
+        # of real scenes
+        w = 0.085
+        base = torch.rand(b, 3, n, generator=g) - 0.5
+        gau = torch.randn(b, 3, n, generator=g) * 0.3
+        mix = torch.rand(b, 1, 1, generator=g)
+        pts = torch.where(mix < 0.5, base, gau)
+        shell = pts / pts.norm(dim=1, keepdim=True).clamp_min(1e-3) * 0.5
+        pts = torch.where(mix > 0.8, shell, pts)
+        scale = (0.4 + 1.2 * torch.rand(b, 3, 1, generator=g)) * torch.tensor([w / 2, w, w / 2]).view(1, 3, 1)
+        q = torch.randn(b, 4, generator=g); q = q / q.norm(dim=1, keepdim=True)
+        a, bq, c, d = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+        R = torch.stack([1 - 2 * (c * c + d * d), 2 * (bq * c - a * d), 2 * (bq * d + a * c),
+                         2 * (bq * c + a * d), 1 - 2 * (bq * bq + d * d), 2 * (c * d - a * bq),
+                         2 * (bq * d - a * c), 2 * (c * d + a * bq), 1 - 2 * (bq * bq + c * c)], 1).view(b, 3, 3)
+        off = (torch.rand(b, 3, 1, generator=g) - 0.5) * 0.02
+        return (torch.bmm(R, pts * scale) + off).float().contiguous()
     return torch.randn(b, 3, n, generator=g).float().contiguous()
 
 

@@ -1,0 +1,111 @@
+"""GPU: the plain-bf16 mode (BASELINE.json configs[2]: "3-class ... bf16") — bf16 cloud storage (6 B/point), single-
+product v_mfma_f32_32x32x16_bf16 with fp32 accumulation for the two GEMM layers of the trunk, fp32 BatchNorm
+statistics.  SURVEY.md §7: bf16 operands do NOT meet the 1e-3 log-prob contract in general, so this file MEASURES and
+BOUNDS the error against the fp32/fp64 oracle (printed with -s, summarised in DESIGN.md §2.1c) instead of asserting
+1e-3: max |d log-prob|, arg-max agreement (overall and where the oracle's margin exceeds the bf16 error), and for the
+training step the loss and per-tensor gradient errors."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import pointnet_oracle as po
+from tests.helpers import build_model, state_dict_cpu, synth_cloud, oracle_train_step_on_device
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def bf16_modes():
+    from pointnetgpd_amd.model import pointnet as pn
+    from pointnetgpd_amd import train
+    yield pn, train
+    pn.set_inference_precision("fp32")
+    train.set_train_precision("fp32")
+
+
+@pytest.mark.parametrize("B,N,k,kind", [(512, 1024, 3, "box"), (64, 750, 2, "box"), (7, 129, 3, "gauss")])
+def test_bf16_inference_error(B, N, k, kind, bf16_modes, cuda_device):
+    pn, _ = bf16_modes
+    m = build_model(N, k, 610 + B, 6100 + B).eval()
+    sd = state_dict_cpu(m)
+    x = synth_cloud(B, N, 2500 + B, kind)
+    with torch.no_grad():
+        lp_ref, tr_ref = po.forward_torch(sd, x)
+    mg = m.to(cuda_device)
+    xg = x.to(cuda_device)
+    with torch.no_grad():
+        lp32, _ = mg(xg)
+        pn.set_inference_precision("bf16")
+        lp_b, tr_b = mg(xg)                                   # bf16 arithmetic, fp32 cloud storage
+        xb = xg.to(torch.bfloat16)
+        lp_bs, tr_bs = mg(xb)                                 # bf16 arithmetic AND bf16 cloud storage
+        pn.set_inference_precision("fp32")
+        lp_st, _ = mg(xb)                                     # fp32 arithmetic on the bf16-stored cloud
+    assert "libpngpd.so" in open("/proc/self/maps").read()
+    ref = lp_ref
+    margin = ref.max(1)[0] - ref.kthvalue(ref.shape[1] - 1, 1)[0]
+    rows = {}
+    for name, lp in (("fp32", lp32), ("bf16 arithmetic", lp_b), ("bf16 arithmetic + storage", lp_bs),
+                     ("fp32 arithmetic, bf16 storage", lp_st)):
+        d = (lp.cpu() - ref).abs().max().item()
+        agree = (lp.argmax(1).cpu() == ref.argmax(1)).float().mean().item()
+        rows[name] = (d, agree)
+        print(f"[B={B} N={N} k={k} {kind}] {name:32s} max|dlogp| {d:.3e}  argmax agreement {agree:.4f}")
+    assert rows["fp32"][0] < 1e-3
+    # measured round 2: bf16 arithmetic 2e-3 .. 3e-2, storage alone up to ~5e-2 on these clouds
+    assert rows["bf16 arithmetic"][0] < 0.15 and rows["bf16 arithmetic"][1] >= 0.95
+    assert rows["bf16 arithmetic + storage"][0] < 0.3 and rows["bf16 arithmetic + storage"][1] >= 0.9
+    # where the oracle's decision margin exceeds twice the measured error, the decision is identical
+    d = rows["bf16 arithmetic"][0]
+    clear = margin > 2 * d
+    assert (lp_b.argmax(1).cpu()[clear] == ref.argmax(1)[clear]).all()
+    assert torch.isfinite(lp_bs).all() and (tr_bs.cpu() - tr_ref).abs().max().item() < 0.3
+
+
+@pytest.mark.parametrize("kind", ["diverse", "box"])
+def test_bf16_train_step_error(kind, bf16_modes, cuda_device):
+    """BASELINE configs[2] per-GPU share: k = 3, B = 512, N = 1024; pass C in bf16, bf16 cloud storage.
+    "box" = the bench's iid box clouds: the pooled features are nearly identical across the batch, so the FC
+    BatchNorms (batch statistics) divide by a vanishing variance and amplify any arithmetic noise — reported, only
+    finiteness asserted.  "diverse" = clouds that differ from each other, as crops of real scenes do: bounded."""
+    pn, train = bf16_modes
+    B, N, k = 512, 1024, 3
+    m = build_model(N, k, 77, 6177).train()
+    sd = state_dict_cpu(m)
+    x = synth_cloud(B, N, 2677, kind)
+    y = (torch.arange(B) * 7 % k).long()
+    loss_ref, logp_ref, trans_ref, g64, stats_ref = oracle_train_step_on_device(sd, x, y, torch.float64, cuda_device)
+    _, logp32, _, g32, _ = oracle_train_step_on_device(sd, x, y, torch.float32, cuda_device)
+    res = {}
+    names = [n for n in g64 if g64[n].double().norm().item() >= 1e-9]
+
+    def summarise(tag, loss, logp, grads):
+        rel = {n: (grads[n].double() - g64[n].double()).norm().item() / g64[n].double().norm().item() for n in names}
+        worst = max(rel, key=rel.get)
+        big = {n: r for n, r in rel.items() if n.endswith("conv3.weight") or n.endswith("fc1.weight")}
+        res[tag] = (abs(loss - loss_ref.item()), (logp - logp_ref).abs().max().item(), rel[worst],
+                    float(np.median(list(rel.values()))),
+                    (logp.argmax(1) == logp_ref.argmax(1)).float().mean().item())
+        print(f"[train {kind} B={B} N={N} k={k}] {tag:22s} |dloss| {res[tag][0]:.2e}  max|dlogp| {res[tag][1]:.2e}  argmax "
+              f"{res[tag][4]:.4f}  grad rel err: median {res[tag][3]:.2e}, worst {worst} {rel[worst]:.2e}, "
+              + ", ".join(f"{n} {r:.2e}" for n, r in sorted(big.items())))
+
+    summarise("ATen fp32 (yardstick)", F.nll_loss(logp32, y).item(), logp32, g32)
+    for mode, xin in (("fp32", x), ("bf16x3", x), ("bf16", x), ("bf16+storage", x.to(torch.bfloat16))):
+        mm = build_model(N, k, 77, 6177).train().to(cuda_device)
+        train.set_train_precision("bf16" if mode.startswith("bf16+") else mode)
+        try:
+            logp, _ = mm(xin.to(cuda_device))
+            loss = F.nll_loss(logp, y.to(cuda_device))
+            loss.backward()
+        finally:
+            train.set_train_precision("fp32")
+        assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in mm.parameters())
+        summarise(mode, loss.item(), logp.detach().cpu(), {n: p.grad.cpu() for n, p in mm.named_parameters()})
+    assert res["fp32"][0] < 1e-3 and res["fp32"][1] < 1e-3            # the exact mode: 1e-3 on any input
+    if kind == "diverse":
+        assert res["bf16x3"][0] < 1e-3 and res["bf16x3"][1] < 1e-3    # the exact-enough mode: 1e-3
+        # plain bf16: bounded, NOT 1e-3 (bounds = measured round-2 values x ~3)
+        assert res["bf16"][0] < 0.02 and res["bf16"][1] < 0.1 and res["bf16"][4] >= 0.97
+        assert res["bf16"][3] < 0.25 and res["bf16+storage"][3] < 0.3

@@ -42,17 +42,19 @@ def main():
         y = torch.randint(0, k, (B,), device=dev)
         flops = B * (N * 557842 + 2627072)
         row = dict(config=name)
-        for prec in ("fp32", "bf16x3"):
-            pn.set_inference_precision(prec)
+        xb = x.to(torch.bfloat16)
+        for prec in ("fp32", "bf16x3", "bf16", "bf16_storage"):
+            pn.set_inference_precision("bf16" if prec == "bf16_storage" else prec)
             m.eval()
+            xin = xb if prec == "bf16_storage" else x
             with torch.no_grad():
-                ms = timeit(lambda: m(x), 20)
+                ms = timeit(lambda: m(xin), 20)
             row[f"infer_{prec}_ms"] = round(ms, 3)
             row[f"infer_{prec}_grasps_s"] = round(B / ms * 1e3)
             if prec == "fp32":
                 row["infer_fp32_tflops"] = round(flops / ms / 1e9, 1)
         pn.set_inference_precision("fp32")
-        for prec in ("fp32", "bf16x3"):
+        for prec in ("fp32", "bf16x3", "bf16"):
             pt.set_train_precision(prec)
             m.train()
             opt = torch.optim.Adam(m.parameters(), lr=0.005, fused=True)
