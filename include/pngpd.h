@@ -278,13 +278,17 @@ int pngpd_crop_count_compact_gather(const void *arena, int cloud_is_f64, int P, 
                                     void *stream);
 /* out (G,3,N) fp32 = N resampled in-box points per grasp in the hand frame (the `.T` layout of
  * dataset.py:440-444); valid (G) = count >= min_points (dataset.py:71, kinect2grasp.py:462).
- * mode 0: without replacement iff m > N (dataset.py:439); mode 1: iff m >= N (kinect2grasp.py:474),
- * m = min(count, max_keep).  sel (G,N) int32 ranks in [0,m) injects the draw (else device RNG
- * keyed by seed; a without-replacement draw is a uniform random N-subset written in ascending
- * point-index order — the scorer is invariant to the column order).  Invalid grasps are zero-filled. */
-int pngpd_crop_resample(const void *cloud, int cloud_is_f64, const double *frames, int G, const int *counts,
-                        const int *idx, int max_keep, int N, int mode, int min_points,
-                        unsigned long long seed, const int *sel, float *out, unsigned char *valid, void *stream);
+ * mode 0: without replacement iff count > N (dataset.py:439); mode 1: iff count >= N (kinect2grasp.py:474).
+ * The draw is uniform over ALL `count` in-box points even when count > max_keep (the index list is then only a
+ * prefix): such a grasp re-scans its own cloud, described exactly as for the count pass — cloud/P, and ranges
+ * (G,2) or gather (G,Pg) when the count pass used them (else NULL).  sel (G,N) int32 ranks in [0, min(count,
+ * max_keep)) injects the draw (tests; list-based, no re-scan); otherwise a device RNG keyed by seed; a
+ * without-replacement draw is a uniform random N-subset written in ascending point-index order — the scorer is
+ * invariant to the column order.  Invalid grasps are zero-filled.  Dynamic LDS: max(max_keep, N) * 4 bytes.   */
+int pngpd_crop_resample(const void *cloud, int cloud_is_f64, int P, const double *frames, const int *ranges,
+                        const int *gather, int Pg, int G, const int *counts, const int *idx, int max_keep, int N,
+                        int mode, int min_points, unsigned long long seed, const int *sel, float *out,
+                        unsigned char *valid, void *stream);
 
 /* =======================================================================================
  * GPG grasp-candidate sampler, device half (upstream of the crop at inference) —

@@ -85,9 +85,9 @@ SIGNATURES = {
                                                        ctypes.c_int, c_void, c_void, c_void]),
     "pngpd_crop_count_compact_gather": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, c_void, ctypes.c_int,
                                                        ctypes.c_int, ctypes.c_int, c_void, c_void, c_void]),
-    "pngpd_crop_resample": (ctypes.c_int, [c_void, ctypes.c_int, c_void, ctypes.c_int, c_void, c_void,
-                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                           ctypes.c_ulonglong, c_void, c_void, c_void, c_void]),
+    "pngpd_crop_resample": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, c_void, c_void, ctypes.c_int,
+                                           ctypes.c_int, c_void, c_void, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_ulonglong, c_void, c_void, c_void, c_void]),
     # ---- GPG sampler (device half)
     "pngpd_gpg_normal_moments": (ctypes.c_int, [c_void, ctypes.c_int, c_void, ctypes.c_int, c_void, ctypes.c_int,
                                                 ctypes.c_double, ctypes.c_int, c_void, c_void, c_void]),

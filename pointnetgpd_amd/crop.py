@@ -148,8 +148,13 @@ def crop_count_compact_gather(arena, frames, gather, max_keep=4096):
 
 
 def crop_resample(cloud, frames, counts, idx, num_points, mode=MODE_INFER, min_points=MIN_POINTS_TO_NET,
-                  seed=0, sel=None):
-    """-> out (G,3,num_points) fp32 in the hand frame, valid (G) bool."""
+                  seed=0, sel=None, ranges=None, gather=None):
+    """-> out (G,3,num_points) fp32 in the hand frame, valid (G) bool.
+
+    ``ranges`` / ``gather``: the same per-grasp cloud description the count pass was given
+    (``crop_count_compact_ranges`` / ``_gather``).  They matter only for grasps holding MORE than ``max_keep`` in-box
+    points: the draw stays uniform over all of them (kinect2grasp.py:473-478, dataset.py:438-444) by re-scanning
+    the grasp's own cloud instead of using the truncated index list."""
     lib = _lib.load()
     cloud, frames = cloud.contiguous(), frames.contiguous()
     G, max_keep = idx.shape
@@ -159,9 +164,20 @@ def crop_resample(cloud, frames, counts, idx, num_points, mode=MODE_INFER, min_p
         if not sel.is_cuda or sel.dtype != torch.int32 or tuple(sel.shape) != (G, num_points):
             raise RuntimeError("sel: expected a CUDA (G,N) int32 tensor")
         sel = sel.contiguous()
+    Pg = 0
+    if ranges is not None:
+        if not ranges.is_cuda or ranges.dtype != torch.int32 or tuple(ranges.shape) != (G, 2):
+            raise RuntimeError("ranges: expected a CUDA (G,2) int32 tensor")
+        ranges = ranges.contiguous()
+    if gather is not None:
+        if not gather.is_cuda or gather.dtype != torch.int32 or gather.dim() != 2 or gather.shape[0] != G:
+            raise RuntimeError("gather: expected a CUDA (G,Pg) int32 tensor")
+        gather = gather.contiguous()
+        Pg = gather.shape[1]
     with _lib.device_guard(cloud.device):
-        _lib.check(lib.pngpd_crop_resample(_p(cloud), int(cloud.dtype == torch.float64), _p(frames), G, _p(counts),
-                                           _p(idx), int(max_keep), int(num_points), int(mode), int(min_points),
+        _lib.check(lib.pngpd_crop_resample(_p(cloud), int(cloud.dtype == torch.float64), cloud.shape[0], _p(frames),
+                                           _p(ranges), _p(gather), int(Pg), G, _p(counts), _p(idx), int(max_keep),
+                                           int(num_points), int(mode), int(min_points),
                                            ctypes.c_ulonglong(int(seed) & (2 ** 64 - 1)), _p(sel), _p(out),
                                            _p(valid), _stream(cloud)), "crop_resample")
     return out, valid.bool()

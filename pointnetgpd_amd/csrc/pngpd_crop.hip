@@ -120,17 +120,26 @@ __device__ __forceinline__ int crop_block_sum(int v, int *sh) {
 // LDS), and the winners leave in ascending rank by ballot-ordered compaction — fully parallel, where a
 // Fisher-Yates draw is a serial chain of N dependent swaps.  The column ORDER of the output is therefore the
 // index order, not a random permutation; the scorer is invariant to it (per-point MLP + max-pool).
+//
+// count > max_keep (the index list was truncated): the draw must still be uniform over ALL in-box points
+// (kinect2grasp.py:473-478, dataset.py:438-444), so the kernel re-scans the grasp's own cloud instead of using the
+// list.  Without replacement: the same keys (counter hash of the in-box RANK) are recomputed on the fly and the
+// N-th smallest is found by a 4-level radix histogram (4 scans) + 1 emitting scan.  With replacement (only
+// possible when max_keep < count <= N): the full list (count <= N entries) is rebuilt in LDS first.
 template <bool F64>
 __global__ __launch_bounds__(256) void crop_resample_kernel(
-    const void *__restrict__ cloud, const double *__restrict__ frames, const int *__restrict__ counts,
+    const void *__restrict__ cloud, int P, const double *__restrict__ frames, const int *__restrict__ ranges,
+    const int *__restrict__ gather, int Pg, const int *__restrict__ counts,
     const int *__restrict__ idx, int max_keep, int N, int mode, int min_points, unsigned long long seed,
     const int *__restrict__ sel, float *__restrict__ out, unsigned char *__restrict__ valid) {
-    extern __shared__ unsigned keys[];   // [max_keep] only used for the without-replacement draw
+    extern __shared__ unsigned keys[];   // [max(max_keep, N)]: keys of the without-replacement draw / rebuilt list
     __shared__ int shi[4];
     __shared__ int wsel[4], wtie[4];
+    __shared__ int hist[256];
+    __shared__ int hsel[2];
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cnt = counts[g];
-    const int m = cnt < max_keep ? cnt : max_keep;
+    int m = cnt < max_keep ? cnt : max_keep;
     float *o = out + (size_t)g * 3 * N;
     const bool ok = cnt >= min_points && m > 0;
     if (tid == 0) valid[g] = ok ? 1 : 0;
@@ -141,6 +150,108 @@ __global__ __launch_bounds__(256) void crop_resample_kernel(
     Frame F;
     load_frame(frames + (size_t)g * 18, F);
     const int *gi = idx + (size_t)g * max_keep;
+    if (cnt > max_keep && !sel) {
+        // ---- overflow: scan the grasp's own cloud (same order and test as crop_count_compact_kernel)
+        const int p_begin = (!gather && ranges) ? ranges[2 * g] : 0;
+        const int n = gather ? Pg : (ranges ? ranges[2 * g + 1] : P);
+        const int *gl = gather ? gather + (size_t)g * Pg : nullptr;
+        auto key_of = [&](int rank) {
+            return (unsigned)(mix64(seed ^ mix64(((unsigned long long)g << 32) | (unsigned)rank)) >> 32);
+        };
+        // scan(f): f(in, rank, p) for every candidate point, rank = number of in-box points before it
+        auto scan = [&](auto f) {
+            int running = 0;
+            for (int base = 0; base < n; base += 256) {
+                const int i = base + tid;
+                bool in = false; int p = 0;
+                if (i < n) {
+                    p = gl ? gl[i] : p_begin + i;
+                    double x, y, z, a, b, c;
+                    load_point<F64>(cloud, p, x, y, z);
+                    to_frame(F, x, y, z, a, b, c);
+                    in = (a > F.lo[0]) && (a < F.hi[0]) && (b > F.lo[1]) && (b < F.hi[1]) && (c > F.lo[2]) && (c < F.hi[2]);
+                }
+                const unsigned long long mask = __ballot(in);
+                __syncthreads();
+                if (lane == 0) wsel[wave] = __popcll(mask);
+                __syncthreads();
+                int woff = 0, total = 0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { const int c = wsel[w]; if (w < wave) woff += c; total += c; }
+                f(in, running + woff + __popcll(mask & ((1ull << lane) - 1ull)), p);
+                running += total;
+            }
+        };
+        const bool without_all = (mode == 0) ? (cnt > N) : (cnt >= N);
+        if (!without_all) {   // with replacement and max_keep < cnt <= N: rebuild the complete list in LDS
+            int *list = (int *)keys;
+            scan([&](bool in, int rank, int p) { if (in) list[rank] = p; });
+            __syncthreads();
+            for (int nn = tid; nn < N; nn += 256) {
+                const int r = (int)(mix64(seed ^ mix64(((unsigned long long)g << 32) | (unsigned)nn)) % (unsigned long long)cnt);
+                double x, y, z, a, b, c;
+                load_point<F64>(cloud, list[r], x, y, z);
+                to_frame(F, x, y, z, a, b, c);
+                o[nn] = (float)a; o[N + nn] = (float)b; o[2 * N + nn] = (float)c;
+            }
+            return;
+        }
+        // N-th smallest key by radix selection: prefix = the key bits fixed so far, need = how many keys with
+        // that prefix are still to be taken
+        unsigned prefix = 0u; int need = N;
+        for (int level = 0; level < 4; ++level) {
+            const int shift = 24 - 8 * level;
+            hist[tid] = 0;
+            __syncthreads();
+            scan([&](bool in, int rank, int) {
+                if (in) {
+                    const unsigned k = key_of(rank);
+                    if (level == 0 || (k >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(k >> shift) & 255u], 1);
+                }
+            });
+            __syncthreads();
+            if (tid == 0) {   // 256 bins: a serial walk is cheaper than a scan
+                int acc = 0, b = 0;
+                for (; b < 255 && acc + hist[b] < need; ++b) acc += hist[b];
+                hsel[0] = b; hsel[1] = need - acc;
+            }
+            __syncthreads();
+            prefix |= (unsigned)hsel[0] << shift;
+            need = hsel[1];
+            __syncthreads();
+        }
+        const unsigned T = prefix;   // keys < T are all taken; of the keys == T the `need` lowest ranks
+        int run_sel = 0, run_tie = 0;
+        scan([&](bool in, int rank, int p) {
+            const unsigned k = in ? key_of(rank) : 0xFFFFFFFFu;
+            const bool tie = in && k == T;
+            const unsigned long long tmask = __ballot(tie);
+            __syncthreads();
+            if (lane == 0) wtie[wave] = __popcll(tmask);
+            __syncthreads();
+            int toff = 0, ttot = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { const int c = wtie[w]; if (w < wave) toff += c; ttot += c; }
+            const int tie_rank = run_tie + toff + __popcll(tmask & ((1ull << lane) - 1ull));
+            const bool take = in && (k < T || (tie && tie_rank < need));
+            const unsigned long long smask = __ballot(take);
+            __syncthreads();
+            if (lane == 0) wtie[wave] = __popcll(smask);
+            __syncthreads();
+            int soff = 0, stot = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { const int c = wtie[w]; if (w < wave) soff += c; stot += c; }
+            if (take) {
+                const int nn = run_sel + soff + __popcll(smask & ((1ull << lane) - 1ull));
+                double x, y, z, a, b, c;
+                load_point<F64>(cloud, p, x, y, z);
+                to_frame(F, x, y, z, a, b, c);
+                o[nn] = (float)a; o[N + nn] = (float)b; o[2 * N + nn] = (float)c;
+            }
+            run_sel += stot; run_tie += ttot;
+        });
+        return;
+    }
     const bool without = (mode == 0) ? (m > N) : (m >= N);
     if (!sel && without) {
         for (int i = tid; i < m; i += 256)
@@ -245,24 +356,27 @@ int pngpd_crop_count_compact_gather(const void *arena, int cloud_is_f64, int P, 
     return pngpd_launch_status();
 }
 
-int pngpd_crop_resample(const void *cloud, int cloud_is_f64, const double *frames, int G, const int *counts,
-                        const int *idx, int max_keep, int N, int mode, int min_points,
-                        unsigned long long seed, const int *sel, float *out, unsigned char *valid, void *stream) {
-    if (!cloud || !frames || !counts || !idx || !out || !valid || G <= 0 || max_keep <= 0 || N <= 0 ||
-        (mode != 0 && mode != 1))
+int pngpd_crop_resample(const void *cloud, int cloud_is_f64, int P, const double *frames, const int *ranges,
+                        const int *gather, int Pg, int G, const int *counts, const int *idx, int max_keep, int N,
+                        int mode, int min_points, unsigned long long seed, const int *sel, float *out,
+                        unsigned char *valid, void *stream) {
+    if (!cloud || !frames || !counts || !idx || !out || !valid || P <= 0 || G <= 0 || max_keep <= 0 || N <= 0 ||
+        (mode != 0 && mode != 1) || (gather && Pg <= 0))
         return PNGPD_ERR_INVALID_ARG;
-    const size_t lds = (size_t)max_keep * sizeof(int);
+    const size_t lds = (size_t)(max_keep > N ? max_keep : N) * sizeof(int);
     if (lds > 150 * 1024) return PNGPD_ERR_UNSUPPORTED;
     if (cloud_is_f64) {
         const int st = pngpd_allow_lds((const void *)crop_resample_kernel<true>, lds);
         if (st != PNGPD_OK) return st;
         hipLaunchKernelGGL(crop_resample_kernel<true>, dim3(G), dim3(256), lds, (hipStream_t)stream,
-                           cloud, frames, counts, idx, max_keep, N, mode, min_points, seed, sel, out, valid);
+                           cloud, P, frames, ranges, gather, Pg, counts, idx, max_keep, N, mode, min_points, seed, sel,
+                           out, valid);
     } else {
         const int st = pngpd_allow_lds((const void *)crop_resample_kernel<false>, lds);
         if (st != PNGPD_OK) return st;
         hipLaunchKernelGGL(crop_resample_kernel<false>, dim3(G), dim3(256), lds, (hipStream_t)stream,
-                           cloud, frames, counts, idx, max_keep, N, mode, min_points, seed, sel, out, valid);
+                           cloud, P, frames, ranges, gather, Pg, counts, idx, max_keep, N, mode, min_points, seed, sel,
+                           out, valid);
     }
     return pngpd_launch_status();
 }

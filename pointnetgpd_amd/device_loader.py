@@ -127,11 +127,11 @@ class DeviceGraspLoader:
                 gather = self._gather_lists(spans, bi)
                 counts, idx = crop.crop_count_compact_gather(self.arena, fr, gather, self.max_keep)
             else:
-                gather = None
-                rg = torch.from_numpy(spans.astype(np.int32)).to(self.device)
+                gather, rg = None, torch.from_numpy(spans.astype(np.int32)).to(self.device)
                 counts, idx = crop.crop_count_compact_ranges(self.arena, fr, rg, self.max_keep)
             out, valid = crop.crop_resample(self.arena, fr, counts, idx, ds.grasp_points_num, crop.MODE_TRAIN,
-                                            ds.min_point_limit, seed=(self.seed * 1000003 + self.epoch) * 100003 + bi)
+                                            ds.min_point_limit, seed=(self.seed * 1000003 + self.epoch) * 100003 + bi,
+                                            ranges=None if self.fullview else rg, gather=gather)
             keep = valid & torch.from_numpy(has_label).to(self.device)     # my_collate drops the Nones
             self.last_meta = dict(items=items, views=views, counts=counts, keep=keep, labels=labels, gather=gather)
             yield out[keep], torch.from_numpy(labels).to(self.device)[keep]

@@ -240,3 +240,41 @@ def test_resample_without_replacement_is_a_uniform_subset(cuda_device):
     freq = torch.bincount(rank.reshape(-1), minlength=m).double() / G
     p = N / m
     assert float((freq - p).abs().max()) < 5 * np.sqrt(p * (1 - p) / G)
+
+
+@pytest.mark.parametrize("max_keep,N,mode_name", [(128, 16, "infer"), (64, 32, "train"), (48, 500, "train")])
+def test_resample_uniform_over_all_points_when_count_exceeds_max_keep(max_keep, N, mode_name, cuda_device):
+    """A hand holding MORE in-box points than ``max_keep``: the draw is still uniform over ALL of them (reference:
+    np.random.choice over the whole in-box set, kinect2grasp.py:473-478 / dataset.py:438-444), not over the first
+    max_keep in index order.  Third case: count <= N with max_keep < count -> the with-replacement branch, also over
+    every in-box point."""
+    from pointnetgpd_amd import crop
+    pc, grasps = _scene(1, 40000, 77)
+    pc32 = pc.astype(np.float32)
+    G = 3000
+    mode = crop.MODE_INFER if mode_name == "infer" else crop.MODE_TRAIN
+    frames1 = crop.frames_from_grasps_infer(grasps)
+    frames = torch.from_numpy(np.repeat(frames1, G, 0)).to(cuda_device)
+    cloud = torch.from_numpy(pc32).to(cuda_device)
+    counts, idx = crop.crop_count_compact(cloud, frames, max_keep=max_keep)
+    m = int(counts[0])
+    assert m > max_keep, (m, max_keep)
+    out, valid = crop.crop_resample(cloud, frames, counts, idx, N, mode, 1, seed=4321)
+    assert bool(valid.all())
+    ind_ref, pts_ref = co.collect_pc_infer(grasps, pc32)
+    assert len(ind_ref[0]) == m
+    ref32 = torch.from_numpy(pts_ref[0].astype(np.float32)).to(cuda_device)          # (m,3)
+    rank = torch.empty(G, N, dtype=torch.long, device=cuda_device)
+    for s in range(0, G, 250):                                                       # (250,N,m) distance blocks
+        d = (out[s:s + 250].permute(0, 2, 1).unsqueeze(2) - ref32.view(1, 1, m, 3)).abs().amax(3)
+        assert float(d.amin(2).max()) <= 1e-8                                        # every column IS an in-box point
+        rank[s:s + 250] = d.argmin(2)
+    without = m > N if mode == crop.MODE_TRAIN else m >= N
+    if without:
+        assert bool((rank[:, 1:] > rank[:, :-1]).all())                              # distinct, ascending index order
+    freq = torch.bincount(rank.reshape(-1), minlength=m).double() / G
+    p = N / m
+    sd = np.sqrt(p * (1 - p) / G) if without else np.sqrt(N * (1 / m) * (1 - 1 / m) / G)
+    assert float((freq - p).abs().max()) < 5.5 * sd, (float((freq - p).abs().max()), sd)
+    # the points beyond the truncated list are drawn as often as the ones inside it
+    assert abs(float(freq[max_keep:].mean()) / float(freq[:max_keep].mean()) - 1.0) < 0.05
