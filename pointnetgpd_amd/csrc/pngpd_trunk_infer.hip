@@ -40,6 +40,11 @@ __global__ __launch_bounds__(256, 2) void trunk_infer_kernel(
         for (int i = 0; i < 9; ++i) tm[i] = trans[(size_t)b * 9 + i];
     }
     for (int i = L.tid; i < 1024; i += 256) rm[i] = -INFINITY;
+    // A non-finite input coordinate must reach the output like it does through max_pool1d / torch.max (which
+    // propagate NaN), but fmaxf drops NaNs and the ReLUs turn them into zeros: remember it and poison this
+    // workgroup's pooled row at the end.
+    __shared__ int s_bad;
+    if (L.tid == 0) s_bad = 0;
     // layer-3 weight fragments are double-buffered in registers: while channel block ci is on the
     // MFMA pipe the 16 KiB of block ci+1 are in flight from L2 (the last block of a tile prefetches the
     // first block of the next tile, which also covers the tile prologue).
@@ -61,6 +66,7 @@ __global__ __launch_bounds__(256, 2) void trunk_infer_kernel(
                 x2 = fmaf(px2, tm[8], fmaf(px1, tm[5], px0 * tm[2]));
             }
             xs[L.tid] = x0; xs[TP + L.tid] = x1; xs[2 * TP + L.tid] = x2;
+            if (!__builtin_isfinite(px0 + px1 + px2)) s_bad = 1;
             if (tile + 1 < t1) {
                 int n = (tile + 1) * TP + L.tid; n = n < N ? n : N - 1;
                 px0 = xb[n]; px1 = xb[N + n]; px2 = xb[2 * N + n];
@@ -127,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void trunk_infer_kernel(
             const int c = (L.wave + 4 * ci) * 32 + L.j;
             float v = rm[c] + b3[c];
             if (relu_last) v = fmaxf(v, 0.f);
-            o[c] = v;
+            o[c] = s_bad ? __builtin_nanf("") : v;
         }
     }
 }
@@ -138,8 +144,9 @@ __global__ void pool_reduce_kernel(const float *__restrict__ part, int S, float 
     int b = idx >> 10, c = idx & 1023;
     const float *p = part + (size_t)b * S * 1024 + c;
     float m = p[0];
-    for (int s = 1; s < S; ++s) m = fmaxf(m, p[(size_t)s * 1024]);
-    out[idx] = m;
+    bool nan = m != m;
+    for (int s = 1; s < S; ++s) { const float v = p[(size_t)s * 1024]; nan |= v != v; m = fmaxf(m, v); }
+    out[idx] = nan ? __builtin_nanf("") : m;   // NaN-propagating like torch.max
 }
 
 #define TRUNK_DEFAULT_TARGET_BLOCKS 2048   // 8 per CU; measured flat between 1024 and 4096 at B = N = 1024

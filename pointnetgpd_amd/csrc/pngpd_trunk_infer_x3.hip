@@ -93,6 +93,9 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
         for (int i = 0; i < 9; ++i) tm[i] = trans[(size_t)b * 9 + i];
     }
     for (int i = tid; i < 1024; i += 512) rm[i] = -INFINITY;
+    __shared__ int s_bad;   // non-finite input coordinate seen: poison the pooled row (see trunk_infer_kernel)
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
 
     // layer-3 weight fragments (hi+lo of one 32-channel block = 64 VGPRs)
     f32x4 wah[8], wal[8];
@@ -112,6 +115,7 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
                 x2 = fmaf(px2, tm[8], fmaf(px1, tm[5], px0 * tm[2]));
             }
             xs[tid] = x0; xs[XP + tid] = x1; xs[2 * XP + tid] = x2;
+            if (!__builtin_isfinite(px0 + px1 + px2)) s_bad = 1;
             if (tile + 1 < t1) {
                 int n = (tile + 1) * XP + tid; n = n < N ? n : N - 1;
                 px0 = ldx<XBF>(x, xo + n); px1 = ldx<XBF>(x, xo + N + n); px2 = ldx<XBF>(x, xo + 2 * (size_t)N + n);
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
             const int c = (wave + 8 * ci) * 32 + j;
             float v = rm[c] + b3[c];
             if (relu_last) v = fmaxf(v, 0.f);
-            o[c] = v;
+            o[c] = s_bad ? __builtin_nanf("") : v;
         }
     }
 }
@@ -434,8 +438,9 @@ __global__ void pool_reduce_x3_kernel(const float *__restrict__ part, int S, flo
     int b = idx >> 10, c = idx & 1023;
     const float *p = part + (size_t)b * S * 1024 + c;
     float m = p[0];
-    for (int s = 1; s < S; ++s) m = fmaxf(m, p[(size_t)s * 1024]);
-    out[idx] = m;
+    bool nan = m != m;
+    for (int s = 1; s < S; ++s) { const float v = p[(size_t)s * 1024]; nan |= v != v; m = fmaxf(m, v); }
+    out[idx] = nan ? __builtin_nanf("") : m;
 }
 
 #define X3_DEFAULT_TARGET_BLOCKS 1024

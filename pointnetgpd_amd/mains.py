@@ -131,9 +131,20 @@ class SyntheticGraspDataset(torch.utils.data.Dataset):
         return pc, label
 
 
-def _make_loaders(cfg, args):
+def per_rank_batch(batch_size, world):
+    """--batch-size is the GLOBAL batch, as under the reference's ``nn.DataParallel`` (main_1v.py:158-165 scatters one
+    batch of --batch-size over the GPUs): each rank loads batch_size / world samples, lr is unchanged."""
+    if world <= 1:
+        return batch_size
+    if batch_size % world:
+        raise ValueError(f"--batch-size {batch_size} must be divisible by the number of ranks ({world})")
+    return batch_size // world
+
+
+def _make_loaders(cfg, args, world=1):
     from .model import dataset as ds
-    common = dict(batch_size=args.batch_size, num_workers=args.num_workers, pin_memory=True, shuffle=True,
+    args.rank_batch = per_rank_batch(args.batch_size, world)
+    common = dict(batch_size=args.rank_batch, num_workers=args.num_workers, pin_memory=True, shuffle=True,
                   worker_init_fn=worker_init_fn, collate_fn=my_collate)
     if args.synthetic:
         tr = SyntheticGraspDataset(args.synthetic, cfg["num_points"], cfg["k"], seed=1)
@@ -155,10 +166,28 @@ def _make_loaders(cfg, args):
     if getattr(args, "device_data", False) and args.cuda and sampler is None and not args.synthetic:
         from .device_loader import DeviceGraspLoader
         dev = torch.device("cuda", args.gpu if args.gpu != -1 else 0)
-        train_loader = DeviceGraspLoader(tr, args.batch_size, dev, shuffle=True, seed=args.seed or 0,
+        train_loader = DeviceGraspLoader(tr, args.rank_batch, dev, shuffle=True, seed=args.seed or 0,
                                          max_keep=16384 if cfg["fullview"] else 8192)
         return train_loader, torch.utils.data.DataLoader(te, **common), train_loader   # set_epoch() like a sampler
     return (torch.utils.data.DataLoader(tr, **common_tr), torch.utils.data.DataLoader(te, **common), sampler)
+
+
+def save_model(model, path):
+    """Whole-module pickle like the reference's ``torch.save(model, path)`` (main_1v.py:177-178), written so that BOTH
+    implementations can load it: the classes are pickled under the reference's module path ``model.pointnet`` (which
+    ``install_reference_aliases`` maps to this package, and which IS the reference's own module in its scripts —
+    kinect2grasp.py / main_test.py); the per-instance cache of folded inference weights is never pickled."""
+    from . import install_reference_aliases
+    from .model import pointnet as pn
+    install_reference_aliases()
+    classes = [c for c in vars(pn).values() if isinstance(c, type) and c.__module__ == pn.__name__]
+    try:
+        for c in classes:
+            c.__module__ = "model.pointnet"
+        torch.save(model, path)          # _HipModule.__getstate__ leaves the fold cache out
+    finally:
+        for c in classes:
+            c.__module__ = pn.__name__
 
 
 def run(variant, argv=None):
@@ -174,7 +203,7 @@ def run(variant, argv=None):
     else:
         np.random.seed(args.seed); torch.manual_seed(args.seed)
     logger = _ScalarLog(os.path.join(args.log_dir, args.tag)) if rank == 0 else None
-    train_loader, test_loader, sampler = _make_loaders(cfg, args)
+    train_loader, test_loader, sampler = _make_loaders(cfg, args, world)
 
     device = torch.device("cpu")
     if args.cuda:
@@ -187,6 +216,8 @@ def run(variant, argv=None):
         from . import install_reference_aliases
         install_reference_aliases()
         model = torch.load(args.load_model, map_location=device, weights_only=False)
+        if isinstance(model, torch.nn.DataParallel):     # a reference checkpoint saved with --gpu -1 (main_1v.py:158-165)
+            model = model.module
         print("load model {}".format(args.load_model))
     else:
         model = PointNetCls(num_points=cfg["num_points"], input_chann=3, k=cfg["k"])
@@ -231,7 +262,7 @@ def run(variant, argv=None):
             dataset_size += data.shape[0]
             data, target = data.float(), target.long().squeeze()
             data, target = data.to(device), target.to(device)
-            if use_graph and data.shape[0] == args.batch_size and target.dim() == 1:
+            if use_graph and data.shape[0] == args.rank_batch and target.dim() == 1:
                 if state["graph"] is None:
                     from .train import GraphedTrainStep
                     state["graph"] = GraphedTrainStep(model, data.shape[0], data.shape[2], optimizer=optimizer)
@@ -249,7 +280,7 @@ def run(variant, argv=None):
             pred = output.data.max(1, keepdim=True)[1]
             correct += pred.eq(target.view_as(pred)).long().cpu().sum()
             if batch_idx % args.log_interval == 0 and rank == 0:
-                percentage = 100. * batch_idx * args.batch_size / len(train_loader.dataset)
+                percentage = 100. * batch_idx * args.batch_size / len(train_loader.dataset)   # global samples
                 print(f"Train Epoch: {epoch} [{batch_idx * args.batch_size}/{len(train_loader.dataset)} "
                       f"({percentage}%)]\tLoss: {loss.item()}\t{args.tag}")
                 logger.add_scalar("train_loss", loss.cpu().item(), batch_idx + epoch * len(train_loader))
@@ -288,7 +319,7 @@ def run(variant, argv=None):
                 logger.add_scalar("test_loss", loss, epoch)
                 if epoch % args.save_interval == 0:
                     path = os.path.join(args.model_path, args.tag + "_{}.model".format(epoch))
-                    torch.save(model, path)
+                    save_model(model, path)
                     print("Save model @ {}".format(path))
             result = dict(train_acc=acc_train, test_acc=acc, test_loss=loss, epoch=epoch)
     else:

@@ -62,6 +62,13 @@ CASES = [   # (class name, ctor kwargs) recorded by make_golden.py and replayed 
                                with_obj=True)),
     ("PointGraspMultiClassDataset", dict(obj_points_num=4000, grasp_points_num=100, pc_file_used_num=3,
                                          grasp_amount_per_file=12, thresh_good=0.5, thresh_bad=1.2, tag="test")),
+    # items the reference returns as None: (a) a score between the two thresholds of the 2-class rule
+    # (dataset.py:448-453), (b) fewer than min_point_limit in-box points (dataset.py:71-72; the limit is an instance
+    # attribute set in __init__, raised here after construction so that the 3000-point views fall below it)
+    ("PointGraspOneViewDataset", dict(grasp_points_num=64, grasp_amount_per_file=12, thresh_good=0.5,
+                                      thresh_bad=1.2, tag="train")),
+    ("PointGraspOneViewDataset", dict(grasp_points_num=64, grasp_amount_per_file=12, thresh_good=0.6,
+                                      thresh_bad=0.6, tag="test"), dict(min_point_limit=175)),
 ]
 
 
@@ -71,8 +78,11 @@ def replay(module, root, np_seed=77, indices=range(0, 36, 5)):
     not depend on set-iteration order of ``self.object`` (hash-randomised between processes)."""
     os.environ["PointNetGPD_FOLDER"] = root
     out = []
-    for name, kw in CASES:
+    for case in CASES:
+        name, kw = case[0], case[1]
         ds = getattr(module, name)(**kw)
+        for attr, val in (case[2] if len(case) > 2 else {}).items():
+            setattr(ds, attr, val)
         assert len(ds) == len(OBJECTS) * kw["grasp_amount_per_file"], (name, len(ds))
         ds.object = sorted(ds.object)
         for key in ds.d_pc:               # glob order is filesystem-dependent (full-view classes do not sort)

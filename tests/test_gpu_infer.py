@@ -163,3 +163,32 @@ def test_wrong_num_points_raises(cuda_device):
         m(torch.zeros(2, 3, 65, device=cuda_device))
     with pytest.raises(RuntimeError, match="Float"):
         m(torch.zeros(2, 3, 64, device=cuda_device, dtype=torch.float64))
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("B,N", [(6, 200), (40, 1024)])       # one workgroup per cloud / several workgroups per cloud
+def test_non_finite_coordinates_propagate(B, N, precision, cuda_device):
+    """A NaN coordinate poisons exactly its own cloud's outputs, as through the reference's max_pool1d / torch.max
+    (NaN-propagating) — although the kernels reduce with fmaxf (NaN-dropping) and ReLU maps NaN to 0.  The other
+    clouds of the batch are bit-identical to a clean run (eval-mode BatchNorm couples nothing)."""
+    from pointnetgpd_amd.model import pointnet as pn
+    m = build_model(N, 3, 41, 4141).eval()
+    x = synth_cloud(B, N, 808, "box")
+    xb = x.clone()
+    xb[1, 2, N // 2] = float("nan")
+    xb[B - 1, 0, N - 1] = float("inf")
+    with torch.no_grad():
+        ref_lp, ref_tr = m(xb)                            # CPU: the ATen composite the reference runs
+    mg = m.to(cuda_device)
+    pn.set_inference_precision(precision)
+    try:
+        with torch.no_grad():
+            lp_clean, _ = mg(x.to(cuda_device))
+            lp, tr = mg(xb.to(cuda_device))
+    finally:
+        pn.set_inference_precision("fp32")
+    lp, tr, lp_clean = lp.cpu(), tr.cpu(), lp_clean.cpu()
+    assert torch.isnan(ref_lp[1]).all() and torch.isnan(lp[1]).all() and torch.isnan(tr[1]).all()
+    assert not torch.isfinite(lp[B - 1]).any() and not torch.isfinite(ref_lp[B - 1]).any()
+    clean = [b for b in range(B) if b not in (1, B - 1)]
+    assert torch.equal(lp[clean], lp_clean[clean]) and torch.isfinite(lp[clean]).all()

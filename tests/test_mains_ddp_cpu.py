@@ -182,3 +182,53 @@ def test_cli_two_ranks_gloo(tmp_path):
     r0 = torch.load(tmp_path / "cli0.pt"); r1 = torch.load(tmp_path / "cli1.pt")
     assert np.isfinite(r0["test_loss"]) and np.isfinite(r1["test_loss"])
     assert (tmp_path / "m" / "ddp_0.model").exists()
+
+
+def test_per_rank_batch_keeps_the_reference_global_batch():
+    """--batch-size is the global batch (the reference's nn.DataParallel scatters ONE batch of --batch-size,
+    main_1v.py:158-165): each of `world` ranks loads batch_size / world."""
+    from pointnetgpd_amd import mains
+    assert mains.per_rank_batch(512, 1) == 512 and mains.per_rank_batch(512, 8) == 64
+    with pytest.raises(ValueError, match="divisible"):
+        mains.per_rank_batch(100, 8)
+
+
+REF = "/root/reference/PointNetGPD"
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "model", "pointnet.py")),
+                    reason="needs the reference checkout (build container only)")
+def test_saved_checkpoint_loads_in_the_unmodified_reference(tmp_path):
+    """Two-way pickle compatibility: a checkpoint written by mains.save_model unpickles in a process that only has
+    the REFERENCE's model.pointnet on its path (as kinect2grasp.py / main_test.py do) and computes the same output;
+    the same file also loads back onto this implementation."""
+    import subprocess
+    from pointnetgpd_amd import mains
+    from pointnetgpd_amd.model.pointnet import PointNetCls
+    torch.manual_seed(3)
+    m = PointNetCls(64, 3, 3).eval()
+    x = torch.randn(4, 3, 64)
+    with torch.no_grad():
+        m(x)                                         # populate the fold cache: it must not be pickled
+        lp, _ = m(x)
+    path = str(tmp_path / "ckpt.model")
+    mains.save_model(m, path)
+    assert type(m).__module__ == "pointnetgpd_amd.model.pointnet"          # restored after saving
+    torch.save(dict(x=x, lp=lp), str(tmp_path / "io.pt"))
+    code = (f"import sys, torch; sys.path.insert(0, {REF!r})\n"
+            f"m = torch.load({path!r}, weights_only=False)\n"
+            "assert type(m).__module__ == 'model.pointnet' and 'reference' in sys.modules['model.pointnet'].__file__\n"
+            f"io = torch.load({str(tmp_path / 'io.pt')!r})\n"
+            "m.eval()\n"
+            "with torch.no_grad(): lp, _ = m(io['x'])\n"
+            "assert torch.allclose(lp, io['lp'], atol=1e-6), (lp - io['lp']).abs().max()\n"
+            "print('REFERENCE-LOADED-OK')\n")
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path), env=env)
+    assert "REFERENCE-LOADED-OK" in out.stdout, out.stderr[-1500:]
+    from pointnetgpd_amd import install_reference_aliases
+    install_reference_aliases()
+    back = torch.load(path, weights_only=False)
+    assert isinstance(back, PointNetCls)
+    with torch.no_grad():
+        assert torch.equal(back.eval()(x)[0], lp)
