@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void fc_kernel(const float *__restrict__ in, i
         const int orow = rb * 32 + mfma_row(r, lane);
         float v = acc[r] + bv;
         if (epi == PNGPD_EPI_RELU) {
-            v = fmaxf(v, 0.f);
+            v = (v < 0.f) ? 0.f : v;   // NaN-propagating like F.relu (fmaxf would turn a NaN into 0)
         } else if (epi == PNGPD_EPI_ADD_IDEN3) {
             if (c == 0 || c == 4 || c == 8) v += 1.0f;
         } else if (epi == PNGPD_EPI_LOG_SOFTMAX) {
