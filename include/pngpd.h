@@ -317,6 +317,37 @@ int pngpd_hand_box_counts_indexed(const void *cloud_sorted, int cloud_is_f64, in
                                   const double *poses, int Q, const double *boxes, int num_boxes, int *counts,
                                   void *stream);
 
+/* =======================================================================================
+ * GPD baseline (the comparator model of the paper) and the depth-registration preprocessing — SURVEY.md §8f-4.
+ * ======================================================================================= */
+/* PointNetGPD/model/dataset.py:88-198 (project_pc / cal_projection) given the in-box points and their normals:
+ * points / normals (sum M_g, 3) f64 = the kept points of all G grasps in the hand frame, concatenated in input order;
+ * offsets (G+1) int32; widths (G) f64 gripper widths.  out (G,60,60,chann) f64, chann 3 = the normal image of
+ * projection order (0,1,2); chann 12 = [occupancy, normal xyz] x orders (0,1,2), (1,2,0), (0,2,1) (:104-116).
+ * Points with a NaN normal component are skipped (:97-101).  Bit-identical to numpy (float32 sequential normal sums,
+ * last-z-wins pixel assignment).  project_size must be 60 (as in the reference, :221).                       */
+int pngpd_gpd_projection(const double *points, const double *normals, const int *offsets, const double *widths,
+                         int G, int chann, int project_size, int margin, int voxel_point_num, double *out,
+                         void *stream);
+/* PointNetGPD/ycb_cloud_generate.py:60-121 registerDepthMap: depth (hd,wd) f64 metres, cam20 = depthK fx,fy,cx,cy |
+ * rgbK fx,fy,cx,cy | H_RGBFromDepth rows 0..2 (3x4) -> registered (hr,wr) f64 (zero where nothing lands; the
+ * largest transformed depth per pixel, as the reference's `>` keeps).                                        */
+int pngpd_depth_register(const double *depth, int hd, int wd, const double *cam20, int hr, int wr,
+                         double *registered, void *stream);
+/* :124-184 registeredDepthMapToPointCloud (organized=False): the pixels with depth > 0 in row-major order ->
+ * xyz (count,3) f64 in the object frame (+ their colours when rgb / rgb_out are given); cam28 = rgbK fx,fy,cx,cy |
+ * refFromRGB 3x4 | objFromref 3x4.  xyz / rgb_out must hold h*w rows; *count (device int) receives the number
+ * written.  workspace: pngpd_depth_cloud_workspace_bytes(h, w).                                              */
+size_t pngpd_depth_cloud_workspace_bytes(int h, int w);
+int pngpd_depth_to_cloud(const double *depth, int h, int w, const double *cam28, const unsigned char *rgb,
+                         double *xyz, unsigned char *rgb_out, int *count, void *workspace, size_t workspace_bytes,
+                         void *stream);
+/* PointNetGPD/model/gpd.py:13-24: one convolution stage of GPDClassifier = Conv2d(Cin,Cout,5) (valid) + bias +
+ * MaxPool2d(2, stride 2), no activation (as the reference).  in (B,Cin,Hin,Hin), W (Cout,Cin,5,5), out
+ * (B,Cout,(Hin-4)/2,(Hin-4)/2) fp32.  The two FC layers of the classifier use pngpd_fc_fwd.                  */
+int pngpd_conv5_pool2(const float *in, int B, int Cin, int Hin, const float *W, const float *bias, int Cout,
+                      float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

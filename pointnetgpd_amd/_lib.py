@@ -93,6 +93,16 @@ SIGNATURES = {
                                                 ctypes.c_double, ctypes.c_int, c_void, c_void, c_void]),
     "pngpd_hand_box_counts": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, ctypes.c_int, c_void,
                                              ctypes.c_int, c_void, c_void]),
+    # ---- GPD baseline + depth registration
+    "pngpd_gpd_projection": (ctypes.c_int, [c_void, c_void, c_void, c_void, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_int, ctypes.c_int, c_void, c_void]),
+    "pngpd_depth_register": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, ctypes.c_int, ctypes.c_int,
+                                            c_void, c_void]),
+    "pngpd_depth_cloud_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "pngpd_depth_to_cloud": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, c_void, c_void, c_void, c_void,
+                                            c_void, ctypes.c_size_t, c_void]),
+    "pngpd_conv5_pool2": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, ctypes.c_int,
+                                         c_f32p, c_void]),
     "pngpd_hand_box_counts_indexed": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, ctypes.c_int, c_void,
                                                      ctypes.c_int, c_void, ctypes.c_int, c_void, c_void]),
 }

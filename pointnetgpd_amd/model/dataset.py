@@ -13,8 +13,10 @@ Same classes, constructor keywords, on-disk layout, numpy RNG call sequence and 
 ``__getitem__`` runs inside forked DataLoader workers, where a HIP context cannot be used, so —
 exactly like the reference — it is numpy on the host (fp64).  The crop arithmetic is shared with
 the batched GPU crop (``pointnetgpd_amd.crop``: same frames, same strict box test).  The GPD
-projection branch (``projection=True``, dataset.py:78-198) belongs to the GPD CNN baseline and is
-out of scope: it raises ``NotImplementedError``.
+projection branch (``projection=True``, dataset.py:78-198: the 60x60 images of the CNN baseline) is implemented on
+the host without the reference's per-point Python loop; its surface normals come from open3d when installed, or
+from ``dataset.normal_estimator`` (open3d's un-oriented estimate cannot be reproduced bit for bit — the images are
+pinned given the normals, tests/golden/gpd_projection.npz).  The batched GPU version is ``gpd_ops.project_grasps``.
 
 Differences that do not change results: ``.npy`` files are opened memory-mapped and kept in a small
 per-process LRU (the reference re-reads the whole grasp file for every sample).
@@ -29,8 +31,7 @@ import torch.utils.data
 
 from .. import crop
 
-_PROJECTION_MSG = ("projection=True builds the 60x60 GPD images of the CNN baseline "
-                   "(reference dataset.py:78-198); only the PointNet path is implemented here")
+_ORDERS = ((0, 1, 2), (1, 2, 0), (0, 2, 1))        # dataset.py:104,110,113
 
 
 class _NpyCache:
@@ -67,8 +68,67 @@ class BaseGraspDataset(torch.utils.data.Dataset):
         if len(self.in_ind) < self.min_point_limit:
             return None
         if self.projection:
-            raise NotImplementedError(_PROJECTION_MSG)
+            f = np.asarray(frame, dtype=np.float64)
+            pc_t = (f[3:12].reshape(3, 3).dot((np.asarray(pc) - f[0:3]).T)).T      # the whole cloud in the hand frame
+            return self.project_pc(pc_t, np.asarray(grasp, dtype=np.float64)[6])  # width = grasp[6], dataset.py:22
         return pts
+
+    # ---- GPD baseline images (reference dataset.py:78-198) -------------------------------------------------
+    normal_estimator = None     # callable(points (P,3)) -> normals (P,3); None = open3d's estimate_normals (:78-86)
+
+    def get_normal(self, points, radius=0.1, max_nn=30):
+        if self.normal_estimator is not None:
+            return np.asarray(self.normal_estimator(points), dtype=np.float64)
+        try:
+            import open3d as o3d
+            pcd = o3d.geometry.PointCloud()
+            pcd.points = o3d.utility.Vector3dVector(points)
+            pcd.estimate_normals(search_param=o3d.geometry.KDTreeSearchParamHybrid(radius=radius, max_nn=max_nn))
+            return np.asarray(pcd.normals)
+        except (ImportError, AttributeError) as e:
+            raise RuntimeError("projection=True needs surface normals: open3d is not installed here — set "
+                               "`dataset.normal_estimator = fn(points) -> normals`") from e
+
+    def project_pc(self, pc, gripper_width):
+        """dataset.py:88-118: (60,60,3|12) float64 images of the in-box points ``pc[self.in_ind]``."""
+        nrm = self.get_normal(pc)
+        pts, nrm = np.asarray(pc, dtype=np.float64)[self.in_ind], np.asarray(nrm, dtype=np.float64)[self.in_ind]
+        ok = ~np.isnan(nrm).any(axis=1)                              # rows with a NaN normal are deleted (:97-101)
+        pts, nrm = pts[ok], nrm[ok]
+        occ1, n1 = self.cal_projection(pts, self.project_size, self.projection_margin, nrm, _ORDERS[0], gripper_width)
+        if self.project_chann == 3:
+            return n1
+        occ2, n2 = self.cal_projection(pts, self.project_size, self.projection_margin, nrm, _ORDERS[1], gripper_width)
+        occ3, n3 = self.cal_projection(pts, self.project_size, self.projection_margin, nrm, _ORDERS[2], gripper_width)
+        return np.dstack([occ1, n1, occ2, n2, occ3, n3])
+
+    def cal_projection(self, point_cloud_voxel, m_width_of_pic, margin, surface_normal, order, gripper_width):
+        """dataset.py:139-198 without the Python loop over points: voxels are ranked by a stable sort, the float32
+        normal sums are accumulated rank by rank (sequential per voxel, like the reference's buffer fill), and the
+        (x, y) pixel keeps the voxel with the largest z index (numpy's last-write-wins on the sorted unique list)."""
+        S = m_width_of_pic
+        occupy, norm = np.zeros((S, S, 1)), np.zeros((S, S, 3))
+        p = np.asarray(point_cloud_voxel, dtype=np.float64)
+        a, b = p[:, order[0]], p[:, order[1]]
+        if max(a.max() - a.min(), b.max() - b.min()) == 0:
+            return occupy, norm
+        res = gripper_width / (S - margin)
+        vox = np.stack([np.floor(p[:, o] / res + S / 2).astype(np.int64) for o in order], 1)
+        uniq, inv = np.unique(vox, axis=0, return_inverse=True)
+        inv = inv.reshape(-1)
+        first = np.argsort(inv, kind="stable")                       # points grouped by voxel, input order kept
+        start = np.searchsorted(inv[first], np.arange(len(uniq)))
+        rank = np.empty(len(p), dtype=np.int64)
+        rank[first] = np.arange(len(p)) - start[inv[first]]
+        number = np.minimum(np.bincount(inv, minlength=len(uniq)), self.voxel_point_num)
+        acc = np.zeros((len(uniq), 3), dtype=np.float32)
+        n32 = np.asarray(surface_normal, dtype=np.float64).astype(np.float32)
+        for r in range(int(number.max())):                           # <= voxel_point_num rounds, each one float32 add
+            sel = np.nonzero(rank == r)[0]
+            acc[inv[sel]] = acc[inv[sel]] + n32[sel]
+        norm[uniq[:, 0], uniq[:, 1], :] = acc.astype(np.float64) / number[:, None].astype(np.float64)
+        occupy[uniq[:, 0], uniq[:, 1], 0] = number
+        return occupy / occupy.max(), norm
 
     # ---- shared pieces of the four concrete datasets
     def _init_common(self, grasp_points_num, grasp_amount_per_file, thresh_good, thresh_bad, tag, with_obj,
@@ -116,7 +176,7 @@ class BaseGraspDataset(torch.utils.data.Dataset):
         if grasp_pc is None:
             return None
         level_score, refine_score = grasp[-2:]
-        grasp_pc = self._resample(grasp_pc)
+        grasp_pc = grasp_pc.transpose((2, 1, 0)) if self.projection else self._resample(grasp_pc)   # dataset.py:262-270
         label = self._label(level_score + refine_score * 0.01)
         if label is None:
             return None

@@ -1,0 +1,55 @@
+"""Mirror of the reference's ``PointNetGPD/model/gpd.py`` — ``GPDClassifier``, the GPD baseline CNN the paper
+compares against.  Same constructor, attribute names and construction order (identical state_dict
+keys and seeded initialisation), same forward graph:
+
+    conv1(C,20,5) -> pool1 -> conv2(20,50,5) -> pool2 -> view(-1,7200) -> relu(fc1) -> [dropout] -> fc2 -> log_softmax
+
+Dispatch: CUDA tensor in eval mode -> libpngpd (``pngpd_conv5_pool2`` x2 + ``pngpd_fc_fwd`` x2, no fallback);
+CPU tensors, and training mode (the comparator's training is not part of the hot path — DESIGN.md §6) -> the ATen
+composite the reference itself runs."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import gpd_ops, ops
+
+
+class GPDClassifier(nn.Module):
+    """Input: (batch_size, input_chann, 60, 60)"""
+
+    def __init__(self, input_chann, dropout=False):
+        super().__init__()
+        self.conv1 = nn.Conv2d(input_chann, 20, 5)
+        self.pool1 = nn.MaxPool2d(2, stride=2)
+        self.conv2 = nn.Conv2d(20, 50, 5)
+        self.pool2 = nn.MaxPool2d(2, stride=2)
+        self.fc1 = nn.Linear(12 * 12 * 50, 500)
+        self.dp = nn.Dropout2d(p=0.5, inplace=False)
+        self.relu = nn.ReLU()
+        self.fc2 = nn.Linear(500, 2)
+        self.if_dropout = dropout
+
+    def forward(self, x):
+        if x.is_cuda and not self.training:
+            return self._forward_hip(x)
+        x = self.pool1(self.conv1(x))
+        x = self.pool2(self.conv2(x))
+        x = x.view(-1, 7200)
+        x = self.relu(self.fc1(x))
+        if self.if_dropout:
+            x = self.dp(x)
+        x = self.fc2(x)
+        return F.log_softmax(x, dim=-1)
+
+    def _forward_hip(self, x):
+        if x.dim() != 4 or x.shape[1] != self.conv1.in_channels or x.shape[2] != 60 or x.shape[3] != 60:
+            raise RuntimeError(f"expected input of shape (B,{self.conv1.in_channels},60,60), got {tuple(x.shape)}")
+        x = x.float().contiguous()
+        x = gpd_ops.conv5_pool2(x, self.conv1.weight, self.conv1.bias)          # (B,20,28,28)
+        x = gpd_ops.conv5_pool2(x, self.conv2.weight, self.conv2.bias)          # (B,50,12,12)
+        x = x.view(-1, 7200)
+        x = ops.fc_fwd(x, self.fc1.weight.detach().contiguous(), self.fc1.bias.detach().contiguous(), ops.EPI_RELU)
+        # fc2: K = 500 is not a multiple of the FC kernel's 8-wide k-blocks: zero-pad input and weight columns to 504
+        w2 = F.pad(self.fc2.weight.detach(), (0, 4)).contiguous()
+        x = F.pad(x, (0, 4)).contiguous()
+        return ops.fc_fwd(x, w2, self.fc2.bias.detach().contiguous(), ops.EPI_LOG_SOFTMAX)

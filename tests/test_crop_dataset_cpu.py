@@ -107,15 +107,28 @@ def test_dataset_mirror_matches_reference_record():
             assert str(item[2]) == str(fx[f"obj_{n}"])
 
 
-def test_dataset_projection_is_out_of_scope():
+def test_dataset_projection_items():
+    """``projection=True`` (the GPD baseline's input, dataset.py:73-74,262-270): an item is a (chann,60,60) image stack
+    built from the in-box points; without an estimator (open3d is absent here) the error says what to do."""
     from pointnetgpd_amd.model import dataset as mirror
     with tempfile.TemporaryDirectory() as root:
         synth_dataset.build(root)
         os.environ["PointNetGPD_FOLDER"] = root
         ds = mirror.PointGraspOneViewDataset(grasp_points_num=64, grasp_amount_per_file=12, thresh_good=0.6,
-                                             thresh_bad=0.6, tag="train", projection=True)
-        with pytest.raises(NotImplementedError):
+                                             thresh_bad=0.6, tag="train", projection=True, project_chann=12)
+        with pytest.raises(RuntimeError, match="open3d"):
             ds[0]
+        rng = np.random.default_rng(0)
+
+        def fake_normals(points):
+            n = rng.normal(size=points.shape)
+            return n / np.linalg.norm(n, axis=1, keepdims=True)
+        ds.normal_estimator = fake_normals
+        np.random.seed(3)
+        item = ds[0]
+        assert item[0].shape == (12, 60, 60) and item[0].dtype == np.float64 and item[1] in (0, 1)
+        occ = item[0][0]
+        assert occ.max() == 1.0 and (occ >= 0).all()                       # occupancy normalised by its maximum
 
 
 def test_device_loader_host_half(tmp_path, monkeypatch):

@@ -1,0 +1,104 @@
+"""GPU parity of the GPD-baseline row against the records of the executed reference
+(tests/golden/gpd_*.npz) and the oracle: projection images (bit-exact, floats included), depth registration and
+back-projection (bit-exact), GPDClassifier forward (1e-5), and the drop-in ``cloudgen`` functions."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gpd_oracle as go
+from tests import synth_gpd
+from tests.conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def test_projection_images_bit_exact(cuda_device):
+    from pointnetgpd_amd import gpd_ops
+    fx = np.load(os.path.join(GOLDEN, "gpd_projection.npz"))
+    tags = [str(t) for t in fx["tags"]]
+    pts, nrm, off, widths = [], [], [0], []
+    for tag in tags:                                       # all cases as ONE batch of grasps
+        ind = fx[f"{tag}/in_ind"]
+        pts.append(fx[f"{tag}/pc"][ind]); nrm.append(fx[f"{tag}/normals"][ind])
+        off.append(off[-1] + len(ind)); widths.append(float(fx[f"{tag}/width"]))
+    pts, nrm = np.concatenate(pts), np.concatenate(nrm)
+    for chann in (3, 12):
+        out = gpd_ops.project_grasps(pts, nrm, np.array(off, dtype=np.int32), np.array(widths), chann, cuda_device)
+        assert "libpngpd.so" in open("/proc/self/maps").read()
+        assert out.shape == (len(tags), 60, 60, chann) and out.dtype == torch.float64
+        for g, tag in enumerate(tags):
+            np.testing.assert_array_equal(out[g].cpu().numpy(), fx[f"{tag}/out{chann}"], err_msg=f"{tag} chann {chann}")
+
+
+def test_projection_large_random_vs_oracle(cuda_device):
+    """Many points per grasp (several 1,024-point chunks, voxels far above the 50-point cap) and ragged sizes."""
+    from pointnetgpd_amd import gpd_ops
+    rng = np.random.default_rng(5)
+    sizes = [3000, 1, 0, 1025, 257]
+    pts, nrm, off, widths = [], [], [0], []
+    for m in sizes:
+        w = rng.uniform(0.03, 0.085)
+        p = rng.uniform(-1, 1, size=(m, 3)) * np.array([w / 4, w / 2, w / 4])
+        if m > 100:
+            p[: m // 3] = p[0] + rng.normal(size=(m // 3, 3)) * 1e-4          # one voxel with hundreds of points
+        n = rng.normal(size=(m, 3))
+        if m > 10:
+            n[rng.choice(m, 5, replace=False), 1] = np.nan
+        pts.append(p); nrm.append(n); off.append(off[-1] + m); widths.append(w)
+    out = gpd_ops.project_grasps(np.concatenate(pts), np.concatenate(nrm), np.array(off, dtype=np.int32),
+                                 np.array(widths), 12, cuda_device).cpu().numpy()
+    for g, m in enumerate(sizes):
+        if m == 0:
+            assert not out[g].any()                      # the reference raises on an empty hand; we return zeros
+            continue
+        np.testing.assert_array_equal(out[g], go.project_pc(pts[g], nrm[g], widths[g], 12), err_msg=str(m))
+
+
+@pytest.mark.parametrize("tag", ["small", "vga"])
+def test_depth_registration_and_cloud(tag, cuda_device):
+    from pointnetgpd_amd import gpd_ops, cloudgen
+    fx = np.load(os.path.join(GOLDEN, "gpd_cloudgen.npz"))
+    sc = synth_gpd.cloudgen_scene(tag)
+    reg = gpd_ops.register_depth_map(sc["depth"], sc["rgb"].shape, sc["depthK"], sc["rgbK"], sc["H"], cuda_device)
+    regn = reg.cpu().numpy()
+    assert int((regn > 0).sum()) == int(fx[f"{tag}/reg_nonzero"])
+    np.testing.assert_array_equal(regn.reshape(-1)[fx[f"{tag}/reg_pix"]], fx[f"{tag}/reg_val"])
+    np.testing.assert_array_equal(regn, go.register_depth_map(sc["depth"], sc["rgb"].shape, sc["depthK"], sc["rgbK"], sc["H"]))
+    regm = regn.copy(); regm[sc["mask"]] = 0
+    xyz, col = gpd_ops.depth_map_to_cloud(regm, sc["rgbK"], sc["refFromRGB"], sc["objFromref"], rgb=sc["rgb"],
+                                          device=cuda_device)
+    assert xyz.shape[0] == int(fx[f"{tag}/cloud_len"])
+    rows = fx[f"{tag}/cloud_rows"]
+    np.testing.assert_array_equal(xyz.cpu().numpy()[rows], fx[f"{tag}/cloud_val"][:, :3])
+    np.testing.assert_array_equal(col.cpu().numpy()[rows].astype(np.float64), fx[f"{tag}/cloud_val"][:, 3:])
+    np.testing.assert_array_equal(xyz.cpu().numpy(), go.depth_map_to_cloud(regm, sc["rgbK"], sc["refFromRGB"], sc["objFromref"]))
+    if tag == "small":                                    # the drop-in functions, numpy in / numpy out
+        reg2 = cloudgen.registerDepthMap(sc["depth"], sc["rgb"], sc["depthK"], sc["rgbK"], sc["H"])
+        np.testing.assert_array_equal(reg2, fx["small/registered"])
+        reg2[sc["mask"]] = 0
+        cloud = cloudgen.registeredDepthMapToPointCloud(reg2, sc["rgb"], sc["rgbK"], sc["refFromRGB"], sc["objFromref"])
+        np.testing.assert_array_equal(cloud[0], fx["small/cloud"])
+
+
+@pytest.mark.parametrize("chann", [3, 12])
+def test_gpd_classifier_forward(chann, cuda_device):
+    from pointnetgpd_amd.model.gpd import GPDClassifier
+    fx = np.load(os.path.join(GOLDEN, "gpd_classifier.npz"))
+    torch.manual_seed(100 + chann)
+    m = GPDClassifier(chann).eval()
+    x = torch.from_numpy(fx[f"x{chann}"])
+    with torch.no_grad():
+        logp = m.to(cuda_device)(x.to(cuda_device))
+    assert "libpngpd.so" in open("/proc/self/maps").read()
+    np.testing.assert_allclose(logp.cpu().numpy(), fx[f"logp{chann}"], atol=1e-5, rtol=0)
+    # a larger batch against the oracle's functional restatement
+    g = torch.Generator().manual_seed(9)
+    xb = torch.rand(70, chann, 60, 60, generator=g)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = go.gpd_forward_torch(sd, xb)
+        got = m(xb.to(cuda_device)).cpu()
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=2e-5, rtol=0)
+    assert (got.argmax(1) == ref.argmax(1)).all()
