@@ -37,6 +37,27 @@ static inline int pngpd_splits_for(int B, int T, int target) {
     return S;
 }
 
+// fp64 operations that must round exactly like numpy's separate multiply / add.  HIP's __dmul_rn / __dadd_rn are
+// plain operators defined in a header under the default -ffp-contract=fast-honor-pragmas: once inlined, hipcc fuses
+// them into v_fma_f64 (measured: the crop kernel held 96 v_fmac_f64).  These helpers carry contract(off), so neither
+// half of a*b + c may be fused.
+__device__ __forceinline__ double pn_dmul(double a, double b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ double pn_dadd(double a, double b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ double pn_dsub(double a, double b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+__device__ __forceinline__ double pn_ddiv(double a, double b) {
+#pragma clang fp contract(off)
+    return a / b;
+}
+
 static inline int pngpd_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PNGPD_OK : (PNGPD_ERR_HIP + (int)e);

@@ -13,6 +13,11 @@
 //   y = M (p - origin);  keep  lo < y < hi  component-wise.
 #include "pngpd_common.h"
 
+// The fp64 geometry in this file must round exactly like numpy's (separate multiply and add): hipcc's default
+// -ffp-contract=fast-honor-pragmas would otherwise fuse a*b + c into one FMA (the pn_dmul/pn_dadd helpers are
+// plain operators in HIP's headers and do not prevent it).
+#pragma clang fp contract(off)
+
 struct Frame {
     double o[3], m[9], lo[3], hi[3];
 };
@@ -40,9 +45,9 @@ __device__ __forceinline__ void load_point(const void *__restrict__ cloud, int p
 __device__ __forceinline__ void to_frame(const Frame &F, double x, double y, double z, double &a, double &b, double &c) {
     const double dx = x - F.o[0], dy = y - F.o[1], dz = z - F.o[2];
     // same association as a row-times-column dot product: ((m0*dx + m1*dy) + m2*dz), no FMA
-    a = __dadd_rn(__dadd_rn(__dmul_rn(F.m[0], dx), __dmul_rn(F.m[1], dy)), __dmul_rn(F.m[2], dz));
-    b = __dadd_rn(__dadd_rn(__dmul_rn(F.m[3], dx), __dmul_rn(F.m[4], dy)), __dmul_rn(F.m[5], dz));
-    c = __dadd_rn(__dadd_rn(__dmul_rn(F.m[6], dx), __dmul_rn(F.m[7], dy)), __dmul_rn(F.m[8], dz));
+    a = pn_dadd(pn_dadd(pn_dmul(F.m[0], dx), pn_dmul(F.m[1], dy)), pn_dmul(F.m[2], dz));
+    b = pn_dadd(pn_dadd(pn_dmul(F.m[3], dx), pn_dmul(F.m[4], dy)), pn_dmul(F.m[5], dz));
+    c = pn_dadd(pn_dadd(pn_dmul(F.m[6], dx), pn_dmul(F.m[7], dy)), pn_dmul(F.m[8], dz));
 }
 
 // One workgroup per grasp: count the in-box points and write their indices in ascending order

@@ -7,6 +7,11 @@
 // FMA contraction, so voxel indices, pixel indices and depths are bit-identical to numpy's.
 #include "pngpd_common.h"
 
+// The fp64 geometry in this file must round exactly like numpy's (separate multiply and add): hipcc's default
+// -ffp-contract=fast-honor-pragmas would otherwise fuse a*b + c into one FMA (the pn_dmul/pn_dadd helpers are
+// plain operators in HIP's headers and do not prevent it).
+#pragma clang fp contract(off)
+
 // ---------------------------------------------------------------------------------------
 // Projection images (dataset.py:139-198).  One workgroup per (grasp, projection order).
 //   voxel = floor(coord / res + size/2) per axis of the order, res = gripper_width / (size - margin)
@@ -67,17 +72,17 @@ __global__ __launch_bounds__(256) void gpd_projection_kernel(
     }
     mx0 = gpd_blk_minmax(mx0, true, red); mn0 = gpd_blk_minmax(mn0, false, red);
     mx1 = gpd_blk_minmax(mx1, true, red); mn1 = gpd_blk_minmax(mn1, false, red);
-    const double e0 = __dsub_rn(mx0, mn0), e1 = __dsub_rn(mx1, mn1);
+    const double e0 = pn_dsub(mx0, mn0), e1 = pn_dsub(mx1, mn1);
     const double tmp = e0 > e1 ? e0 : e1;
     const bool empty = !(tmp > 0.0);                             // no kept point, or a single location: zero images
     for (int i = tid; i < GPD_NPIX; i += 256) { zmax[i] = INT_MIN; cnt[i] = 0; sum[3 * i] = 0.f; sum[3 * i + 1] = 0.f; sum[3 * i + 2] = 0.f; }
     __syncthreads();
-    const double res = __ddiv_rn(widths[g], (double)(GPD_S - margin));
+    const double res = pn_ddiv(widths[g], (double)(GPD_S - margin));
     const double half = (double)GPD_S / 2.0;
     auto vox = [&](int i, int &ix, int &iy, int &iz) {
-        ix = (int)floor(__dadd_rn(__ddiv_rn(P[3 * i + o0], res), half));
-        iy = (int)floor(__dadd_rn(__ddiv_rn(P[3 * i + o1], res), half));
-        iz = (int)floor(__dadd_rn(__ddiv_rn(P[3 * i + o2], res), half));
+        ix = (int)floor(pn_dadd(pn_ddiv(P[3 * i + o0], res), half));
+        iy = (int)floor(pn_dadd(pn_ddiv(P[3 * i + o1], res), half));
+        iz = (int)floor(pn_dadd(pn_ddiv(P[3 * i + o2], res), half));
     };
     if (!empty) {
         // ---- pass 1: the winning (largest) z index of every pixel
@@ -124,14 +129,14 @@ __global__ __launch_bounds__(256) void gpd_projection_kernel(
         const int c = cnt[i];
         double *oi = o + (size_t)i * chann + cbase;
         if (chann == 3) {
-            oi[0] = c ? __ddiv_rn((double)sum[3 * i], (double)c) : 0.0;
-            oi[1] = c ? __ddiv_rn((double)sum[3 * i + 1], (double)c) : 0.0;
-            oi[2] = c ? __ddiv_rn((double)sum[3 * i + 2], (double)c) : 0.0;
+            oi[0] = c ? pn_ddiv((double)sum[3 * i], (double)c) : 0.0;
+            oi[1] = c ? pn_ddiv((double)sum[3 * i + 1], (double)c) : 0.0;
+            oi[2] = c ? pn_ddiv((double)sum[3 * i + 2], (double)c) : 0.0;
         } else {
-            oi[0] = cm ? __ddiv_rn((double)c, (double)cm) : 0.0;
-            oi[1] = c ? __ddiv_rn((double)sum[3 * i], (double)c) : 0.0;
-            oi[2] = c ? __ddiv_rn((double)sum[3 * i + 1], (double)c) : 0.0;
-            oi[3] = c ? __ddiv_rn((double)sum[3 * i + 2], (double)c) : 0.0;
+            oi[0] = cm ? pn_ddiv((double)c, (double)cm) : 0.0;
+            oi[1] = c ? pn_ddiv((double)sum[3 * i], (double)c) : 0.0;
+            oi[2] = c ? pn_ddiv((double)sum[3 * i + 1], (double)c) : 0.0;
+            oi[3] = c ? pn_ddiv((double)sum[3 * i + 2], (double)c) : 0.0;
         }
     }
 }
@@ -150,18 +155,18 @@ __global__ __launch_bounds__(256) void depth_register_kernel(const double *__res
     const double d = depth[idx];
     if (d == 0.0) return;
     const int v = idx / wd, u = idx - v * wd;
-    const double inv_fx = __ddiv_rn(1.0, cam[0]), inv_fy = __ddiv_rn(1.0, cam[1]);
-    const double x = __dmul_rn(__dmul_rn(__dsub_rn((double)u, cam[2]), d), inv_fx);
-    const double y = __dmul_rn(__dmul_rn(__dsub_rn((double)v, cam[3]), d), inv_fy);
+    const double inv_fx = pn_ddiv(1.0, cam[0]), inv_fy = pn_ddiv(1.0, cam[1]);
+    const double x = pn_dmul(pn_dmul(pn_dsub((double)u, cam[2]), d), inv_fx);
+    const double y = pn_dmul(pn_dmul(pn_dsub((double)v, cam[3]), d), inv_fy);
     const double *H = cam + 8;
     auto row = [&](int r) {
-        return __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(H[4 * r], x), __dmul_rn(H[4 * r + 1], y)), __dmul_rn(H[4 * r + 2], d)),
+        return pn_dadd(pn_dadd(pn_dadd(pn_dmul(H[4 * r], x), pn_dmul(H[4 * r + 1], y)), pn_dmul(H[4 * r + 2], d)),
                          H[4 * r + 3]);
     };
     const double X = row(0), Y = row(1), Z = row(2);
-    const double inv = __ddiv_rn(1.0, Z);
-    const double uu = __dadd_rn(__dadd_rn(__dmul_rn(__dmul_rn(cam[4], X), inv), cam[6]), 0.5);
-    const double vv = __dadd_rn(__dadd_rn(__dmul_rn(__dmul_rn(cam[5], Y), inv), cam[7]), 0.5);
+    const double inv = pn_ddiv(1.0, Z);
+    const double uu = pn_dadd(pn_dadd(pn_dmul(pn_dmul(cam[4], X), inv), cam[6]), 0.5);
+    const double vv = pn_dadd(pn_dadd(pn_dmul(pn_dmul(cam[5], Y), inv), cam[7]), 0.5);
     if (!(uu > -1.0e9 && uu < 1.0e9 && vv > -1.0e9 && vv < 1.0e9)) return;   // int() of these would be out of any image
     const int ur = (int)uu, vr = (int)vv;                                     // truncation toward zero, like int()
     if (ur < 0 || ur >= wr || vr < 0 || vr >= hr) return;
@@ -217,10 +222,10 @@ __global__ __launch_bounds__(256) void depth_emit_kernel(const double *__restric
     int pos = boff[blockIdx.x] + __popcll(m & ((1ull << lane) - 1ull));
     for (int q = 0; q < wave; ++q) pos += wc[q];
     const int v = idx / w_, u = idx - v * w_;
-    const double x = __dmul_rn(__dmul_rn(__dsub_rn((double)u, cam[2]), d), __ddiv_rn(1.0, cam[0]));
-    const double y = __dmul_rn(__dmul_rn(__dsub_rn((double)v, cam[3]), d), __ddiv_rn(1.0, cam[1]));
+    const double x = pn_dmul(pn_dmul(pn_dsub((double)u, cam[2]), d), pn_ddiv(1.0, cam[0]));
+    const double y = pn_dmul(pn_dmul(pn_dsub((double)v, cam[3]), d), pn_ddiv(1.0, cam[1]));
     auto rigid = [&](const double *A, int r, double a, double b, double c) {
-        return __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(A[4 * r], a), __dmul_rn(A[4 * r + 1], b)), __dmul_rn(A[4 * r + 2], c)),
+        return pn_dadd(pn_dadd(pn_dadd(pn_dmul(A[4 * r], a), pn_dmul(A[4 * r + 1], b)), pn_dmul(A[4 * r + 2], c)),
                          A[4 * r + 3]);
     };
     const double *A = cam + 4, *O = cam + 16;

@@ -10,6 +10,11 @@
 // transformed point.  Geometry is fp64 with strict inequalities and no FMA contraction, like pngpd_crop.hip.
 #include "pngpd_common.h"
 
+// The fp64 geometry in this file must round exactly like numpy's (separate multiply and add): hipcc's default
+// -ffp-contract=fast-honor-pragmas would otherwise fuse a*b + c into one FMA (the pn_dmul/pn_dadd helpers are
+// plain operators in HIP's headers and do not prevent it).
+#pragma clang fp contract(off)
+
 template <bool F64>
 __device__ __forceinline__ void gpg_load_point(const void *__restrict__ cloud, int p, double &x, double &y, double &z) {
     if (F64) {
@@ -23,7 +28,7 @@ __device__ __forceinline__ void gpg_load_point(const void *__restrict__ cloud, i
 
 __device__ __forceinline__ double gpg_dist2(double x, double y, double z, double qx, double qy, double qz) {
     const double dx = x - qx, dy = y - qy, dz = z - qz;
-    return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+    return pn_dadd(pn_dadd(pn_dmul(dx, dx), pn_dmul(dy, dy)), pn_dmul(dz, dz));
 }
 
 // Block-wide sum of an int over 256 threads; every thread gets the total.
@@ -104,10 +109,10 @@ __global__ __launch_bounds__(256) void gpg_normal_moments_kernel(
         ++nsel;
         if (d2 == 0.0) continue;                          // :1477 skips the sample point itself
         double nx = normals[(size_t)p * 3], ny = normals[(size_t)p * 3 + 1], nz = normals[(size_t)p * 3 + 2];
-        const double nn = sqrt(__dadd_rn(__dadd_rn(__dmul_rn(nx, nx), __dmul_rn(ny, ny)), __dmul_rn(nz, nz)));
+        const double nn = sqrt(pn_dadd(pn_dadd(pn_dmul(nx, nx), pn_dmul(ny, ny)), pn_dmul(nz, nz)));
         if (nn != 0.0) { nx /= nn; ny /= nn; nz /= nn; }
-        m[0] += __dmul_rn(nx, nx); m[1] += __dmul_rn(nx, ny); m[2] += __dmul_rn(nx, nz);
-        m[3] += __dmul_rn(ny, ny); m[4] += __dmul_rn(ny, nz); m[5] += __dmul_rn(nz, nz);
+        m[0] += pn_dmul(nx, nx); m[1] += pn_dmul(nx, ny); m[2] += pn_dmul(nx, nz);
+        m[3] += pn_dmul(ny, ny); m[4] += pn_dmul(ny, nz); m[5] += pn_dmul(nz, nz);
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i)
@@ -166,9 +171,9 @@ __global__ __launch_bounds__(256) void hand_box_counts_kernel(
         __syncthreads();
         for (int i = 0; i < n; ++i) {
             const double dx = pts[i * 3] - f[0], dy = pts[i * 3 + 1] - f[1], dz = pts[i * 3 + 2] - f[2];
-            const double gx = __dadd_rn(__dadd_rn(__dmul_rn(f[3], dx), __dmul_rn(f[4], dy)), __dmul_rn(f[5], dz));
-            const double gy = __dadd_rn(__dadd_rn(__dmul_rn(f[6], dx), __dmul_rn(f[7], dy)), __dmul_rn(f[8], dz));
-            const double gz = __dadd_rn(__dadd_rn(__dmul_rn(f[9], dx), __dmul_rn(f[10], dy)), __dmul_rn(f[11], dz));
+            const double gx = pn_dadd(pn_dadd(pn_dmul(f[3], dx), pn_dmul(f[4], dy)), pn_dmul(f[5], dz));
+            const double gy = pn_dadd(pn_dadd(pn_dmul(f[6], dx), pn_dmul(f[7], dy)), pn_dmul(f[8], dz));
+            const double gz = pn_dadd(pn_dadd(pn_dmul(f[9], dx), pn_dmul(f[10], dy)), pn_dmul(f[11], dz));
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 const bool in = (bx[b * 6] < gx) && (bx[b * 6 + 1] > gx) && (bx[b * 6 + 2] < gy) &&
@@ -241,9 +246,9 @@ __global__ __launch_bounds__(256) void hand_box_counts_indexed_kernel(
                 double x, y, z;
                 gpg_load_point<F64>(cloud, p, x, y, z);
                 const double dx = x - f[0], dy = y - f[1], dz = z - f[2];
-                const double gx = __dadd_rn(__dadd_rn(__dmul_rn(f[3], dx), __dmul_rn(f[4], dy)), __dmul_rn(f[5], dz));
-                const double gy = __dadd_rn(__dadd_rn(__dmul_rn(f[6], dx), __dmul_rn(f[7], dy)), __dmul_rn(f[8], dz));
-                const double gz = __dadd_rn(__dadd_rn(__dmul_rn(f[9], dx), __dmul_rn(f[10], dy)), __dmul_rn(f[11], dz));
+                const double gx = pn_dadd(pn_dadd(pn_dmul(f[3], dx), pn_dmul(f[4], dy)), pn_dmul(f[5], dz));
+                const double gy = pn_dadd(pn_dadd(pn_dmul(f[6], dx), pn_dmul(f[7], dy)), pn_dmul(f[8], dz));
+                const double gz = pn_dadd(pn_dadd(pn_dmul(f[9], dx), pn_dmul(f[10], dy)), pn_dmul(f[11], dz));
 #pragma unroll
                 for (int b = 0; b < NB; ++b)
                     in[b] = (bx[b * 6] < gx) && (bx[b * 6 + 1] > gx) && (bx[b * 6 + 2] < gy) &&
