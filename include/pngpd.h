@@ -317,6 +317,34 @@ int pngpd_hand_box_counts_indexed(const void *cloud_sorted, int cloud_is_f64, in
                                   const double *poses, int Q, const double *boxes, int num_boxes, int *counts,
                                   void *stream);
 
+/* the same with the number of valid poses on the DEVICE: only poses [0, *valid_units * per_unit) are evaluated (the
+ * launch is sized for Q = the buffer's capacity; valid_units == NULL: all Q). */
+int pngpd_hand_box_counts_indexed_n(const void *cloud_sorted, int cloud_is_f64, int P, const double *spheres, int C,
+                                    const double *poses, int Q, const double *boxes, int num_boxes,
+                                    const int *valid_units, int per_unit, int *counts, void *stream);
+
+/* ---- selection logic of the sampler on the device (grasp_sampler.py:1524-1650); only the 3x3 eigen-decomposition of
+ * :1493 stays on the host (LAPACK's eigenvector signs decide the enumeration order).  prm: gripper / sweep constants
+ * (layout in pngpd_gpg.hip, built by pointnetgpd_amd/gpg.py).  L live sample points, R rotations, D lateral offsets,
+ * S push-in steps; capacity of the per-pose buffers = L*R potential grasps. ---- */
+/* :1524-1541  frames (L,12) = minor, normal, major, sample point -> poses (L,R,D,12), ab (L,R,6) = approach, binormal */
+int pngpd_gpg_enumerate(const double *frames, int L, int R, int D, const double *prm, double *poses, double *ab,
+                        void *stream);
+/* :1565-1573  counts (L,R,D,4) of the sweep -> flag/dsel (L*R): potential grasp and its offset; list (L*R) = the
+ * potential grasps in (l,r) order, *total their number */
+int pngpd_gpg_select(const int *counts, const double *poses, const double *ab, int L, int R, int D, const double *prm,
+                     int *flag, int *dsel, int *list, int *total, void *stream);
+/* :1575-1612  push-in poses and their backed-off, table-corrected twins: poses2 (L*R,S,2,12), back / mod (L*R,S,3) */
+int pngpd_gpg_pushin(const int *list, const int *total, const int *dsel, const double *poses, const double *ab,
+                     const double *frames, int L, int R, int D, int S, const double *prm, double *poses2, double *back,
+                     double *mod, void *stream);
+/* :1614-1637  counts2 (L*R,S,2,4) -> first accepted step per potential grasp; res (1 + L + L*R*15) doubles =
+ * [n_found, grasps per live sample point (L), rows [bottom, approach, binormal, minor, bottom_modified] in the
+ * reference's output order]; found/sfirst/olist (L*R), ototal (1): scratch */
+int pngpd_gpg_finish(const int *counts2, const int *list, const int *total, const double *ab, const double *frames,
+                     const double *back, const double *mod, int L, int R, int S, int min_open, int *found,
+                     int *sfirst, int *olist, int *ototal, double *res, void *stream);
+
 /* =======================================================================================
  * GPD baseline (the comparator model of the paper) and the depth-registration preprocessing — SURVEY.md §8f-4.
  * ======================================================================================= */

@@ -93,6 +93,14 @@ SIGNATURES = {
                                                 ctypes.c_double, ctypes.c_int, c_void, c_void, c_void]),
     "pngpd_hand_box_counts": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, ctypes.c_int, c_void,
                                              ctypes.c_int, c_void, c_void]),
+    "pngpd_hand_box_counts_indexed_n": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, ctypes.c_int, c_void,
+                                                       ctypes.c_int, c_void, ctypes.c_int, c_void, ctypes.c_int, c_void,
+                                                       c_void]),
+    "pngpd_gpg_enumerate": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void, c_void, c_void, c_void]),
+    "pngpd_gpg_select": (ctypes.c_int, [c_void, c_void, c_void, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void, c_void,
+                                        c_void, c_void, c_void, c_void]),
+    "pngpd_gpg_pushin": (ctypes.c_int, [c_void] * 6 + [ctypes.c_int] * 4 + [c_void] * 4 + [c_void]),
+    "pngpd_gpg_finish": (ctypes.c_int, [c_void] * 7 + [ctypes.c_int] * 4 + [c_void] * 5 + [c_void]),
     # ---- GPD baseline + depth registration
     "pngpd_gpd_projection": (ctypes.c_int, [c_void, c_void, c_void, c_void, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_int, c_void, c_void]),

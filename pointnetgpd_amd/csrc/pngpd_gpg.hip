@@ -10,9 +10,8 @@
 // transformed point.  Geometry is fp64 with strict inequalities and no FMA contraction, like pngpd_crop.hip.
 #include "pngpd_common.h"
 
-// The fp64 geometry in this file must round exactly like numpy's (separate multiply and add): hipcc's default
-// -ffp-contract=fast-honor-pragmas would otherwise fuse a*b + c into one FMA (the pn_dmul/pn_dadd helpers are
-// plain operators in HIP's headers and do not prevent it).
+// The fp64 geometry in this file must round exactly like numpy's (separate multiply and add): no FMA contraction for
+// anything written below, and the pn_d* helpers of pngpd_common.h for the expressions that mirror the reference.
 #pragma clang fp contract(off)
 
 template <bool F64>
@@ -202,10 +201,14 @@ __global__ __launch_bounds__(256) void hand_box_counts_kernel(
 template <bool F64, int NB>
 __global__ __launch_bounds__(256) void hand_box_counts_indexed_kernel(
     const void *__restrict__ cloud, int P, const double *__restrict__ spheres, int C,
-    const double *__restrict__ poses, int Q, const double *__restrict__ boxes, int *__restrict__ counts) {
+    const double *__restrict__ poses, int Q, const double *__restrict__ boxes, int *__restrict__ counts,
+    const int *__restrict__ valid_units, int per_unit) {
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= Q) return;                       // wave-uniform; the kernel has no barriers
+    // device-side pose count (the sampler's second sweep: only the first *valid_units * per_unit poses exist, the
+    // launch is sized for the capacity so that the host never has to read the count back)
+    if (valid_units && q >= *valid_units * per_unit) return;
     double f[12], bx[NB * 6];
 #pragma unroll
     for (int i = 0; i < 12; ++i) f[i] = poses[(size_t)q * 12 + i];
@@ -264,6 +267,237 @@ __global__ __launch_bounds__(256) void hand_box_counts_indexed_kernel(
     }
 }
 
+
+// =======================================================================================================
+// Selection logic of the sampler on the device (grasp_sampler.py:1524-1650): pose enumeration, the middle admissible
+// offset per rotation, the 30-degree rule, push-in poses with the table back-off, the first accepted push-in step and
+// the packing of the result.  Only the 3x3 eigen-decomposition stays on the host (LAPACK's arbitrary eigenvector signs
+// decide the enumeration order and cannot be restated).  Every expression keeps numpy's operation order.
+//   prm (doubles): [0] init_bite [1] hand_depth [2] hand_depth*0.5 [3] APPROACH_STEP [4] TABLE_CLEARANCE
+//                  [5] hh*0.5 [6] -(hh*0.5) [7] -(ow*0.5) [8] ow*0.5 [9] -fw [10] fw [11] -hh [12] APPROACH_STEP*3 factor
+//                  [16..16+R) dtheta (rad)   [48..48+D) lateral offsets dy   [80..80+S) push-in step numbers
+// =======================================================================================================
+#define GPG_PRM_DTH 16
+#define GPG_PRM_DYS 48
+#define GPG_PRM_STEPS 80
+
+__device__ __forceinline__ double gpg_norm3(double x, double y, double z) {
+    return sqrt(pn_dadd(pn_dadd(pn_dmul(x, x), pn_dmul(y, y)), pn_dmul(z, z)));
+}
+
+// frames (L,12) = minor, normal (flipped), major, sample point.  One thread per (l, r): the rotation about `minor`
+// by dtheta[r] (rotation_from_quaternion on the un-normalised [dtheta, minor] quaternion, :1503 quirk), the rotated
+// approach / binormal, and the D poses of the lateral sweep (:1524-1541).
+__global__ __launch_bounds__(256) void gpg_enumerate_kernel(const double *__restrict__ frames, int L, int R, int D,
+                                                            const double *__restrict__ prm,
+                                                            double *__restrict__ poses, double *__restrict__ ab) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= L * R) return;
+    const int l = t / R, r = t - l * R;
+    const double *F = frames + (size_t)l * 12;
+    const double mi[3] = {F[0], F[1], F[2]}, no[3] = {F[3], F[4], F[5]}, ma[3] = {F[6], F[7], F[8]};
+    double q[4] = {mi[0], mi[1], mi[2], prm[GPG_PRM_DTH + r]};
+    const double nq = pn_dadd(pn_dadd(pn_dadd(pn_dmul(q[0], q[0]), pn_dmul(q[1], q[1])), pn_dmul(q[2], q[2])), pn_dmul(q[3], q[3]));
+    double rot[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    if (!(nq < 2.220446049250313e-16 * 4.0)) {
+        const double sc = sqrt(pn_ddiv(2.0, nq));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = pn_dmul(q[i], sc);
+        double o[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[i][j] = pn_dmul(q[i], q[j]);
+        rot[0][0] = pn_dsub(pn_dsub(1.0, o[1][1]), o[2][2]); rot[0][1] = pn_dsub(o[0][1], o[2][3]); rot[0][2] = pn_dadd(o[0][2], o[1][3]);
+        rot[1][0] = pn_dadd(o[0][1], o[2][3]); rot[1][1] = pn_dsub(pn_dsub(1.0, o[0][0]), o[2][2]); rot[1][2] = pn_dsub(o[1][2], o[0][3]);
+        rot[2][0] = pn_dsub(o[0][2], o[1][3]); rot[2][1] = pn_dadd(o[1][2], o[0][3]); rot[2][2] = pn_dsub(pn_dsub(1.0, o[0][0]), o[1][1]);
+    }
+    double bi[3], ap[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        bi[i] = pn_dadd(pn_dadd(pn_dmul(rot[i][0], ma[0]), pn_dmul(rot[i][1], ma[1])), pn_dmul(rot[i][2], ma[2]));
+        ap[i] = pn_dadd(pn_dadd(pn_dmul(rot[i][0], no[0]), pn_dmul(rot[i][1], no[1])), pn_dmul(rot[i][2], no[2]));
+    }
+    double *o6 = ab + (size_t)t * 6;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { o6[i] = ap[i]; o6[3 + i] = bi[i]; }
+    const double na = gpg_norm3(ap[0], ap[1], ap[2]), nb = gpg_norm3(bi[0], bi[1], bi[2]), nm = gpg_norm3(mi[0], mi[1], mi[2]);
+    const double ib = prm[0];
+    for (int d = 0; d < D; ++d) {
+        const double dy = prm[GPG_PRM_DYS + d];
+        double *po = poses + ((size_t)t * D + d) * 12;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double b0 = pn_dadd(F[9 + i], pn_dmul(bi[i], dy));               // sample point + binormal * dy
+            po[i] = pn_dadd(pn_dmul(ib, -ap[i]), b0);                              // init_bite * (-approach) + ...
+            po[3 + i] = pn_ddiv(ap[i], na); po[6 + i] = pn_ddiv(bi[i], nb); po[9 + i] = pn_ddiv(mi[i], nm);
+        }
+    }
+}
+
+// One thread per (l, r): the middle admissible lateral offset (:1565-1567) and the 30-degree rule (:1570-1573).
+// flag[t] = 1 and dsel[t] = the offset index when the rotation yields a potential grasp.
+__global__ __launch_bounds__(256) void gpg_select_kernel(const int *__restrict__ cnt, const double *__restrict__ poses,
+                                                         const double *__restrict__ ab, int LR, int D,
+                                                         const double *__restrict__ prm, int *__restrict__ flag,
+                                                         int *__restrict__ dsel) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= LR) return;
+    const int *c = cnt + (size_t)t * D * 4;
+    int n_ok = 0;
+    for (int d = 0; d < D; ++d) n_ok += (c[d * 4 + 0] > 0 && c[d * 4 + 3] == 0 && c[d * 4 + 1] == 0 && c[d * 4 + 2] == 0) ? 1 : 0;
+    int f = 0, ds = 0;
+    if (n_ok > 0) {
+        const int target = (n_ok + 1) / 2 - 1;                                     // ceil(n_ok / 2) - 1
+        int rank = -1;
+        for (int d = 0; d < D; ++d) {
+            if (c[d * 4 + 0] > 0 && c[d * 4 + 3] == 0 && c[d * 4 + 1] == 0 && c[d * 4 + 2] == 0) {
+                if (++rank == target) { ds = d; break; }
+            }
+        }
+        const double p0z = poses[((size_t)t * D + ds) * 12 + 2], paz = ab[(size_t)t * 6 + 2];
+        f = pn_dadd(p0z, pn_dmul(paz, prm[1])) < pn_dsub(p0z, prm[2]) ? 1 : 0;     // (p0 + pa*hd).z < p0.z - hd*0.5
+    }
+    flag[t] = f; dsel[t] = ds;
+}
+
+// Exclusive scan of n 0/1 flags (single workgroup): list[pos] = index of the pos-th set flag, *total = their number.
+__global__ __launch_bounds__(1024) void gpg_flag_scan_kernel(const int *__restrict__ flag, int n, int *__restrict__ list,
+                                                             int *__restrict__ total) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int b = tid * per, e = (b + per < n) ? b + per : n;
+    int s = 0;
+    for (int i = b; i < e; ++i) s += flag[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - s;
+    for (int i = b; i < e; ++i) if (flag[i]) list[run++] = i;
+    if (tid == 1023) *total = part[1023];
+}
+
+// hand corners p1..p20 (:287-321) of pose (centre c, approach a, binormal b) with the construction order of the
+// reference (see gpg.py::_hand_table); returns the lowest corner (first minimum of z) in low[] and its z.
+__device__ __forceinline__ void gpg_lowest_corner(const double *prm, const double c[3], const double a[3],
+                                                  const double b[3], double low[3]) {
+    double m[3] = {pn_dsub(pn_dmul(a[1], b[2]), pn_dmul(a[2], b[1])), pn_dsub(pn_dmul(a[2], b[0]), pn_dmul(a[0], b[2])),
+                   pn_dsub(pn_dmul(a[0], b[1]), pn_dmul(a[1], b[0]))};
+    const double nm = gpg_norm3(m[0], m[1], m[2]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) m[i] = pn_ddiv(m[i], nm);
+    double P[21][3];   // P[0] unused; "u" -> 21st/22nd handled through locals
+    double u[3], dn[3];
+    auto mk = [&](double (&dst)[3], const double (&par)[3], const double *ax, double sc) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dst[i] = pn_dadd(pn_dmul(ax[i], sc), par[i]);
+    };
+    const double cc[3] = {c[0], c[1], c[2]};
+    mk(u, cc, m, prm[5]); mk(dn, cc, m, prm[6]);
+    mk(P[5], u, b, prm[7]); mk(P[6], u, b, prm[8]); mk(P[7], dn, b, prm[8]); mk(P[8], dn, b, prm[7]);
+    mk(P[1], P[5], a, prm[1]); mk(P[2], P[6], a, prm[1]); mk(P[3], P[7], a, prm[1]); mk(P[4], P[8], a, prm[1]);
+    mk(P[9], P[1], b, prm[9]); mk(P[10], P[4], b, prm[9]); mk(P[11], P[5], b, prm[9]); mk(P[12], P[8], b, prm[9]);
+    mk(P[13], P[2], b, prm[10]); mk(P[14], P[3], b, prm[10]); mk(P[15], P[6], b, prm[10]); mk(P[16], P[7], b, prm[10]);
+    mk(P[17], P[11], a, prm[11]); mk(P[18], P[15], a, prm[11]); mk(P[19], P[16], a, prm[11]); mk(P[20], P[12], a, prm[11]);
+    int best = 1;
+#pragma unroll
+    for (int i = 2; i <= 20; ++i) if (P[i][2] < P[best][2]) best = i;
+    low[0] = P[best][0]; low[1] = P[best][1]; low[2] = P[best][2];
+}
+
+// One thread per (potential pose i, push-in step s) (:1575-1612): the pose at step s and its backed-off,
+// table-corrected twin.  poses2 (Np,S,2,12) — pose (i,s) and its twin are neighbours, so the first 2*Np*S poses of the
+// capacity-sized buffer are the valid ones; back / mod (Np,S,3).
+__global__ __launch_bounds__(256) void gpg_pushin_kernel(const int *__restrict__ list, const int *__restrict__ total,
+                                                         const int *__restrict__ dsel, const double *__restrict__ poses,
+                                                         const double *__restrict__ ab, const double *__restrict__ frames,
+                                                         int R, int D, int S, const double *__restrict__ prm,
+                                                         double *__restrict__ poses2, double *__restrict__ back_o,
+                                                         double *__restrict__ mod_o) {
+    const int Np = *total;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= Np * S) return;
+    const int i = t / S, s = t - i * S;
+    const int lr = list[i], l = lr / R;
+    const double *p0 = poses + ((size_t)lr * D + dsel[lr]) * 12;
+    const double *pa = ab + (size_t)lr * 6, *pb = pa + 3, *pm = frames + (size_t)l * 12;
+    const double step = prm[GPG_PRM_STEPS + s], h = prm[3];
+    double cs[3], bk[3], md[3], low[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        cs[k] = pn_dadd(pn_dmul(pn_dmul(pa[k], step), h), p0[k]);                  // pa * s * step_len + p0
+        bk[k] = pn_dadd(cs[k], pn_dmul(pn_dmul(-pa[k], h), 3.0));                  // + (-pa) * step_len * 3
+    }
+    gpg_lowest_corner(prm, bk, pa, pb, low);
+    const double tx = pn_dadd(pn_ddiv(pn_dmul(-low[2], pa[0]), pa[2]), low[0]);
+    const double ty = pn_dadd(pn_ddiv(pn_dmul(-low[2], pa[1]), pa[2]), low[1]);
+    const double dist = pn_dadd(sqrt(pn_dadd(pn_dadd(pn_dadd(pn_dadd(pn_dmul(low[0], low[0]), pn_dmul(low[1], low[1])),
+                                                             pn_dmul(low[2], low[2])), pn_dmul(tx, tx)), pn_dmul(ty, ty))),
+                                prm[4]);
+    const bool corr = low[2] < prm[4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) md[k] = corr ? pn_dsub(bk[k], pn_dmul(pa[k], dist)) : bk[k];
+    const double na = gpg_norm3(pa[0], pa[1], pa[2]), nb = gpg_norm3(pb[0], pb[1], pb[2]), nm = gpg_norm3(pm[0], pm[1], pm[2]);
+    double *q0 = poses2 + ((size_t)i * S + s) * 24, *q1 = q0 + 12;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const bool fin = md[k] == md[k] && fabs(md[k]) != INFINITY;
+        q0[k] = cs[k]; q1[k] = fin ? md[k] : 1e30;                                 // non-finite -> a pose no point can hit
+        q0[3 + k] = q1[3 + k] = pn_ddiv(pa[k], na);
+        q0[6 + k] = q1[6 + k] = pn_ddiv(pb[k], nb);
+        q0[9 + k] = q1[9 + k] = pn_ddiv(pm[k], nm);
+        back_o[((size_t)i * S + s) * 3 + k] = bk[k];
+        mod_o[((size_t)i * S + s) * 3 + k] = md[k];
+    }
+}
+
+// One thread per potential pose: the first accepted push-in step (:1614-1625; the reference's `break` sits inside the
+// accept branch).  found[i] / sfirst[i].
+__global__ __launch_bounds__(256) void gpg_first_accept_kernel(const int *__restrict__ cnt2, const int *__restrict__ total,
+                                                               int S, int cap, int min_open, int *__restrict__ found,
+                                                               int *__restrict__ sfirst) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= cap) return;
+    int f = 0, sf = 0;
+    if (i < *total) {
+        for (int s = 0; s < S; ++s) {
+            const int *a = cnt2 + ((size_t)i * S + s) * 8, *b = a + 4;
+            const bool hit0 = a[3] > 0 || a[1] > 0 || a[2] > 0, hit1 = b[3] > 0 || b[1] > 0 || b[2] > 0;
+            if (hit0 && b[0] > min_open && !hit1) { f = 1; sf = s; break; }
+        }
+    }
+    found[i] = f; sfirst[i] = sf;
+}
+
+// Pack: res = [n_found, per-live-sample-point counts (L), grasps (n_found,5,3)] as doubles, in potential-pose order
+// (= the reference's output order: by sample point, then by rotation).
+__global__ __launch_bounds__(256) void gpg_pack_kernel(const int *__restrict__ olist, const int *__restrict__ ototal,
+                                                       const int *__restrict__ list, const int *__restrict__ sfirst,
+                                                       const double *__restrict__ ab, const double *__restrict__ frames,
+                                                       const double *__restrict__ back, const double *__restrict__ mod,
+                                                       int R, int S, int L, double *__restrict__ res) {
+    const int n = *ototal;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j == 0) res[0] = (double)n;
+    if (j >= n) return;
+    const int i = olist[j], lr = list[i], l = lr / R, s = sfirst[i];
+    double *o = res + 1 + L + (size_t)j * 15;
+    const double *pa = ab + (size_t)lr * 6, *pm = frames + (size_t)l * 12;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        o[k] = back[((size_t)i * S + s) * 3 + k];
+        o[3 + k] = pa[k]; o[6 + k] = pa[3 + k]; o[9 + k] = pm[k];
+        o[12 + k] = mod[((size_t)i * S + s) * 3 + k];
+    }
+    atomicAdd(&res[1 + l], 1.0);      // small-integer counts: exact and order-independent in fp64
+}
+
 extern "C" {
 
 int pngpd_gpg_normal_moments(const void *cloud, int cloud_is_f64, const double *normals, int P,
@@ -303,19 +537,82 @@ int pngpd_hand_box_counts(const void *cloud, int cloud_is_f64, int P, const doub
     return pngpd_launch_status();
 }
 
-int pngpd_hand_box_counts_indexed(const void *cloud_sorted, int cloud_is_f64, int P, const double *spheres, int C,
-                                  const double *poses, int Q, const double *boxes, int num_boxes, int *counts,
-                                  void *stream) {
-    if (!cloud_sorted || !spheres || !poses || !boxes || !counts || P <= 0 || Q <= 0 || C != (P + 63) / 64)
+int pngpd_hand_box_counts_indexed_n(const void *cloud_sorted, int cloud_is_f64, int P, const double *spheres, int C,
+                                    const double *poses, int Q, const double *boxes, int num_boxes,
+                                    const int *valid_units, int per_unit, int *counts, void *stream) {
+    if (!cloud_sorted || !spheres || !poses || !boxes || !counts || P <= 0 || Q <= 0 || C != (P + 63) / 64 ||
+        (valid_units && per_unit <= 0))
         return PNGPD_ERR_INVALID_ARG;
     if (num_boxes != 1 && num_boxes != 4) return PNGPD_ERR_UNSUPPORTED;
     dim3 grid((Q + 3) / 4);
 #define LAUNCH(F64, NB)                                                                                   \
     hipLaunchKernelGGL((hand_box_counts_indexed_kernel<F64, NB>), grid, dim3(256), 0, (hipStream_t)stream, \
-                       cloud_sorted, P, spheres, C, poses, Q, boxes, counts)
+                       cloud_sorted, P, spheres, C, poses, Q, boxes, counts, valid_units, per_unit)
     if (cloud_is_f64) { if (num_boxes == 4) LAUNCH(true, 4); else LAUNCH(true, 1); }
     else              { if (num_boxes == 4) LAUNCH(false, 4); else LAUNCH(false, 1); }
 #undef LAUNCH
+    return pngpd_launch_status();
+}
+
+int pngpd_hand_box_counts_indexed(const void *cloud_sorted, int cloud_is_f64, int P, const double *spheres, int C,
+                                  const double *poses, int Q, const double *boxes, int num_boxes, int *counts,
+                                  void *stream) {
+    return pngpd_hand_box_counts_indexed_n(cloud_sorted, cloud_is_f64, P, spheres, C, poses, Q, boxes, num_boxes,
+                                           nullptr, 0, counts, stream);
+}
+
+/* ---- selection logic on the device (see the kernels above) ---- */
+int pngpd_gpg_enumerate(const double *frames, int L, int R, int D, const double *prm, double *poses, double *ab,
+                        void *stream) {
+    if (!frames || !prm || !poses || !ab || L <= 0 || R <= 0 || R > 32 || D <= 0 || D > 32) return PNGPD_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(gpg_enumerate_kernel, dim3((L * R + 255) / 256), dim3(256), 0, (hipStream_t)stream, frames, L, R, D,
+                       prm, poses, ab);
+    return pngpd_launch_status();
+}
+
+int pngpd_gpg_select(const int *counts, const double *poses, const double *ab, int L, int R, int D, const double *prm,
+                     int *flag, int *dsel, int *list, int *total, void *stream) {
+    if (!counts || !poses || !ab || !prm || !flag || !dsel || !list || !total || L <= 0 || R <= 0 || D <= 0)
+        return PNGPD_ERR_INVALID_ARG;
+    const int LR = L * R;
+    hipLaunchKernelGGL(gpg_select_kernel, dim3((LR + 255) / 256), dim3(256), 0, (hipStream_t)stream, counts, poses, ab, LR,
+                       D, prm, flag, dsel);
+    int st = pngpd_launch_status();
+    if (st != PNGPD_OK) return st;
+    hipLaunchKernelGGL(gpg_flag_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, flag, LR, list, total);
+    return pngpd_launch_status();
+}
+
+int pngpd_gpg_pushin(const int *list, const int *total, const int *dsel, const double *poses, const double *ab,
+                     const double *frames, int L, int R, int D, int S, const double *prm, double *poses2, double *back,
+                     double *mod, void *stream) {
+    if (!list || !total || !dsel || !poses || !ab || !frames || !prm || !poses2 || !back || !mod || L <= 0 || R <= 0 ||
+        D <= 0 || S <= 0 || S > 64)
+        return PNGPD_ERR_INVALID_ARG;
+    const int cap = L * R;      // capacity: every rotation of every sample point may yield a potential grasp
+    hipLaunchKernelGGL(gpg_pushin_kernel, dim3(((size_t)cap * S + 255) / 256), dim3(256), 0, (hipStream_t)stream, list,
+                       total, dsel, poses, ab, frames, R, D, S, prm, poses2, back, mod);
+    return pngpd_launch_status();
+}
+
+int pngpd_gpg_finish(const int *counts2, const int *list, const int *total, const double *ab, const double *frames,
+                     const double *back, const double *mod, int L, int R, int S, int min_open, int *found,
+                     int *sfirst, int *olist, int *ototal, double *res, void *stream) {
+    if (!counts2 || !list || !total || !ab || !frames || !back || !mod || !found || !sfirst || !olist || !ototal ||
+        !res || L <= 0 || R <= 0 || S <= 0)
+        return PNGPD_ERR_INVALID_ARG;
+    const int cap = L * R;
+    hipError_t e = hipMemsetAsync(res, 0, (size_t)(1 + L) * sizeof(double), (hipStream_t)stream);
+    if (e != hipSuccess) return PNGPD_ERR_HIP + (int)e;
+    hipLaunchKernelGGL(gpg_first_accept_kernel, dim3((cap + 255) / 256), dim3(256), 0, (hipStream_t)stream, counts2,
+                       total, S, cap, min_open, found, sfirst);
+    int st = pngpd_launch_status();
+    if (st != PNGPD_OK) return st;
+    hipLaunchKernelGGL(gpg_flag_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, found, cap, olist, ototal);
+    st = pngpd_launch_status();
+    if (st != PNGPD_OK) return st;
+    hipLaunchKernelGGL(gpg_pack_kernel, dim3((cap + 255) / 256), dim3(256), 0, (hipStream_t)stream, olist, ototal, list,
+                       sfirst, ab, frames, back, mod, R, S, L, res);
     return pngpd_launch_status();
 }
 

@@ -6,14 +6,18 @@ sampler ``kinect2grasp.py:150`` calls.  The reference walks the sample points on
 25 push-in steps x 7 passes per surviving pose.  Here all sample points of a call are processed together:
 
 1. ``pngpd_gpg_normal_moments``   one workgroup per sample point: r-ball / 100-NN selection and M = sum n n^T
-2. host (numpy, a few 3x3 ops per sample point): ``np.linalg.eig`` — the same LAPACK call as the reference, so the
-   arbitrary eigenvector SIGNS that decide the enumeration order agree — local frame, pose enumeration
-3. ``pngpd_hand_box_counts``      one thread per pose, four hand boxes per transformed point, whole sweep in ONE launch
-4. host: middle-offset rule per rotation, table check, push-in poses + table back-off
-5. ``pngpd_hand_box_counts``      collision at every push-in step and the final check at every backed-off pose
-6. host: first accepted step per pose, reference output order, ``num_grasps`` / ``max_num_samples`` stop rule
+2. host: ONE batched ``np.linalg.eig`` over the K 3x3 matrices — the same LAPACK call as the reference, because the
+   arbitrary eigenvector SIGNS it returns decide the enumeration order of the sweep — and the local frames
+3. ``pngpd_gpg_enumerate``        rotation about the minor axis x lateral offsets -> the 19 x 21 poses per sample point
+4. ``pngpd_hand_box_counts*``     one wave per pose, four hand boxes per transformed point, the whole sweep in ONE launch
+5. ``pngpd_gpg_select``           middle admissible offset per rotation, 30-degree rule, ordered list of potential grasps
+6. ``pngpd_gpg_pushin``           every push-in step and its backed-off, table-corrected twin (hand corners on the fly)
+7. ``pngpd_hand_box_counts*``     collision at every step / twin; the number of valid poses stays on the device
+8. ``pngpd_gpg_finish``           first accepted step per potential grasp, rows packed in the reference's output order
+9. host: ``num_grasps`` / ``max_num_samples`` stop rule over the per-sample-point counts
 
-Three launches and three small device->host copies per scene instead of ~10^5 numpy calls.
+Per round of sample points: one upload (sample points), one download of the K moment matrices, one upload of the K
+frames, one download of the packed result — the pose enumeration, selection and push-in logic never touch the host.
 
 Reference quirks reproduced on purpose (see oracle/gpg_oracle.py for the executed-reference pin):
 * the "rotation by dtheta" is ``rotation_from_quaternion([dtheta_rad, minor])`` on an un-normalised quaternion;
@@ -32,6 +36,7 @@ import torch
 
 from . import _lib
 from .crop import ROBOTIQ_85 as _CROP_GRIPPER
+from .ops import _call
 
 # dex-net/data/grippers/robotiq_85/params.json
 ROBOTIQ_85 = dict(_CROP_GRIPPER, init_bite=0.01)
@@ -84,25 +89,6 @@ def hand_boxes(g):
     p = {i + 1: c[i] for i in range(20)}
     sel = [(p[1], p[2], p[4], p[8]), (p[9], p[1], p[10], p[12]), (p[2], p[13], p[3], p[7]), (p[11], p[15], p[12], p[20])]
     return np.array([[s8[0], s4[0], s1[1], s2[1], s4[2], s1[2]] for s1, s2, s4, s8 in sel])
-
-
-def _rotations(minor):
-    """(K,3) minor axes -> (K,R,3,3): rotation_from_quaternion([dtheta_rad, minor]) for the dtheta sweep (:1524-1529)."""
-    dth = np.arange(-RANGE_DTHETA, RANGE_DTHETA + 1, DTHETA).astype(np.float64) / 180 * np.pi
-    K, R = minor.shape[0], dth.shape[0]
-    q = np.empty((K, R, 4))                      # xyzw
-    q[:, :, :3] = minor[:, None, :]
-    q[:, :, 3] = dth[None, :]
-    nq = (q * q).sum(-1, keepdims=True)
-    q = q * np.sqrt(2.0 / nq)
-    o = q[..., :, None] * q[..., None, :]
-    rot = np.empty((K, R, 3, 3))
-    rot[..., 0, 0] = 1.0 - o[..., 1, 1] - o[..., 2, 2]; rot[..., 0, 1] = o[..., 0, 1] - o[..., 2, 3]; rot[..., 0, 2] = o[..., 0, 2] + o[..., 1, 3]
-    rot[..., 1, 0] = o[..., 0, 1] + o[..., 2, 3]; rot[..., 1, 1] = 1.0 - o[..., 0, 0] - o[..., 2, 2]; rot[..., 1, 2] = o[..., 1, 2] - o[..., 0, 3]
-    rot[..., 2, 0] = o[..., 0, 2] - o[..., 1, 3]; rot[..., 2, 1] = o[..., 1, 2] + o[..., 0, 3]; rot[..., 2, 2] = 1.0 - o[..., 0, 0] - o[..., 1, 1]
-    tiny = nq[..., 0] < np.finfo(float).eps * 4.0
-    rot[tiny] = np.identity(3)
-    return rot
 
 
 def _unit(v):
@@ -181,10 +167,13 @@ class CloudIndex:
         self.P, self.C = P, C
 
 
-def hand_box_counts(cloud, poses, boxes, index=None):
+def hand_box_counts(cloud, poses, boxes, index=None, valid_units=None, per_unit=1):
     """cloud (P,3) CUDA; poses (Q,12) CUDA f64 [centre, approach, binormal, minor] (unit axes); boxes (NB,6) CUDA f64,
     NB in {1,4} -> counts (Q,NB) int32: cloud points strictly inside each box of each pose.
-    ``index`` (a ``CloudIndex`` of the same cloud) selects the sphere-culling kernel: same counts, less work."""
+    ``index`` (a ``CloudIndex`` of the same cloud) selects the sphere-culling kernel: same counts, less work.
+    ``valid_units`` (CUDA int32 scalar) with ``per_unit``: only the first valid_units * per_unit poses are evaluated —
+    the count lives on the device, the launch covers the buffer's capacity (indexed kernel only; the brute-force
+    kernel evaluates the whole buffer, rows past the count are ignored by the caller)."""
     lib = _lib.load()
     if index is not None:
         if not poses.is_cuda or poses.dtype != torch.float64 or poses.dim() != 2 or poses.shape[1] != 12:
@@ -198,9 +187,11 @@ def hand_box_counts(cloud, poses, boxes, index=None):
             return counts
         c = index.cloud
         with _lib.device_guard(c.device):
-            _lib.check(lib.pngpd_hand_box_counts_indexed(_p(c), int(c.dtype == torch.float64), index.P,
-                                                         _p(index.spheres), index.C, _p(poses), Q, _p(boxes), NB,
-                                                         _p(counts), _stream(c)), "hand_box_counts_indexed")
+            _lib.check(lib.pngpd_hand_box_counts_indexed_n(_p(c), int(c.dtype == torch.float64), index.P,
+                                                           _p(index.spheres), index.C, _p(poses), Q, _p(boxes), NB,
+                                                           _p(valid_units) if valid_units is not None else None,
+                                                           int(per_unit), _p(counts), _stream(c)),
+                       "hand_box_counts_indexed")
         return counts
     cloud = _check_cloud(cloud)
     if not poses.is_cuda or poses.dtype != torch.float64 or poses.dim() != 2 or poses.shape[1] != 12:
@@ -239,6 +230,25 @@ class GpgGraspSamplerPcl:
         self.last_stats = {}
 
     # -- device work for one batch of draws --------------------------------------------------
+    @staticmethod
+    def _params(g):
+        """Gripper / sweep constants of the device kernels, computed with numpy exactly as the reference computes them
+        (layout: pngpd_gpg.hip)."""
+        hh, fw, hd = g["hand_height"], g["finger_width"], g["hand_depth"]
+        ow = g["hand_outer_diameter"] - fw * 2
+        dth = np.arange(-RANGE_DTHETA, RANGE_DTHETA + 1, DTHETA).astype(np.float64) / 180 * np.pi    # :1524-1529
+        dys = np.arange(-NUM_DY * fw, (NUM_DY + 1) * fw, fw)                                         # :1531
+        S = int(hd / APPROACH_STEP)                                                                  # :1576
+        if len(dth) > 32 or len(dys) > 32 or S > 64:
+            raise RuntimeError("sweep larger than the kernels' parameter block")
+        prm = np.zeros(160)
+        prm[0:13] = [g["init_bite"], hd, hd * 0.5, APPROACH_STEP, TABLE_CLEARANCE, hh * 0.5, -(hh * 0.5), -(ow * 0.5),
+                     ow * 0.5, -fw, fw, -hh, 3.0]
+        prm[16:16 + len(dth)] = dth
+        prm[48:48 + len(dys)] = dys
+        prm[80:80 + S] = np.arange(S, dtype=np.float64)
+        return prm, len(dth), len(dys), S
+
     def _run_batch(self, g, cloud_d, normals_d, boxes_d, sel_pts, normals_at_ind, index=None):
         """sel_pts (K,3) sample points, normals_at_ind (K,3) -> (m_zero (K,) bool, per-draw list of (n,5,3) arrays)."""
         dev = cloud_d.device
@@ -246,14 +256,14 @@ class GpgGraspSamplerPcl:
         fw, hd = g["finger_width"], g["hand_depth"]
         r_ball = max(g["hand_outer_diameter"] - fw, hd, g["hand_height"] / 2.0)                  # :1464
         M, _ = normal_moments(cloud_d, normals_d, torch.from_numpy(sel_pts).to(dev), r_ball, MAX_NN)
-        M = M.cpu().numpy()
+        M = M.cpu().numpy()                                                                     # download 1: K x 9 doubles
         m_zero = M.sum((1, 2)) == 0                                                             # :1486
         empty = np.zeros((0, 5, 3))
         res = [empty] * K
         live = np.nonzero(~m_zero)[0]
         if live.size == 0:
             return m_zero, res
-        # local frames (:1493-1512) — np.linalg.eig exactly as the reference calls it
+        # local frames (:1493-1512) — np.linalg.eig exactly as the reference calls it, once for the whole batch
         eigval, eigvec = np.linalg.eig(M[live])
         eigval, eigvec = np.real(eigval), np.real(eigvec)
         ar = np.arange(live.size)
@@ -265,68 +275,38 @@ class GpgGraspSamplerPcl:
         flip = (normals_at_ind[live] * normal).sum(1) < 0
         normal = np.where(flip[:, None], -normal, normal)
         minor = np.where(flip[:, None], -minor, minor)
-        # pose sweep (:1524-1541): (L, R, D) poses
-        rot = _rotations(minor)                                                                 # (L,R,3,3)
-        dys = np.arange(-NUM_DY * fw, (NUM_DY + 1) * fw, fw)                                    # :1531
-        binormal = np.einsum("lrij,lj->lri", rot, major)
-        approach = np.einsum("lrij,lj->lri", rot, normal)
-        L, R, D = live.size, rot.shape[1], dys.shape[0]
-        bottom = sel_pts[live][:, None, None, :] + binormal[:, :, None, :] * dys[None, None, :, None]
-        bottom = g["init_bite"] * (-approach[:, :, None, :]) + bottom                           # (L,R,D,3)
-        poses = np.empty((L, R, D, 12))
-        poses[..., 0:3] = bottom
-        poses[..., 3:6] = _unit(approach)[:, :, None, :]
-        poses[..., 6:9] = _unit(binormal)[:, :, None, :]
-        poses[..., 9:12] = _unit(minor)[:, None, None, :]
-        cnt = hand_box_counts(cloud_d, torch.from_numpy(poses.reshape(-1, 12)).to(dev), boxes_d, index=index)
-        cnt = cnt.cpu().numpy().reshape(L, R, D, 4)
-        ok = (cnt[..., BOX_OPEN] > 0) & (cnt[..., BOX_BOTTOM] == 0) & (cnt[..., BOX_LEFT] == 0) & (cnt[..., BOX_RIGHT] == 0)
-        # the middle admissible offset per rotation (:1565-1567) ...
-        n_ok = ok.sum(-1)
-        target = np.ceil(n_ok / 2).astype(np.int64) - 1
-        rank = np.cumsum(ok, -1) - 1
-        pick = ok & (rank == target[..., None])
-        li, ri, di = np.nonzero(pick)                                                           # ordered by (l, r)
-        p0 = bottom[li, ri, di]
-        pa, pb, pm = approach[li, ri], binormal[li, ri], minor[li]
-        # ... kept if the fingers point down by more than 30 degrees (:1570-1573)
-        keep = (p0 + pa * hd)[:, 2] < p0[:, 2] - hd * 0.5
-        li, p0, pa, pb, pm = li[keep], p0[keep], pa[keep], pb[keep], pm[keep]
-        self.last_stats["potential"] = self.last_stats.get("potential", 0) + int(keep.sum())
-        if li.size == 0:
-            return m_zero, res
-        # push-in (:1575-1612): every step and its backed-off, table-corrected twin
-        S = int(hd / APPROACH_STEP)
-        steps = np.arange(S, dtype=np.float64)
-        c_s = pa[:, None, :] * steps[None, :, None] * APPROACH_STEP + p0[:, None, :]            # (Np,S,3)
-        back = c_s + (-pa[:, None, :]) * APPROACH_STEP * 3
-        A = np.broadcast_to(pa[:, None, :], back.shape)
-        Bn = np.broadcast_to(pb[:, None, :], back.shape)
-        corners = hand_corners(g, back, A, Bn)                                                  # (Np,S,20,3)
-        zmin = corners[..., 2].min(-1)
-        low = np.take_along_axis(corners, np.argmin(corners[..., 2], -1)[..., None, None], axis=-2)[..., 0, :]
-        with np.errstate(divide="ignore", invalid="ignore"):
-            tx = -low[..., 2] * A[..., 0] / A[..., 2] + low[..., 0]
-            ty = -low[..., 2] * A[..., 1] / A[..., 2] + low[..., 1]
-            dist = np.sqrt((low * low).sum(-1) + tx * tx + ty * ty) + TABLE_CLEARANCE             # :1605
-            mod = np.where((zmin < TABLE_CLEARANCE)[..., None], back - A * dist[..., None], back)
-        Np = li.size
-        ax = np.concatenate([_unit(pa), _unit(pb), _unit(pm)], 1)                               # (Np,9)
-        poses2 = np.empty((2, Np, S, 12))
-        poses2[0, :, :, 0:3] = c_s
-        poses2[1, :, :, 0:3] = np.where(np.isfinite(mod), mod, 1e30)                            # non-finite -> empty boxes
-        poses2[:, :, :, 3:12] = ax[None, :, None, :]
-        cnt2 = hand_box_counts(cloud_d, torch.from_numpy(poses2.reshape(-1, 12)).to(dev), boxes_d, index=index)
-        cnt2 = cnt2.cpu().numpy().reshape(2, Np, S, 4)
-        hit = (cnt2[..., BOX_BOTTOM] > 0) | (cnt2[..., BOX_LEFT] > 0) | (cnt2[..., BOX_RIGHT] > 0)   # check_collide
-        accept = hit[0] & (cnt2[1, ..., BOX_OPEN] > MIN_OPEN_POINTS) & ~hit[1]                  # :1614
-        found = accept.any(1)
-        s_first = np.argmax(accept, 1)                                                          # first accepted step (:1625 break)
-        sel = np.nonzero(found)[0]
-        grasps = np.stack([back[sel, s_first[sel]], pa[sel], pb[sel], pm[sel], mod[sel, s_first[sel]]], 1)   # (n,5,3)
-        owner = live[li[sel]]
-        for k in np.unique(owner):
-            res[k] = grasps[owner == k]
+        prm, R, D, S = self._params(g)
+        L = live.size
+        up = np.concatenate([np.concatenate([minor, normal, major, sel_pts[live]], 1).reshape(-1), prm])
+        up_d = torch.from_numpy(up).to(dev)                                                     # upload: frames + constants
+        frames_d, prm_d = up_d[:L * 12], up_d[L * 12:]
+        cap = L * R
+        f64 = dict(device=dev, dtype=torch.float64)
+        i32 = dict(device=dev, dtype=torch.int32)
+        poses = torch.empty(cap * D, 12, **f64)
+        ab = torch.empty(cap, 6, **f64)
+        _call("pngpd_gpg_enumerate", up_d, frames_d, L, R, D, prm_d, poses, ab)
+        cnt = hand_box_counts(cloud_d, poses, boxes_d, index=index)                             # (L*R*D,4)
+        flag, dsel, plist, total = (torch.empty(cap, **i32), torch.empty(cap, **i32), torch.empty(cap, **i32),
+                                    torch.empty(1, **i32))
+        _call("pngpd_gpg_select", up_d, cnt, poses, ab, L, R, D, prm_d, flag, dsel, plist, total)
+        poses2 = torch.empty(cap * S * 2, 12, **f64)
+        back, mod = torch.empty(cap * S, 3, **f64), torch.empty(cap * S, 3, **f64)
+        _call("pngpd_gpg_pushin", up_d, plist, total, dsel, poses, ab, frames_d, L, R, D, S, prm_d, poses2, back, mod)
+        cnt2 = hand_box_counts(cloud_d, poses2, boxes_d, index=index, valid_units=total, per_unit=2 * S)
+        found, sfirst, olist, ototal = (torch.empty(cap, **i32), torch.empty(cap, **i32), torch.empty(cap, **i32),
+                                        torch.empty(1, **i32))
+        out = torch.empty(1 + L + cap * 15, **f64)
+        _call("pngpd_gpg_finish", up_d, cnt2, plist, total, ab, frames_d, back, mod, L, R, S, MIN_OPEN_POINTS, found,
+              sfirst, olist, ototal, out)
+        host = out.cpu().numpy()                                                                # download 2: packed result
+        self.last_stats["potential"] = self.last_stats.get("potential", 0) + int(total.item())
+        n = int(host[0])
+        per = host[1:1 + L].astype(np.int64)
+        grasps = host[1 + L:1 + L + n * 15].reshape(n, 5, 3)
+        ends = np.cumsum(per)
+        for j in np.nonzero(per)[0]:
+            res[live[j]] = grasps[ends[j] - per[j]:ends[j]]
         return m_zero, res
 
     def sample_grasps(self, point_cloud, points_for_sample, all_normal, num_grasps=20, max_num_samples=200,

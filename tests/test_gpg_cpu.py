@@ -46,16 +46,18 @@ def test_host_half_matches_oracle():
         b = np.cross(a, rng.normal(size=3)); b /= np.linalg.norm(b)
         c = rng.normal(size=3) * 0.1
         np.testing.assert_allclose(gpg.hand_corners(g, c, a, b), go.hand_points(go.ROBOTIQ_85, c, a, b)[1:], atol=1e-16)
-    minor = rng.normal(size=(5, 3)); minor /= np.linalg.norm(minor, axis=1, keepdims=True)
-    rot = gpg._rotations(minor)
-    assert rot.shape == (5, 19, 3, 3)
-    for k in range(5):
-        for r, dth in enumerate(np.arange(-90, 91, 10)):
-            ref = go.rotation_from_quaternion(np.array([np.float64(dth) / 180 * np.pi, *minor[k]]))
-            np.testing.assert_allclose(rot[k, r], ref, atol=1e-15)
-    # the quirk: dtheta = 0 is a half turn about the minor axis, not the identity
-    np.testing.assert_allclose(rot[0, 9] @ minor[0], minor[0], atol=1e-15)
-    assert abs(np.trace(rot[0, 9]) + 1.0) < 1e-14
+    # the constants block of the device kernels is what numpy computes for the reference's expressions
+    prm, R, D, S = gpg.GpgGraspSamplerPcl._params(g)
+    assert (R, D, S) == (19, 21, 25)
+    np.testing.assert_array_equal(prm[16:16 + R], np.arange(-90, 91, 10).astype(np.float64) / 180 * np.pi)
+    fw = g["finger_width"]
+    np.testing.assert_array_equal(prm[48:48 + D], np.arange(-10 * fw, 11 * fw, fw))
+    assert prm[1] == 0.125 and prm[2] == 0.0625 and prm[7] == -((g["hand_outer_diameter"] - fw * 2) * 0.5)
+    # the quirk the device enumeration reproduces: dtheta = 0 is a half turn about the minor axis, not the identity
+    minor = rng.normal(size=3); minor /= np.linalg.norm(minor)
+    ref = go.rotation_from_quaternion(np.array([0.0, *minor]))
+    np.testing.assert_allclose(ref @ minor, minor, atol=1e-15)
+    assert abs(np.trace(ref) + 1.0) < 1e-14
 
 
 def test_sampler_needs_the_gpu():
@@ -95,48 +97,6 @@ def test_infer_crop_oracle_matches_executed_reference():
             assert np.array_equal(ih, ind[g])
             n += 1
     assert n == 102
-
-
-def test_sampler_host_half_against_goldens(monkeypatch):
-    """The host half of the product sampler (frames from np.linalg.eig, pose enumeration, middle-offset rule, table
-    rule, push-in / back-off, first-accepted-step, output order) against the executed-reference goldens, on the CPU:
-    ``_run_batch`` is driven directly with the two DEVICE entry points replaced by numpy stand-ins built from the
-    oracle's primitives (the product itself has no such path: ``sample_grasps`` refuses non-CUDA clouds)."""
-    import torch
-    from pointnetgpd_amd import gpg
-    hp = go.hand_points(go.ROBOTIQ_85, np.zeros(3), np.array([1.0, 0, 0]), np.array([0, 1.0, 0]))
-
-    def fake_moments(cloud, normals, queries, radius, max_nn=100):
-        pts, nrm, q = cloud.numpy().astype(np.float64), normals.numpy(), queries.numpy()
-        M = np.stack([go.normal_moment(pts, nrm, q[k], radius) for k in range(len(q))])
-        return torch.from_numpy(M), torch.zeros(len(q), dtype=torch.int32)
-
-    def fake_counts(cloud, poses, boxes, index=None):
-        pts, P = cloud.numpy().astype(np.float64), poses.numpy()
-        out = np.zeros((len(P), 4), dtype=np.int32)
-        for qi, p in enumerate(P):
-            pg = (pts - p[0:3]) @ np.stack([p[3:6], p[6:9], p[9:12]]).T
-            for b, w in enumerate(go.WAYS):
-                bx = go.way_box(hp, w)
-                out[qi, b] = np.count_nonzero((bx[0] < pg[:, 0]) & (bx[1] > pg[:, 0]) & (bx[2] < pg[:, 1]) &
-                                              (bx[3] > pg[:, 1]) & (bx[4] < pg[:, 2]) & (bx[5] > pg[:, 2]))
-        return torch.from_numpy(out)
-
-    monkeypatch.setattr(gpg, "normal_moments", fake_moments)
-    monkeypatch.setattr(gpg, "hand_box_counts", fake_counts)
-    for tag in ("cyl", "ell"):
-        fx, pts, pfs, nrm = load_case(tag)
-        draws = fx["draws"][:8]                                   # 8 sample points x 399 poses x P on numpy: seconds
-        ref = np.array(go.sample_grasps(pts, pfs, nrm, draws, 10 ** 9, len(draws))).reshape(-1, 5, 3)
-        s = gpg.GpgGraspSamplerPcl()
-        g = gpg._gripper_dict(gpg.ROBOTIQ_85)
-        m_zero, res = s._run_batch(g, torch.from_numpy(pts), torch.from_numpy(nrm), torch.from_numpy(gpg.hand_boxes(g)),
-                                   pfs[draws], nrm[draws])
-        got = np.concatenate(res, 0)
-        assert not m_zero.any() and got.shape == ref.shape and (tag != "ell" or len(ref) > 0)
-        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-11)
-        # and the oracle on those draws is a prefix of the executed-reference record
-        np.testing.assert_allclose(ref, fx["grasps"][:len(ref)], rtol=0, atol=1e-13)
 
 
 def test_sampler_alias_for_kinect2grasp_import():
