@@ -103,6 +103,45 @@ def test_two_ranks_hip_path_vs_oracle(tmp_path, cuda_device):
     assert _rel(res[0]["local"]["fc1.weight"], res[1]["local"]["fc1.weight"]) > 1e-3
 
 
+def _score_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import numpy as np
+    import torch.distributed as dist
+    from pointnetgpd_amd import scoring
+    from tests.helpers import build_model
+    from tests.test_gpu_crop_scoring import _scene
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo")
+    m = build_model(64, 3, 33, 4700).eval().to(dev)
+    pc, grasps = _scene(37, 30000, 21)                       # 37 candidates over 2 ranks: slices 19 + 18
+    scorer = scoring.GraspScorer(m, num_points=64, repeat=1, batch=16, seed=5)
+    res = scoring.score_scene_distributed(scorer.score, pc.astype(np.float32), grasps)
+    torch.save({k: v.cpu() for k, v in res.items()}, os.path.join(out_dir, f"s{rank}.pt"))
+    if rank == 0:                                            # single-process answer for the same candidates
+        one = scorer.score(pc.astype(np.float32), grasps)
+        torch.save({k: one[k].cpu() for k in ("pred", "counts", "valid")}, os.path.join(out_dir, "one.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_scene_scoring_two_ranks_hip(tmp_path, cuda_device):
+    """BASELINE config 5's sharding with the REAL scorer (crop + resample + PointNet kernels) on two ranks: every
+    rank ends with the same all-gathered result, and counts / validity / predictions equal the single-process run
+    (scores differ only through the per-slice resampling seeds, so they are not compared)."""
+    world, port = 2, _free_port()
+    mp.start_processes(_score_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    r0, r1, one = torch.load(tmp_path / "s0.pt"), torch.load(tmp_path / "s1.pt"), torch.load(tmp_path / "one.pt")
+    for k in ("pred", "score", "counts", "valid", "order"):
+        assert torch.equal(r0[k], r1[k]), k
+    assert r0["counts"].shape[0] == 37
+    assert torch.equal(r0["counts"], one["counts"]) and torch.equal(r0["valid"], one["valid"])
+    sc = r0["score"][r0["order"]]
+    assert (sc[:-1] >= sc[1:]).all()
+
+
 def test_bench_self_spawns_two_ranks(cuda_device):
     """``python bench.py --gpus 2`` from a plain shell (no torchrun): bench.py launches its own ranks.  On this 1-GPU
     box the debug switch maps both ranks to cuda:0 over gloo; the JSON line must still report 2 ranks and carry the
