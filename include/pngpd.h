@@ -83,7 +83,7 @@ int pngpd_fold_conv_bn(const float *W, const float *b, const float *gamma, const
  *           library holds no process-global tuning state.
  *   workspace: pngpd_trunk_workspace_bytes(B, N, splits) bytes of device scratch (0 when one workgroup per cloud).
  */
-int pngpd_trunk_infer_splits(int B, int N, int target_blocks);   /* target_blocks <= 0: the default (2048) */
+int pngpd_trunk_infer_splits(int B, int N, int target_blocks);   /* target_blocks <= 0: the default (1024) */
 size_t pngpd_trunk_workspace_bytes(int B, int N, int splits);
 int pngpd_trunk_fwd_infer(const float *x, int B, int N, const float *trans,
                           const float *w1, const float *b1, const float *w2p, const float *b2,

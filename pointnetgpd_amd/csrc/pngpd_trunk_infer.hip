@@ -149,7 +149,10 @@ __global__ void pool_reduce_kernel(const float *__restrict__ part, int S, float 
     out[idx] = nan ? __builtin_nanf("") : m;   // NaN-propagating like torch.max
 }
 
-#define TRUNK_DEFAULT_TARGET_BLOCKS 2048   // 8 per CU; measured flat between 1024 and 4096 at B = N = 1024
+// 4 per CU = two resident rounds of 2.  Measured flat between 1024 and 4096 at B = N = 1024 (round 1); 1024 gives one
+// workgroup per cloud there, so the pooled row is written once (4.2 MB instead of 8.4 MB of partial maxima plus a
+// second launch to combine them).
+#define TRUNK_DEFAULT_TARGET_BLOCKS 1024
 
 static int resolve_splits(int B, int T, int splits) {
     return (splits > 0) ? (splits > T ? T : splits) : pngpd_splits_for(B, T, TRUNK_DEFAULT_TARGET_BLOCKS);

@@ -64,7 +64,7 @@ def test_library_loads_and_reports_abi():
     assert lib.pngpd_fc_fwd(None, 1, 8, None, None, 1, 0, None, None) == 1
     # splits are pure functions of their arguments (no process-global tuning state) and size the workspace
     assert lib.pngpd_trunk_infer_splits(4, 100, 0) == 2                    # ceil(100/64) tiles bound the default
-    assert lib.pngpd_trunk_infer_splits(1024, 1024, 0) == 2 and lib.pngpd_trunk_infer_splits(1024, 1024, 1024) == 1
+    assert lib.pngpd_trunk_infer_splits(1024, 1024, 0) == 1 and lib.pngpd_trunk_infer_splits(1024, 1024, 2048) == 2
     assert lib.pngpd_trunk_workspace_bytes(4, 100, 2) == 4 * 2 * 1024 * 4
     assert lib.pngpd_trunk_workspace_bytes(4, 100, 0) == 4 * 2 * 1024 * 4   # 0 -> the default rule
     assert lib.pngpd_trunk_workspace_bytes(4, 100, 1) == 0                  # one workgroup per cloud: no scratch
