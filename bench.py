@@ -36,16 +36,17 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0
 HBM_PEAK_GBS = 8000.0
 REF_ROOT = "/root/reference"
 
-# MFMA FLOPs one training step actually executes per point and trunk: every pass recomputes layers
-# 1-2 (L12); pass C adds layer 3; pass D the 128x128 mat-vec, the one-hot sparse term (dense-ified: ~1 hit per point
-# -> 2*32*128 per hit) and 10 of the 16 Gram blocks; pass E W2^T dz2 and dW2; the gather pass one more L12.
+# MFMA FLOPs one fp32 training step actually executes per point and trunk.  Layers 1-2 are computed in
+# pass B (which stores z2 for passes C / D / E) and once more in the gather pass; pass C adds layer 3; pass D the
+# 128x128 mat-vec, the one-hot sparse term (dense-ified: ~1 hit per point -> 2*32*128 per hit) and 10 of the 16 Gram
+# blocks; pass E W2^T dz2 and dW2.
 _L12 = 2 * (3 * 64 + 64 * 128)
 EXEC_FLOP_PER_POINT_TRUNK = {
-    "B bn2 stats": _L12,
-    "C forward": _L12 + 2 * 128 * 1024,
+    "B bn2 stats (+ z2 store)": _L12,
+    "C forward": 2 * 128 * 1024,
     "gather": _L12,
-    "D": _L12 + 2 * 128 * 128 + 2 * 32 * 128 + (10 * 2 * 128 * 128) // 16,
-    "E": _L12 + 2 * 128 * 64 + 2 * 128 * 64,
+    "D": 2 * 128 * 128 + 2 * 32 * 128 + (10 * 2 * 128 * 128) // 16,
+    "E": 2 * 128 * 64 + 2 * 128 * 64,
 }
 
 

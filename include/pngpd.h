@@ -145,19 +145,23 @@ int pngpd_trunk_splits(int B, int N, int target_blocks);
 /* pass A: per-cloud fp64 moments  mom (B,9) = {sx,sy,sz,sxx,sxy,sxz,syy,syz,szz}  (BN1 stats in closed form) */
 int pngpd_cloud_moments(const float *x, int B, int N, double *mom, void *stream);
 
-/* pass B: BN2 statistics.  part (blk,128,2) = per-workgroup sum / sum-of-squares of z2 = W2 h1 */
+/* pass B: BN2 statistics.  part (blk,128,2) = per-workgroup sum / sum-of-squares of z2 = W2 h1.
+ *   z2t (optional, pngpd_trunk_g2t_bytes(B,N) bytes): z2 itself, stored in the lane-major tile layout of the trunk
+ *   passes; passes C, D and E given this buffer read it back instead of recomputing layers 1-2 (512 B per point of
+ *   HBM traffic each, overlapped, against 6 % / 20 % / 33 % of their matrix work).  NULL: not stored.          */
 int pngpd_trunk_bn2_stats(const float *x, int B, int N, const float *trans,
                           const float *w1, const float *b1, const float *s1c, const float *t1c,
-                          const float *w2p, int S, float *part, void *stream);
+                          const float *w2p, int S, float *part, float *z2t, void *stream);
 
 /* pass C: layer 3 with sign-folded weights w3sp = MFMA_B(sign(gamma3) * W3):
  *   pmax/parg (blk,1024): max / argmax over the workgroup's points of z3s = w3s . h2
  *   psum (blk,2,1024):    sum / sum of squares of z3s over valid points
- *   psh  (blk,128):       sum of h2 over valid points (its mean enters pass D's cvec and the closed-form dW3) */
+ *   psh  (blk,128):       sum of h2 over valid points (its mean enters pass D's cvec and the closed-form dW3)
+ *   z2t  (optional): pass B's stored z2 — read back instead of recomputing layers 1-2 (NULL: recompute from x)   */
 int pngpd_trunk_fwd_train(const float *x, int B, int N, const float *trans,
                           const float *w1, const float *b1, const float *s1c, const float *t1c,
                           const float *w2p, const float *s2c, const float *t2c, const float *w3sp, int S,
-                          float *pmax, int *parg, float *psum, float *psh, void *stream);
+                          float *pmax, int *parg, float *psum, float *psh, const float *z2t, void *stream);
 
 /* sparse (arg-extremum) term of dW3:  Gp (ceil(B/clouds_per_range),1024,128),
  *   Gp[r][c][:] = sum_{b in range r} coef[b][c] * h2[b][:, idx[b][c]]                         */
@@ -172,13 +176,14 @@ int pngpd_trunk_bwd_gather(const float *x, int B, int N, const float *trans,
  *   pa (blk,128,2) = sum g2, sum g2*zhat2;  ps2 (blk,12,16,64) = raw accumulators of 10 of the 16 32x32 blocks of
  *   sum_points h2 h2^T (slot 3w+q of wave w: blocks (w,w), (w,(w+1)%4), (w,w+2 | w<2); the rest by symmetry).
  *   zhat2 = z2*is2 + nm2;  Ap = MFMA_B(A), A (128,128) symmetric;
- *   dh2 = cvec - h2 A + sum_{c: idx[b][c]==n} coef[b][c] W3[c]; w3 (1024,128) raw row-major.  */
+ *   dh2 = cvec - h2 A + sum_{c: idx[b][c]==n} coef[b][c] W3[c]; w3 (1024,128) raw row-major.
+ *   z2t: pass B's stored z2 (or NULL: layers 1-2 are recomputed from x).                      */
 size_t pngpd_trunk_g2t_bytes(int B, int N);
 int pngpd_trunk_bwd_d(const float *x, int B, int N, const float *trans,
                       const float *w1, const float *b1, const float *s1c, const float *t1c,
                       const float *w2p, const float *s2c, const float *t2c,
                       const float *is2, const float *nm2, const float *Ap, const float *cvec,
-                      const float *w3, const int *idx, const float *coef, int S,
+                      const float *w3, const int *idx, const float *coef, const float *z2t, int S,
                       float *g2t, float *pa, float *ps2, void *stream);
 
 /* backward pass E: dz2 = dsc2*(g2 - a1m - zhat2*a2m); dh1 = W2^T dz2 (w2tp = MFMA_B(W2^T as (64,128)));
@@ -188,7 +193,7 @@ int pngpd_trunk_bwd_e(const float *x, int B, int N, const float *trans,
                       const float *w1, const float *b1, const float *s1c, const float *t1c,
                       const float *w2p, const float *is1, const float *nm1, const float *is2, const float *nm2,
                       const float *a1m, const float *a2m, const float *dsc2, const float *w2tp,
-                      const float *g2t, int S, float *pc, float *pR, float *pW2, void *stream);
+                      const float *z2t, const float *g2t, int S, float *pc, float *pR, float *pW2, void *stream);
 
 /* Backward of a Linear layer y = x W^T + b (pointnet.py:35-37,191-193; loss.backward() of main_1v.py:75) in one
  * launch, operands read in place: g (B,Nout) upstream gradient, x (B,K) the layer input, W (Nout,K) ->

@@ -40,14 +40,14 @@ SIGNATURES = {
     "pngpd_trunk_g2t_bytes": (ctypes.c_size_t, [ctypes.c_int] * 2),
     "pngpd_cloud_moments": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, c_f32p, c_void]),
     "pngpd_trunk_bn2_stats": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 6 + [ctypes.c_int,
-                                                                                                  c_f32p, c_void]),
+                                                                                                  c_f32p, c_f32p, c_void]),
     "pngpd_trunk_fwd_train": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 9 + [ctypes.c_int] +
-                              [c_f32p] * 4 + [c_void]),
+                              [c_f32p] * 5 + [c_void]),
     "pngpd_trunk_bwd_gather": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 10 +
                                [ctypes.c_int, c_f32p, c_void]),
-    "pngpd_trunk_bwd_d": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 15 + [ctypes.c_int] +
+    "pngpd_trunk_bwd_d": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 16 + [ctypes.c_int] +
                           [c_f32p] * 3 + [c_void]),
-    "pngpd_trunk_bwd_e": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 15 + [ctypes.c_int] +
+    "pngpd_trunk_bwd_e": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 16 + [ctypes.c_int] +
                           [c_f32p] * 3 + [c_void]),
     "pngpd_fc_bwd": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p,
                                     c_f32p, c_void]),

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void cloud_moments_kernel(const float *__restr
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void trunk_bn2_stats_kernel(
     const float *__restrict__ x, int N, const float *__restrict__ trans, TrainChan P,
-    int T, int S, float *__restrict__ part) {
+    int T, int S, float *__restrict__ part, f32x4 *__restrict__ z2t) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *h1 = smem;             // [TP][H1S]
     float *xs = h1 + TP * H1S;    // [3][TP]
@@ -82,6 +82,14 @@ __global__ __launch_bounds__(256, 2) void trunk_bn2_stats_kernel(
         f32x16 a0, a1;
         layer2_compute(h1, w2f, L, a0, a1);
         const int nbase = tile * TP;
+        if (z2t) {   // z2 is computed ONCE per step, here; passes C, D and E read it back (lane-major tiles, 512 B/point)
+            f32x4 *zt = z2t + ((size_t)(b * T + tile) * 8) * 256 + L.tid;
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                zt[(size_t)rq * 256] = f32x4{a0[4 * rq], a0[4 * rq + 1], a0[4 * rq + 2], a0[4 * rq + 3]};
+                zt[(size_t)(4 + rq) * 256] = f32x4{a1[4 * rq], a1[4 * rq + 1], a1[4 * rq + 2], a1[4 * rq + 3]};
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = mfma_row(r, L.lane);
@@ -109,10 +117,14 @@ __global__ __launch_bounds__(256, 2) void trunk_bn2_stats_kernel(
 
 // Same skeleton as trunk_infer_kernel (pngpd_trunk_infer.hip): unpadded XOR-swizzled LDS tiles, A fragments and
 // layer-3 weight fragments double-buffered in registers, the tile's points fetched one tile ahead.
+// LOADZ: z2 = W2 h1 was stored by pass B (z2t) and is read back — no points, no layer 1, no layer-2 MFMAs, no h1
+// tile, two barriers per tile instead of three; the next tile's z2 is in flight during layer 3.
+template <bool LOADZ>
 __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
     const float *__restrict__ x, int N, const float *__restrict__ trans, TrainChan P,
     const float *__restrict__ w3sp, int T, int S,
-    float *__restrict__ pmax, int *__restrict__ parg, float *__restrict__ psum, float *__restrict__ psh) {
+    float *__restrict__ pmax, int *__restrict__ parg, float *__restrict__ psum, float *__restrict__ psh,
+    const f32x4 *__restrict__ z2t) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *h1 = smem;                 // [TP][I1S] swizzled
     float *h2 = h1 + TP * I1S;        // [TP][I2S] swizzled
@@ -135,15 +147,23 @@ __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
         for (int i = 0; i < 9; ++i) tm[i] = trans[(size_t)b * 9 + i];
     }
     float px0 = 0.f, px1 = 0.f, px2 = 0.f;
-    if (L.tid < TP) {
+    if (!LOADZ && L.tid < TP) {
         int n = t0 * TP + L.tid; n = n < N ? n : N - 1;
         px0 = xb[n]; px1 = xb[N + n]; px2 = xb[2 * N + n];
     }
     const int cb2 = L.wave, c2 = cb2 * 32 + L.j;
     const float sc2 = P.s2c[c2], sh2 = P.t2c[c2];
     float hsum = 0.f;   // sum over this workgroup's valid points of h2[.][c2] (rows of this half-wave)
+    f32x4 zq[8];
+    if (LOADZ) {
+        const f32x4 *zt = z2t + ((size_t)(b * T + t0) * 8) * 256 + L.tid;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) zq[i] = zt[(size_t)i * 256];
+    }
     for (int tile = t0; tile < t1; ++tile) {
-        if (L.tid < TP) {
+        if (LOADZ) {
+            if (tile > t0) __syncthreads();   // every wave is done reading the previous tile's h2
+        } else if (L.tid < TP) {
             float x0 = px0, x1 = px1, x2 = px2;
             if (has_t) {
                 x0 = fmaf(px2, tm[6], fmaf(px1, tm[3], px0 * tm[0]));
@@ -156,8 +176,8 @@ __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
                 px0 = xb[n]; px1 = xb[N + n]; px2 = xb[2 * N + n];
             }
         }
-        __syncthreads();
-        {   // layer 1 (3 -> 64) + batch-stat BN affine + ReLU, VALU: thread = (point = lane, 16-channel group = wave)
+        if (!LOADZ) __syncthreads();
+        if (!LOADZ) {   // layer 1 (3 -> 64) + batch-stat BN affine + ReLU, VALU: thread = (point = lane, 16-channel group = wave)
             const int p = L.lane;
             const float x0 = xs[p], x1 = xs[TP + p], x2 = xs[2 * TP + p];
 #pragma unroll
@@ -172,14 +192,24 @@ __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
                 *(f32x4 *)(h1 + swz(p, L.wave * 16 + g * 4, I1S)) = v;
             }
         }
-        __syncthreads();
+        if (!LOADZ) __syncthreads();
         const int nbase = tile * TP;
         const bool full = nbase + TP <= N;
-        {   // layer 2 (64 -> 128), MFMA
+        {   // layer 2 (64 -> 128): read back (LOADZ) or on the MFMA
             f32x16 a0, a1;
-            f32x4 w2f[8];
-            load_w2frag(w2f, P.w2p, cb2, L);
-            swz_compute<I1S, 8>(h1, w2f, L, a0, a1);
+            if (LOADZ) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { a0[r] = zq[r >> 2][r & 3]; a1[r] = zq[4 + (r >> 2)][r & 3]; }
+                if (tile + 1 < t1) {
+                    const f32x4 *zt = z2t + ((size_t)(b * T + tile + 1) * 8) * 256 + L.tid;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) zq[i] = zt[(size_t)i * 256];
+                }
+            } else {
+                f32x4 w2f[8];
+                load_w2frag(w2f, P.w2p, cb2, L);
+                swz_compute<I1S, 8>(h1, w2f, L, a0, a1);
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mfma_row(r, L.lane);
@@ -357,9 +387,15 @@ struct BwdDParams {
 #define BWD_D_HITS 1032   // per list: up to 1024 hits + read-ahead padding of the 8-hit sparse step
 #define BWD_D_LDS_FLOATS (TP * H2S + TP * H1S + 3 * TP + 1024 + 1024 + BWD_D_HITS + 16)
 
+// LOADZ: the raw layer-2 output z2 was stored by pass C (z2t, lane-major tiles) and is read back here instead of
+// recomputing layers 1-2: 64 of the 324 MFMAs per wave and tile, the layer-1 VALU work, the h1 tile and one of the
+// three barriers disappear, for 512 B per point of (overlapped) HBM reads.  !LOADZ (the bf16 modes, whose pass C
+// computes z2 on other operands): recompute in fp32 as before.
+template <bool LOADZ>
 __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
     const float *__restrict__ x, int N, const float *__restrict__ trans, TrainChan P, BwdDParams D,
-    int T, int S, f32x4 *__restrict__ g2t, float *__restrict__ pa, float *__restrict__ ps2) {
+    int T, int S, const f32x4 *__restrict__ z2t, f32x4 *__restrict__ g2t, float *__restrict__ pa,
+    float *__restrict__ ps2) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *h2 = smem;                     // [TP][H2S], rows past N zeroed
     float *h1 = h2 + TP * H2S;            // [TP][H1S]
@@ -393,7 +429,14 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
     __syncthreads();   // cfl / idxl visible
     for (int tile = t0; tile < t1; ++tile) {
         const int nbase = tile * TP;
-        stage_points(xb, N, tile, has_t, tm, xs, nullptr, L.tid);
+        f32x4 zq[8];
+        if (LOADZ) {
+            const f32x4 *zt = z2t + ((size_t)(b * T + tile) * 8) * 256 + L.tid;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) zq[i] = zt[(size_t)i * 256];
+        } else {
+            stage_points(xb, N, tile, has_t, tm, xs, nullptr, L.tid);
+        }
         // hit census of this wave's channel quarter [256 wave, 256 wave + 256): ballots stay in scalar registers
         {
             int clo = 0, chi = 0;
@@ -407,8 +450,10 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
         }
         __syncthreads();
         f32x4 w2f[8];   // requested a phase ahead of layer 2 (not kept across the long MFMA phase: register budget)
-        load_w2frag(w2f, P.w2p, cb, L);
-        layer1_tile(xs, P.w1, P.b1, P.s1c, P.t1c, h1, L);
+        if (!LOADZ) {
+            load_w2frag(w2f, P.w2p, cb, L);
+            layer1_tile(xs, P.w1, P.b1, P.s1c, P.t1c, h1, L);
+        }
         int nlo = 0, nhi = 0;
         {   // ordered compaction at the prefix offsets of the four quarters
             int olo = 0, ohi = 0;
@@ -431,9 +476,14 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
         }
         nlo = __builtin_amdgcn_readfirstlane(nlo);
         nhi = __builtin_amdgcn_readfirstlane(nhi);
-        __syncthreads();
         f32x16 z0, z1;   // raw z2 of (this lane's rows, channel c2): ReLU mask and zhat2 are derived in the epilogue
-        layer2_compute(h1, w2f, L, z0, z1);
+        if (LOADZ) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { z0[r] = zq[r >> 2][r & 3]; z1[r] = zq[4 + (r >> 2)][r & 3]; }
+        } else {
+            __syncthreads();   // h1 complete
+            layer2_compute(h1, w2f, L, z0, z1);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = mfma_row(r, L.lane);
@@ -501,7 +551,10 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
                 }
             }
         }
-        // epilogue: g2 = (cvec - d) masked by ReLU(bn2) and validity; running sums; lane-major hand-off
+        // epilogue: g2 = (cvec - d) masked by ReLU(bn2) and validity; running sums; lane-major hand-off.
+        // (Measured: writing this VALU work interleaved with the Gram MFMAs above — two k-steps, one element pair —
+        // is SLOWER, 0.96 vs 0.89 ms: the partner wave on the SIMD already fills the MFMA pipe during the epilogue,
+        // and fillers between the dependent Gram MFMAs only delay them.)
         {
             f32x4 *gt = g2t + ((size_t)(b * T + tile) * 8) * 256 + L.tid;
 #pragma unroll
@@ -557,10 +610,11 @@ struct BwdEParams {
 };
 #define BWD_E_LDS_FLOATS (TP * H1S + TP * H2S + 12 * TP)
 
+template <bool LOADZ>   // LOADZ: z2 read back from pass C's z2t instead of recomputing layer 2 (64 of 192 MFMAs per wave and tile)
 __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
     const float *__restrict__ x, int N, const float *__restrict__ trans, TrainChan P, BwdEParams E,
-    int T, int S, const f32x4 *__restrict__ g2t, float *__restrict__ pc, float *__restrict__ pR,
-    float *__restrict__ pW2) {
+    int T, int S, const f32x4 *__restrict__ z2t, const f32x4 *__restrict__ g2t, float *__restrict__ pc,
+    float *__restrict__ pR, float *__restrict__ pW2) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *h1 = smem;
     float *dz = h1 + TP * H1S;    // [TP][H2S]
@@ -586,23 +640,33 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) { pw0[r] = 0.f; pw1[r] = 0.f; }
     f32x4 w2f[8];   // this wave's layer-2 weight fragments stay in registers for the whole kernel
-    load_w2frag(w2f, P.w2p, cb, L);
+    if (!LOADZ) load_w2frag(w2f, P.w2p, cb, L);
     for (int tile = t0; tile < t1; ++tile) {
         const int nbase = tile * TP;
         float *xs = xbuf + ((tile - t0) & 1) * 6 * TP, *xo = xs + 3 * TP;
-        f32x4 gq[8];   // this lane's 32 g2 values of the tile (rows past N hold zeros)
+        f32x4 gq[8], zq[8];   // this lane's 32 g2 (and z2) values of the tile (g2 rows past N hold zeros)
         {
             const f32x4 *gt = g2t + ((size_t)(b * T + tile) * 8) * 256 + L.tid;
 #pragma unroll
             for (int i = 0; i < 8; ++i) gq[i] = gt[(size_t)i * 256];
+            if (LOADZ) {
+                const f32x4 *zt = z2t + ((size_t)(b * T + tile) * 8) * 256 + L.tid;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) zq[i] = zt[(size_t)i * 256];
+            }
         }
         stage_points(xb, N, tile, has_t, tm, xs, xo, L.tid);
         __syncthreads();
         layer1_tile(xs, P.w1, P.b1, P.s1c, P.t1c, h1, L);
-        __syncthreads();
+        if (!LOADZ) __syncthreads();   // layer 2 reads h1; with LOADZ the dz tile below depends on registers only
         {
             f32x16 a0, a1;
-            layer2_compute(h1, w2f, L, a0, a1);
+            if (LOADZ) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { a0[r] = zq[r >> 2][r & 3]; a1[r] = zq[4 + (r >> 2)][r & 3]; }
+            } else {
+                layer2_compute(h1, w2f, L, a0, a1);
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mfma_row(r, L.lane);
@@ -801,38 +865,50 @@ __global__ __launch_bounds__(256) void fc_bwd_kernel(const float *__restrict__ g
                                                      const float *__restrict__ W, int B, int K, int Nout,
                                                      int tilesW, int tilesX, float *__restrict__ dW,
                                                      float *__restrict__ dx, float *__restrict__ db) {
+    // One WORKGROUP = one 32x32 output tile; its four waves each contract a quarter of the reduction range and meet in
+    // LDS (a tile's contraction is a chain of up to 512 dependent MFMAs: one wave per tile left the launch 4x off the
+    // MFMA time with 1.5 workgroups per CU; split four ways there are 6 balanced workgroups per CU).
+    __shared__ float red[3 * 16 * 64];
+    __shared__ float dred[3 * 32];
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-    const int wid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wid = blockIdx.x;
     const int kblocks = (K + 31) >> 5;
     f32x16 acc = {0};
-    if (wid < tilesW) {
+    const bool is_w = wid < tilesW;
+    int orow0 = 0, ocol = 0;          // output tile: rows orow0 + mfma_row, column ocol (per lane)
+    float dbs = 0.f;
+    if (is_w) {
         const int nb = wid / kblocks, kbk = wid - nb * kblocks;
         const int n = nb * 32 + j, kc = kbk * 32 + j;
         const bool nv = n < Nout, kv = kc < K;
         const float *gp = g + (nv ? n : 0), *xp = x + (kv ? kc : 0);
-        float dbs = 0.f;
-        for (int b0 = 0; b0 < B; b0 += 16) {   // 8 k-steps: 16 loads in flight per lane
-            float av[8], bv[8];
+        const int per = (((B + 3) / 4) + 15) & ~15;               // rows of the batch per wave, a multiple of 16
+        const int bb = wave * per, be = (bb + per < B) ? bb + per : B;
+        float av[8], bv[8];
+        auto fetch = [&](int b0, float (&a)[8], float (&bq)[8]) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int b = b0 + 2 * u + h;
-                const bool ok = b < B;
-                av[u] = (ok && nv) ? gp[(size_t)b * Nout] : 0.f;
-                bv[u] = (ok && kv) ? xp[(size_t)b * K] : 0.f;
+                const bool ok = b < be;
+                a[u] = (ok && nv) ? gp[(size_t)b * Nout] : 0.f;
+                bq[u] = (ok && kv) ? xp[(size_t)b * K] : 0.f;
             }
+        };
+        if (bb < be) fetch(bb, av, bv);
+        for (int b0 = bb; b0 < be; b0 += 16) {   // group i+1's 16 loads in flight while group i's 8 MFMAs issue
+            float na[8], nbv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { na[u] = 0.f; nbv[u] = 0.f; }
+            if (b0 + 16 < be) fetch(b0 + 16, na, nbv);
 #pragma unroll
             for (int u = 0; u < 8; ++u) { acc = mfma32(av[u], bv[u], acc); dbs += av[u]; }
-        }
-        if (kv) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = nb * 32 + mfma_row(r, lane);
-                if (row < Nout) dW[(size_t)row * K + kc] = acc[r];
-            }
+            for (int u = 0; u < 8; ++u) { av[u] = na[u]; bv[u] = nbv[u]; }
         }
+        orow0 = nb * 32; ocol = kc;
         dbs += __shfl_xor(dbs, 32);
-        if (kbk == 0 && h == 0 && nv) db[n] = dbs;
-    } else if (wid - tilesW < tilesX && dx) {
+    } else if (dx) {
         const int t = wid - tilesW;
         const int rb = t / kblocks, kbk = t - rb * kblocks;
         int row = rb * 32 + j; row = row < B ? row : B - 1;
@@ -843,28 +919,44 @@ __global__ __launch_bounds__(256) void fc_bwd_kernel(const float *__restrict__ g
         if (VEC) {   // Nout % 8 == 0: k-block = 8 values of n, lane (j,h) holds n = 8kb + 4h .. +3
             const f32x4 *ap = (const f32x4 *)gr + h;
             const int KB = Nout >> 3;
-            for (int kb = 0; kb < KB; kb += 2) {
-                f32x4 a[2]; float w[2][4];
+            const int per = (((KB + 3) / 4) + 1) & ~1;            // k-blocks per wave, even
+            const int k0 = wave * per, k1 = (k0 + per < KB) ? k0 + per : KB;
+            f32x4 a[2]; float w[2][4];
+            auto fetch = [&](int kb, f32x4 (&aa)[2], float (&ww)[2][4]) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const int kk = kb + u < KB ? kb + u : KB - 1;
-                    a[u] = ap[kk * 2];
+                    const bool ok = kb + u < k1;
+                    const int kk = ok ? kb + u : (k1 > 0 ? k1 - 1 : 0);
+                    aa[u] = ok ? ap[kk * 2] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) w[u][e] = kv ? wp[(size_t)(kk * 8 + 4 * h + e) * K] : 0.f;
-                    if (kb + u >= KB) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int e = 0; e < 4; ++e) ww[u][e] = (kv && ok) ? wp[(size_t)(kk * 8 + 4 * h + e) * K] : 0.f;
                 }
+            };
+            if (k0 < k1) fetch(k0, a, w);
+            for (int kb = k0; kb < k1; kb += 2) {
+                f32x4 na[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+                float nw[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                if (kb + 2 < k1) fetch(kb + 2, na, nw);
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc = mfma32(a[u][e], w[u][e], acc);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    a[u] = na[u];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[u][e] = nw[u][e];
+                }
             }
         } else {
-            for (int n0 = 0; n0 < Nout; n0 += 8) {
+            const int per = (((Nout + 3) / 4) + 7) & ~7;          // values of n per wave, a multiple of 8
+            const int n0w = wave * per, n1w = (n0w + per < Nout) ? n0w + per : Nout;
+            for (int n0 = n0w; n0 < n1w; n0 += 8) {
                 float av[4], bv[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int n = n0 + 2 * u + h;
-                    const bool ok = n < Nout;
+                    const bool ok = n < n1w;
                     av[u] = ok ? gr[n] : 0.f;
                     bv[u] = (ok && kv) ? wp[(size_t)n * K] : 0.f;
                 }
@@ -872,11 +964,35 @@ __global__ __launch_bounds__(256) void fc_bwd_kernel(const float *__restrict__ g
                 for (int u = 0; u < 4; ++u) acc = mfma32(av[u], bv[u], acc);
             }
         }
-        if (kv) {
+        orow0 = rb * 32; ocol = kc;
+    }
+    // meet in LDS: waves 1..3 park their tile, wave 0 adds and stores
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+        if (h == 0) dred[(wave - 1) * 32 + j] = dbs;
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += red[r * 64 + lane] + red[(16 + r) * 64 + lane] + red[(32 + r) * 64 + lane];
+    if (is_w) {
+        const int kbk = wid % kblocks;
+        if (ocol < K) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int orow = rb * 32 + mfma_row(r, lane);
-                if (orow < B) dx[(size_t)orow * K + kc] = acc[r];
+                const int row = orow0 + mfma_row(r, lane);
+                if (row < Nout) dW[(size_t)row * K + ocol] = acc[r];
+            }
+        }
+        const int n = orow0 + j;
+        if (kbk == 0 && h == 0 && n < Nout) db[n] = dbs + dred[j] + dred[32 + j] + dred[64 + j];
+    } else if (dx) {
+        if (ocol < K) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int orow = orow0 + mfma_row(r, lane);
+                if (orow < B) dx[(size_t)orow * K + ocol] = acc[r];
             }
         }
     }
@@ -911,21 +1027,21 @@ int pngpd_cloud_moments(const float *x, int B, int N, double *mom, void *stream)
 
 int pngpd_trunk_bn2_stats(const float *x, int B, int N, const float *trans,
                           const float *w1, const float *b1, const float *s1c, const float *t1c,
-                          const float *w2p, int S, float *part, void *stream) {
+                          const float *w2p, int S, float *part, float *z2t, void *stream) {
     if (!x || !w1 || !b1 || !s1c || !t1c || !w2p || !part || B <= 0 || N <= 0) return PNGPD_ERR_INVALID_ARG;
     const int T = (N + TP - 1) / TP;
     if (!splits_ok(S, T)) return PNGPD_ERR_INVALID_ARG;
     TrainChan P = make_chan(w1, b1, s1c, t1c, w2p, nullptr, nullptr);
     const size_t lds = (TP * H1S + 3 * TP) * sizeof(float);
     hipLaunchKernelGGL(trunk_bn2_stats_kernel, dim3((unsigned)B * S), dim3(256), lds, (hipStream_t)stream,
-                       x, N, trans, P, T, S, part);
+                       x, N, trans, P, T, S, part, (f32x4 *)z2t);
     return pngpd_launch_status();
 }
 
 int pngpd_trunk_fwd_train(const float *x, int B, int N, const float *trans,
                           const float *w1, const float *b1, const float *s1c, const float *t1c,
                           const float *w2p, const float *s2c, const float *t2c, const float *w3sp, int S,
-                          float *pmax, int *parg, float *psum, float *psh, void *stream) {
+                          float *pmax, int *parg, float *psum, float *psh, const float *z2t, void *stream) {
     if (!x || !w1 || !b1 || !s1c || !t1c || !w2p || !s2c || !t2c || !w3sp || !pmax || !parg || !psum || !psh ||
         B <= 0 || N <= 0)
         return PNGPD_ERR_INVALID_ARG;
@@ -933,10 +1049,14 @@ int pngpd_trunk_fwd_train(const float *x, int B, int N, const float *trans,
     if (!splits_ok(S, T)) return PNGPD_ERR_INVALID_ARG;
     TrainChan P = make_chan(w1, b1, s1c, t1c, w2p, s2c, t2c);
     const size_t lds = TRAIN_MAIN_LDS_FLOATS * sizeof(float);
-    int st = pngpd_allow_lds((const void *)trunk_fwd_train_kernel, lds);
+    int st = pngpd_allow_lds(z2t ? (const void *)trunk_fwd_train_kernel<true> : (const void *)trunk_fwd_train_kernel<false>, lds);
     if (st != PNGPD_OK) return st;
-    hipLaunchKernelGGL(trunk_fwd_train_kernel, dim3((unsigned)B * S), dim3(256), lds, (hipStream_t)stream,
-                       x, N, trans, P, w3sp, T, S, pmax, parg, psum, psh);
+    if (z2t)
+        hipLaunchKernelGGL(trunk_fwd_train_kernel<true>, dim3((unsigned)B * S), dim3(256), lds, (hipStream_t)stream,
+                           x, N, trans, P, w3sp, T, S, pmax, parg, psum, psh, (const f32x4 *)z2t);
+    else
+        hipLaunchKernelGGL(trunk_fwd_train_kernel<false>, dim3((unsigned)B * S), dim3(256), lds, (hipStream_t)stream,
+                           x, N, trans, P, w3sp, T, S, pmax, parg, psum, psh, (const f32x4 *)nullptr);
     return pngpd_launch_status();
 }
 
@@ -961,7 +1081,7 @@ int pngpd_trunk_bwd_d(const float *x, int B, int N, const float *trans,
                       const float *w1, const float *b1, const float *s1c, const float *t1c,
                       const float *w2p, const float *s2c, const float *t2c,
                       const float *is2, const float *nm2, const float *Ap, const float *cvec,
-                      const float *w3, const int *idx, const float *coef, int S,
+                      const float *w3, const int *idx, const float *coef, const float *z2t, int S,
                       float *g2t, float *pa, float *ps2, void *stream) {
     if (!x || !w1 || !b1 || !s1c || !t1c || !w2p || !s2c || !t2c || !is2 || !nm2 || !Ap || !cvec || !w3 ||
         !idx || !coef || !g2t || !pa || !ps2 || B <= 0 || N <= 0)
@@ -972,10 +1092,14 @@ int pngpd_trunk_bwd_d(const float *x, int B, int N, const float *trans,
     TrainChan P = make_chan(w1, b1, s1c, t1c, w2p, s2c, t2c);
     BwdDParams D; D.is2 = is2; D.nm2 = nm2; D.Ap = Ap; D.cvec = cvec; D.w3 = w3; D.idx = idx; D.coef = coef;
     const size_t lds = BWD_D_LDS_FLOATS * sizeof(float);
-    int st = pngpd_allow_lds((const void *)trunk_bwd_d_kernel, lds);
+    int st = pngpd_allow_lds(z2t ? (const void *)trunk_bwd_d_kernel<true> : (const void *)trunk_bwd_d_kernel<false>, lds);
     if (st != PNGPD_OK) return st;
-    hipLaunchKernelGGL(trunk_bwd_d_kernel, dim3((unsigned)B * S), dim3(256), lds, (hipStream_t)stream,
-                       x, N, trans, P, D, T, S, (f32x4 *)g2t, pa, ps2);
+    if (z2t)
+        hipLaunchKernelGGL(trunk_bwd_d_kernel<true>, dim3((unsigned)B * S), dim3(256), lds, (hipStream_t)stream,
+                           x, N, trans, P, D, T, S, (const f32x4 *)z2t, (f32x4 *)g2t, pa, ps2);
+    else
+        hipLaunchKernelGGL(trunk_bwd_d_kernel<false>, dim3((unsigned)B * S), dim3(256), lds, (hipStream_t)stream,
+                           x, N, trans, P, D, T, S, (const f32x4 *)nullptr, (f32x4 *)g2t, pa, ps2);
     return pngpd_launch_status();
 }
 
@@ -983,7 +1107,7 @@ int pngpd_trunk_bwd_e(const float *x, int B, int N, const float *trans,
                       const float *w1, const float *b1, const float *s1c, const float *t1c,
                       const float *w2p, const float *is1, const float *nm1, const float *is2, const float *nm2,
                       const float *a1m, const float *a2m, const float *dsc2, const float *w2tp,
-                      const float *g2t, int S, float *pc, float *pR, float *pW2, void *stream) {
+                      const float *z2t, const float *g2t, int S, float *pc, float *pR, float *pW2, void *stream) {
     if (!x || !w1 || !b1 || !s1c || !t1c || !w2p || !is1 || !nm1 || !is2 || !nm2 || !a1m || !a2m || !dsc2 ||
         !w2tp || !g2t || !pc || !pR || !pW2 || B <= 0 || N <= 0)
         return PNGPD_ERR_INVALID_ARG;
@@ -993,10 +1117,14 @@ int pngpd_trunk_bwd_e(const float *x, int B, int N, const float *trans,
     BwdEParams E; E.is1 = is1; E.nm1 = nm1; E.is2 = is2; E.nm2 = nm2; E.a1m = a1m; E.a2m = a2m; E.dsc2 = dsc2;
     E.w2tp = w2tp;
     const size_t lds = BWD_E_LDS_FLOATS * sizeof(float);
-    int st = pngpd_allow_lds((const void *)trunk_bwd_e_kernel, lds);
+    int st = pngpd_allow_lds(z2t ? (const void *)trunk_bwd_e_kernel<true> : (const void *)trunk_bwd_e_kernel<false>, lds);
     if (st != PNGPD_OK) return st;
-    hipLaunchKernelGGL(trunk_bwd_e_kernel, dim3((unsigned)B * S), dim3(256), lds, (hipStream_t)stream,
-                       x, N, trans, P, E, T, S, (const f32x4 *)g2t, pc, pR, pW2);
+    if (z2t)
+        hipLaunchKernelGGL(trunk_bwd_e_kernel<true>, dim3((unsigned)B * S), dim3(256), lds, (hipStream_t)stream,
+                           x, N, trans, P, E, T, S, (const f32x4 *)z2t, (const f32x4 *)g2t, pc, pR, pW2);
+    else
+        hipLaunchKernelGGL(trunk_bwd_e_kernel<false>, dim3((unsigned)B * S), dim3(256), lds, (hipStream_t)stream,
+                           x, N, trans, P, E, T, S, (const f32x4 *)nullptr, (const f32x4 *)g2t, pc, pR, pW2);
     return pngpd_launch_status();
 }
 
@@ -1005,7 +1133,7 @@ int pngpd_fc_bwd(const float *g, const float *x, const float *W, int B, int K, i
     if (!g || !x || !W || !dW || !db || B <= 0 || K <= 0 || Nout <= 0) return PNGPD_ERR_INVALID_ARG;
     const int kblocks = (K + 31) / 32;
     const int tilesW = ((Nout + 31) / 32) * kblocks, tilesX = dx ? ((B + 31) / 32) * kblocks : 0;
-    const unsigned grid = (unsigned)((tilesW + tilesX + 3) / 4);
+    const unsigned grid = (unsigned)(tilesW + tilesX);   // one workgroup per output tile (its waves split the contraction)
     if ((Nout & 7) == 0)
         hipLaunchKernelGGL(fc_bwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, x, W, B, K, Nout,
                            tilesW, tilesX, dW, dx, db);

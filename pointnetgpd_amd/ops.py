@@ -195,24 +195,19 @@ def train_splits(B, N, target_blocks=None):
 
 
 def pack_mfma_b(W, scale=None):
-    """(C,K) fp32 -> MFMA_B packed flat tensor (optionally rows scaled by ``scale``)."""
-    C, K = W.shape
-    zb = torch.zeros(C, device=W.device, dtype=torch.float32)
-    wp, _ = fold_conv_bn(W, zb, bn_weight=scale, layout=LAYOUT_MFMA_B) if scale is None else \
-        _fold_scale(W, zb, scale)
-    return wp
-
-
-def _fold_scale(W, b, scale):
+    """(C,K) fp32 -> MFMA_B packed flat tensor (optionally rows scaled by ``scale``).  No bias operand: the fold
+    kernel reads a NULL bias as zeros."""
     lib = _lib.load()
-    W = _req(W.detach().contiguous(), "W"); C, K = W.shape
-    scale = _req(scale.detach().contiguous(), "scale", (C,))
+    W = _req(W.detach().contiguous(), "W")
+    C, K = W.shape
+    if scale is not None:
+        scale = _req(scale.detach().contiguous(), "scale", (C,))
     wf = torch.empty(C * K, device=W.device, dtype=torch.float32)
     bf = torch.empty(C, device=W.device, dtype=torch.float32)
     with _lib.device_guard(W.device):
-        _lib.check(lib.pngpd_fold_conv_bn(_ptr(W), _ptr(b), _ptr(scale), None, None, None, 0.0, C, K,
-                                          LAYOUT_MFMA_B, _ptr(wf), _ptr(bf), _stream(W)), "fold(scale)")
-    return wf, bf
+        _lib.check(lib.pngpd_fold_conv_bn(_ptr(W), None, _ptr(scale), None, None, None, 0.0, C, K, LAYOUT_MFMA_B,
+                                          _ptr(wf), _ptr(bf), _stream(W)), "pack_mfma_b")
+    return wf
 
 
 def cloud_moments(x):
@@ -222,22 +217,27 @@ def cloud_moments(x):
     return mom
 
 
-def trunk_bn2_stats(x, trans, w1, b1, s1c, t1c, w2p, S):
+def trunk_bn2_stats(x, trans, w1, b1, s1c, t1c, w2p, S, store_z2=True):
+    """-> part (B*S,128,2) partial sums of z2 = W2 h1, z2t (z2 itself in the lane-major tile layout the later passes
+    read back instead of recomputing layers 1-2, or None)."""
     B, _, N = x.shape
     part = torch.empty(B * S, 128, 2, device=x.device, dtype=torch.float32)
-    _call("pngpd_trunk_bn2_stats", x, x, B, N, trans, w1, b1, s1c, t1c, w2p, int(S), part)
-    return part
+    z2t = torch.empty(_lib.load().pngpd_trunk_g2t_bytes(B, N) // 4, device=x.device, dtype=torch.float32) \
+        if store_z2 else None
+    _call("pngpd_trunk_bn2_stats", x, x, B, N, trans, w1, b1, s1c, t1c, w2p, int(S), part, z2t)
+    return part, z2t
 
 
-def trunk_fwd_train(x, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, w3sp, S):
-    """-> pmax (B,S,1024), parg, psum (B*S,2,1024), psh (B*S,128)."""
+def trunk_fwd_train(x, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, w3sp, S, z2t=None):
+    """-> pmax (B,S,1024), parg, psum (B*S,2,1024), psh (B*S,128).  z2t: pass B's stored z2 (read back instead of
+    recomputing layers 1-2) or None."""
     B, _, N = x.shape
     pmax = torch.empty(B, S, 1024, device=x.device, dtype=torch.float32)
     parg = torch.empty(B, S, 1024, device=x.device, dtype=torch.int32)
     psum = torch.empty(B * S, 2, 1024, device=x.device, dtype=torch.float32)
     psh = torch.empty(B * S, 128, device=x.device, dtype=torch.float32)
     _call("pngpd_trunk_fwd_train", x, x, B, N, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, w3sp, int(S), pmax, parg,
-          psum, psh)
+          psum, psh, z2t)
     return pmax, parg, psum, psh
 
 
@@ -266,14 +266,14 @@ def trunk_bwd_gather(x, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, idx, coef, cloud
     return Gp
 
 
-def trunk_bwd_d(x, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, is2, nm2, Ap, cvec, w3, idx, coef, S):
+def trunk_bwd_d(x, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, is2, nm2, Ap, cvec, w3, idx, coef, S, z2t=None):
     """-> g2t (pass D -> pass E hand-off, opaque tile layout), pa (B*S,128,2), ps2 (B*S,12,16,64)."""
     B, _, N = x.shape
     g2t = torch.empty(_lib.load().pngpd_trunk_g2t_bytes(B, N) // 4, device=x.device, dtype=torch.float32)
     pa = torch.empty(B * S, 128, 2, device=x.device, dtype=torch.float32)
     ps2 = torch.empty(B * S, 12 * 1024, device=x.device, dtype=torch.float32)
     _call("pngpd_trunk_bwd_d", x, x, B, N, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, is2, nm2, Ap, cvec, w3,
-          idx, coef, int(S), g2t, pa, ps2)
+          idx, coef, z2t, int(S), g2t, pa, ps2)
     return g2t, pa, ps2
 
 
@@ -291,13 +291,13 @@ def g2t_to_rows(g2t, B, N):
     return out.reshape(B, T * 64, 128)[:, :N].contiguous()
 
 
-def trunk_bwd_e(x, trans, w1, b1, s1c, t1c, w2p, is1, nm1, is2, nm2, a1m, a2m, dsc2, w2tp, g2t, S):
+def trunk_bwd_e(x, trans, w1, b1, s1c, t1c, w2p, is1, nm1, is2, nm2, a1m, a2m, dsc2, w2tp, g2t, S, z2t=None):
     B, _, N = x.shape
     pc = torch.empty(B * S, 64, 2, device=x.device, dtype=torch.float32)
     pR = torch.empty(B, S, 64, 3, device=x.device, dtype=torch.float32)
     pW2 = torch.empty(B * S, 128, 64, device=x.device, dtype=torch.float32)
     _call("pngpd_trunk_bwd_e", x, x, B, N, trans, w1, b1, s1c, t1c, w2p, is1, nm1, is2, nm2, a1m, a2m, dsc2,
-          w2tp, g2t, int(S), pc, pR, pW2)
+          w2tp, z2t, g2t, int(S), pc, pR, pW2)
     return pc, pR, pW2
 
 

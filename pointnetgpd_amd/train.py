@@ -88,7 +88,10 @@ class TrunkTrainFn(torch.autograd.Function):
         s1c, t1c, is1, nm1 = chan1[0], chan1[1], chan1[2], chan1[3]
         # ---- pass B + BN2
         w2p = ops.pack_mfma_b(w2)
-        part = ops.trunk_bn2_stats(x, T, w1, b1c, s1c, t1c, w2p, S)
+        # z2 = W2 h1 is computed once, here, and handed to passes C / D / E (512 B per point): in the fp32 mode always
+        # (pass C reads it), in the bf16 modes (whose pass C computes layer 2 on other operands) only for a backward
+        part, z2t = ops.trunk_bn2_stats(x, T, w1, b1c, s1c, t1c, w2p, S,
+                                        store_z2=_TRAIN_PRECISION == "fp32" or any(ctx.needs_input_grad))
         chan2, stats2 = _e(dev, 4, 128), _e(dev, 256, dtype=F64)
         rm, rv, nbt = _bufs3(bufs2)
         tot2 = _reduce(part, 1, blk, 256)
@@ -106,7 +109,7 @@ class TrunkTrainFn(torch.autograd.Function):
                                                                nterms=_NTERMS[_TRAIN_PRECISION])
         else:
             w3sp = ops.pack_mfma_b(w3, scale=sgn)
-            pmax, parg, psum, psh = ops.trunk_fwd_train(x, T, w1, b1c, s1c, t1c, w2p, s2c, t2c, w3sp, S)
+            pmax, parg, psum, psh = ops.trunk_fwd_train(x, T, w1, b1c, s1c, t1c, w2p, s2c, t2c, w3sp, S, z2t)
         stats3 = _e(dev, 2048, dtype=F64)
         rm, rv, nbt = _bufs3(bufs3)
         # the pass's two partial buffers in one launch: sum / sum of squares of z3s, and the column sums of h2
@@ -117,6 +120,7 @@ class TrunkTrainFn(torch.autograd.Function):
         _call("pngpd_pool_finalize", x, pmax, parg, B, Sc, stats3, g3c, be3c, float(eps), int(relu_last), pooled,
               idx, zhat)
         ctx.relu_last, ctx.eps, ctx.has_t, ctx.S = relu_last, eps, T is not None, S
+        ctx.z2t = z2t          # a plain workspace buffer, not part of the autograd graph
         ctx.save_for_backward(x, T if T is not None else x.new_empty(0), w1, b1c, g1c, w2, g2c, w3, g3c, mom,
                               chan1, stats1, chan2, stats2, stats3, pooled, idx, zhat, w2p, sh)
         return pooled
@@ -141,7 +145,8 @@ class TrunkTrainFn(torch.autograd.Function):
         _call("pngpd_a_cvec_finalize", x, sh, B, N, w3, g3c, stats3, m12, eps, Ap, cvec)
         # ---- arg-extremum gather (sparse term of dW3) and pass D (g2, its BN2 sums, and the Gram of h2)
         Gp = ops.trunk_bwd_gather(x, T, w1, b1c, s1c, t1c, w2p, s2c, t2c, idx, coef)
-        g2t, pa, ps2 = ops.trunk_bwd_d(x, T, w1, b1c, s1c, t1c, w2p, s2c, t2c, is2, nm2, Ap, cvec, w3, idx, coef, S)
+        z2t = ctx.z2t
+        g2t, pa, ps2 = ops.trunk_bwd_d(x, T, w1, b1c, s1c, t1c, w2p, s2c, t2c, is2, nm2, Ap, cvec, w3, idx, coef, S, z2t)
         G, a12, S2c = ops.reduce4((Gp, 1, Gp.shape[0], 1024 * 128), (pa, 1, blk, 256), (ps2, 1, blk, 12 * 1024))
         dW3 = _e(dev, 1024, 128)
         _call("pngpd_dw3_finalize", x, G, S2c, sh, B, N, w3, g3c, stats3, m12, eps, dW3)
@@ -150,7 +155,7 @@ class TrunkTrainFn(torch.autograd.Function):
         # ---- pass E (also contracts dW2 = sum_points dz2 h1^T on the MFMA)
         w2tp = ops.pack_mfma_b(w2.t().contiguous())
         pc, pR, pW2 = ops.trunk_bwd_e(x, T, w1, b1c, s1c, t1c, w2p, is1, nm1, is2, nm2, evec[0], evec[1], evec[2],
-                                      w2tp, g2t, S)
+                                      w2tp, g2t, S, z2t)
         dW2_64, c12, Rb = ops.reduce4((pW2, 1, blk, 128 * 64), (pc, 1, blk, 128), (pR, B, S, 192))
         dW2 = dW2_64[0].to(torch.float32)
         dW1, dg1, dbe1 = _e(dev, 64, 3), _e(dev, 64), _e(dev, 64)

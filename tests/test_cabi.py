@@ -110,11 +110,11 @@ def test_argument_validation_of_every_family():
     assert lib.pngpd_crop_resample(p, 0, 10, p, None, p, 0, 1, p, p, 16, 8, 1, 20, 0, None, p, p, None) == INV      # gather, Pg 0
     assert lib.pngpd_crop_resample(p, 0, 10, p, None, None, 0, 1, p, p, 1 << 20, 8, 1, 20, 0, None, p, p, None) == UNSUP  # LDS
     # training passes
-    assert lib.pngpd_trunk_bn2_stats(p, 4, 100, None, p, p, p, p, p, 0, p, None) == INV               # S < 1
-    assert lib.pngpd_trunk_bn2_stats(p, 4, 100, None, p, p, p, p, p, 3, p, None) == INV               # S > ceil(N/64)
-    assert lib.pngpd_trunk_fwd_train(p, 4, 100, None, p, p, p, p, p, p, p, p, 3, p, p, p, p, None) == INV
-    assert lib.pngpd_trunk_bwd_d(p, 4, 100, None, *([p] * 14), 3, p, p, p, None) == INV
-    assert lib.pngpd_trunk_bwd_e(p, 4, 100, None, *([p] * 14), 0, p, p, p, None) == INV
+    assert lib.pngpd_trunk_bn2_stats(p, 4, 100, None, p, p, p, p, p, 0, p, None, None) == INV         # S < 1
+    assert lib.pngpd_trunk_bn2_stats(p, 4, 100, None, p, p, p, p, p, 3, p, None, None) == INV         # S > ceil(N/64)
+    assert lib.pngpd_trunk_fwd_train(p, 4, 100, None, p, p, p, p, p, p, p, p, 3, p, p, p, p, None, None) == INV
+    assert lib.pngpd_trunk_bwd_d(p, 4, 100, None, *([p] * 14), None, 3, p, p, p, None) == INV
+    assert lib.pngpd_trunk_bwd_e(p, 4, 100, None, *([p] * 14), p, 0, p, p, p, None) == INV
     assert lib.pngpd_reduce_partials4(*([None, 0, 0, 0, None] * 4), None) == INV                   # no segment
     assert lib.pngpd_reduce_partials4(p, 1, 0, 8, p, *([None, 0, 0, 0, None] * 3), None) == INV    # R == 0
     assert lib.pngpd_fold_conv_bn(p, p, None, None, None, None, 1e-5, 30, 8, 1, p, p, None) == INV      # MFMA_B needs C % 32 == 0

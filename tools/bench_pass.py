@@ -39,11 +39,13 @@ def timeit(name, fn, reps=10):
 S = int(os.environ.get("PNGPD_TRAIN_SPLITS", "0")) or ops.train_splits(B, N)
 print(f"B {B} N {N} S {S}")
 timeit("infer", lambda: ops.trunk_fwd_infer(x, T, w1, b1, w2p, t2c, w3p, r(1024), relu_last=False))
-timeit("bn2_stats", lambda: ops.trunk_bn2_stats(x, T, w1, b1, s1c, t1c, w2p, S))
-timeit("fwd_train", lambda: ops.trunk_fwd_train(x, T, w1, b1, s1c, t1c, w2p, s2c, t2c, w3p, S))
+_, z2t = timeit("bn2_stats", lambda: ops.trunk_bn2_stats(x, T, w1, b1, s1c, t1c, w2p, S))
+if os.environ.get("PNGPD_RECOMPUTE") == "1":
+    z2t = None          # A/B: passes C / D / E recompute layers 1-2 instead of reading pass B's z2
+timeit("fwd_train", lambda: ops.trunk_fwd_train(x, T, w1, b1, s1c, t1c, w2p, s2c, t2c, w3p, S, z2t))
 timeit("gather", lambda: ops.trunk_bwd_gather(x, T, w1, b1, s1c, t1c, w2p, s2c, t2c, idx, coef))
-g2t, pa, ps2 = timeit("bwd_d", lambda: ops.trunk_bwd_d(x, T, w1, b1, s1c, t1c, w2p, s2c, t2c, is2, nm2, Ap, cvec, w3, idx, coef, S))
-pc, pR, pW2 = timeit("bwd_e", lambda: ops.trunk_bwd_e(x, T, w1, b1, s1c, t1c, w2p, is1, nm1, is2, nm2, ev[0], ev[1], ev[2], w2tp, g2t, S))
+g2t, pa, ps2 = timeit("bwd_d", lambda: ops.trunk_bwd_d(x, T, w1, b1, s1c, t1c, w2p, s2c, t2c, is2, nm2, Ap, cvec, w3, idx, coef, S, z2t))
+pc, pR, pW2 = timeit("bwd_e", lambda: ops.trunk_bwd_e(x, T, w1, b1, s1c, t1c, w2p, is1, nm1, is2, nm2, ev[0], ev[1], ev[2], w2tp, g2t, S, z2t))
 Gp = ops.trunk_bwd_gather(x, T, w1, b1, s1c, t1c, w2p, s2c, t2c, idx, coef)
 timeit("reduce_D(3seg)", lambda: ops.reduce4((Gp, 1, Gp.shape[0], 1024 * 128), (pa, 1, B * S, 256), (ps2, 1, B * S, 12 * 1024)))
 timeit("reduce_E(3seg)", lambda: ops.reduce4((pW2, 1, B * S, 128 * 64), (pc, 1, B * S, 128), (pR, B, S, 192)))
