@@ -758,41 +758,79 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
 
 // ---------------------------------------------------------------------------------------
 // BatchNorm1d over the batch (FC stacks) — train forward / backward, optional fused ReLU.
-// block = 32 channels x 32 row lanes (1024 threads).
+// block = 16 channels x 64 row lanes (1024 threads); thread (cx, ry) owns rows ry, ry+64, ...  With REG (B <= 1024)
+// the thread's <= 16 values are loaded ONCE, all loads in flight together, and stay in registers through the
+// statistics and the normalisation (the layer is 2 MB: the kernel is pure load latency, so one exposed round trip
+// instead of three, and 2x the workgroups of a 32-channel block).
 // ---------------------------------------------------------------------------------------
+#define BN1D_CW 16
+#define BN1D_RL 64
+#define BN1D_NV 16
+
+__device__ __forceinline__ float bn1d_colsum(float (*red)[BN1D_CW + 1], int cx, int ry, float v) {
+    __syncthreads();          // previous use of red finished
+    red[ry][cx] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < BN1D_RL; ++i) t += red[i][cx];
+    return t;
+}
+
+template <bool REG>
 __global__ __launch_bounds__(1024) void bn1d_fwd_train_kernel(
     const float *__restrict__ z, int B, int C, const float *__restrict__ gamma,
     const float *__restrict__ beta, float eps, int relu, float *__restrict__ y,
     float *__restrict__ mean_out, float *__restrict__ var_out,
     float momentum, float *rm, float *rv, long long *nbt) {
-    __shared__ float red[32][33];
-    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cx;
+    __shared__ float red[BN1D_RL][BN1D_CW + 1];
+    const int cx = threadIdx.x & (BN1D_CW - 1), ry = threadIdx.x / BN1D_CW;
+    const int c = blockIdx.x * BN1D_CW + cx;
     const bool ok = c < C;
+    const float *zc = z + (ok ? c : 0);
+    float zv[BN1D_NV];
     float s = 0.f;
-    if (ok) for (int b = ry; b < B; b += 32) s += z[(size_t)b * C + c];
-    red[ry][cx] = s;
-    __syncthreads();
-    float mean = 0.f;
+    if (REG) {
 #pragma unroll
-    for (int i = 0; i < 32; ++i) mean += red[i][cx];
-    mean /= (float)B;
-    __syncthreads();
+        for (int i = 0; i < BN1D_NV; ++i) {
+            const int b = ry + BN1D_RL * i;
+            zv[i] = (ok && b < B) ? zc[(size_t)b * C] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < BN1D_NV; ++i) s += zv[i];
+    } else if (ok) {
+        for (int b = ry; b < B; b += BN1D_RL) s += zc[(size_t)b * C];
+    }
+    const float mean = bn1d_colsum(red, cx, ry, s) / (float)B;
     float q = 0.f;
-    if (ok) for (int b = ry; b < B; b += 32) { float d = z[(size_t)b * C + c] - mean; q = fmaf(d, d, q); }
-    red[ry][cx] = q;
-    __syncthreads();
-    float var = 0.f;
+    if (REG) {
 #pragma unroll
-    for (int i = 0; i < 32; ++i) var += red[i][cx];
-    var /= (float)B;
+        for (int i = 0; i < BN1D_NV; ++i) {
+            const float d = (ry + BN1D_RL * i < B) ? zv[i] - mean : 0.f;
+            q = fmaf(d, d, q);
+        }
+    } else if (ok) {
+        for (int b = ry; b < B; b += BN1D_RL) { const float d = zc[(size_t)b * C] - mean; q = fmaf(d, d, q); }
+    }
+    const float var = bn1d_colsum(red, cx, ry, q) / (float)B;
     if (!ok) return;
     const float inv = 1.0f / sqrtf(var + eps);
     const float g = gamma[c], be = beta[c];
-    for (int b = ry; b < B; b += 32) {
-        float v = (z[(size_t)b * C + c] - mean) * inv * g + be;
-        if (relu) v = fmaxf(v, 0.f);
-        y[(size_t)b * C + c] = v;
+    float *yc = y + c;
+    if (REG) {
+#pragma unroll
+        for (int i = 0; i < BN1D_NV; ++i) {
+            const int b = ry + BN1D_RL * i;
+            float v = (zv[i] - mean) * inv * g + be;
+            if (relu) v = v < 0.f ? 0.f : v;
+            if (b < B) yc[(size_t)b * C] = v;
+        }
+    } else {
+        for (int b = ry; b < B; b += BN1D_RL) {
+            float v = (zc[(size_t)b * C] - mean) * inv * g + be;
+            if (relu) v = v < 0.f ? 0.f : v;
+            yc[(size_t)b * C] = v;
+        }
     }
     if (ry == 0) {
         mean_out[c] = mean; var_out[c] = var;
@@ -805,36 +843,63 @@ __global__ __launch_bounds__(1024) void bn1d_fwd_train_kernel(
 }
 
 // dy: gradient wrt the (post-ReLU if relu) output y.  dz, dgamma, dbeta out.
+template <bool REG>
 __global__ __launch_bounds__(1024) void bn1d_bwd_kernel(
     const float *__restrict__ dy, const float *__restrict__ z, const float *__restrict__ y, int B, int C,
     const float *__restrict__ gamma, const float *__restrict__ mean, const float *__restrict__ var,
     float eps, int relu, float *__restrict__ dz, float *__restrict__ dgamma, float *__restrict__ dbeta) {
-    __shared__ float red[2][32][33];
-    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cx;
+    __shared__ float red[BN1D_RL][BN1D_CW + 1];
+    const int cx = threadIdx.x & (BN1D_CW - 1), ry = threadIdx.x / BN1D_CW;
+    const int c = blockIdx.x * BN1D_CW + cx;
     const bool ok = c < C;
-    float mu = 0.f, inv = 0.f;
-    if (ok) { mu = mean[c]; inv = 1.0f / sqrtf(var[c] + eps); }
+    const int cc = ok ? c : 0;
+    const float mu = mean[cc], inv = 1.0f / sqrtf(var[cc] + eps);
+    float gv[BN1D_NV], xh[BN1D_NV];
     float s1 = 0.f, s2 = 0.f;
-    if (ok) for (int b = ry; b < B; b += 32) {
-        const size_t i = (size_t)b * C + c;
-        float g = dy[i];
-        if (relu && !(y[i] > 0.f)) g = 0.f;
-        s1 += g;
-        s2 = fmaf(g, (z[i] - mu) * inv, s2);
-    }
-    red[0][ry][cx] = s1; red[1][ry][cx] = s2;
-    __syncthreads();
-    float t1 = 0.f, t2 = 0.f;
+    if (REG) {
+        float yv[BN1D_NV];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) { t1 += red[0][i][cx]; t2 += red[1][i][cx]; }
+        for (int i = 0; i < BN1D_NV; ++i) {
+            const int b = ry + BN1D_RL * i;
+            const bool in = ok && b < B;
+            const unsigned o = (unsigned)b * (unsigned)C + (unsigned)cc;   // B <= 1024 here: B*C fits 32 bits
+            gv[i] = in ? dy[o] : 0.f;
+            xh[i] = in ? z[o] : mu;
+            yv[i] = (in && relu) ? y[o] : 1.f;
+        }
+#pragma unroll
+        for (int i = 0; i < BN1D_NV; ++i) {
+            if (!(yv[i] > 0.f)) gv[i] = 0.f;
+            xh[i] = (xh[i] - mu) * inv;
+            s1 += gv[i];
+            s2 = fmaf(gv[i], xh[i], s2);
+        }
+    } else if (ok) {
+        for (int b = ry; b < B; b += BN1D_RL) {
+            const size_t i = (size_t)b * C + c;
+            float g = dy[i];
+            if (relu && !(y[i] > 0.f)) g = 0.f;
+            s1 += g;
+            s2 = fmaf(g, (z[i] - mu) * inv, s2);
+        }
+    }
+    const float t1 = bn1d_colsum(red, cx, ry, s1);
+    const float t2 = bn1d_colsum(red, cx, ry, s2);
     if (!ok) return;
     const float gi = gamma[c] * inv, m1 = t1 / (float)B, m2 = t2 / (float)B;
-    for (int b = ry; b < B; b += 32) {
-        const size_t i = (size_t)b * C + c;
-        float g = dy[i];
-        if (relu && !(y[i] > 0.f)) g = 0.f;
-        dz[i] = gi * (g - m1 - (z[i] - mu) * inv * m2);
+    if (REG) {
+#pragma unroll
+        for (int i = 0; i < BN1D_NV; ++i) {
+            const int b = ry + BN1D_RL * i;
+            if (b < B) dz[(size_t)b * C + c] = gi * (gv[i] - m1 - xh[i] * m2);
+        }
+    } else {
+        for (int b = ry; b < B; b += BN1D_RL) {
+            const size_t i = (size_t)b * C + c;
+            float g = dy[i];
+            if (relu && !(y[i] > 0.f)) g = 0.f;
+            dz[i] = gi * (g - m1 - (z[i] - mu) * inv * m2);
+        }
     }
     if (ry == 0) { dgamma[c] = t2; dbeta[c] = t1; }
 }
@@ -1147,8 +1212,13 @@ int pngpd_bn1d_fwd_train(const float *z, int B, int C, const float *gamma, const
                          int relu, float *y, float *mean, float *var, float momentum, float *rm, float *rv,
                          long long *nbt, void *stream) {
     if (!z || !gamma || !beta || !y || !mean || !var || B <= 0 || C <= 0 || (rm && !rv)) return PNGPD_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(bn1d_fwd_train_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream,
-                       z, B, C, gamma, beta, eps, relu, y, mean, var, momentum, rm, rv, nbt);
+    const dim3 grid((C + BN1D_CW - 1) / BN1D_CW);
+    if (B <= BN1D_RL * BN1D_NV)
+        hipLaunchKernelGGL(bn1d_fwd_train_kernel<true>, grid, dim3(1024), 0, (hipStream_t)stream,
+                           z, B, C, gamma, beta, eps, relu, y, mean, var, momentum, rm, rv, nbt);
+    else
+        hipLaunchKernelGGL(bn1d_fwd_train_kernel<false>, grid, dim3(1024), 0, (hipStream_t)stream,
+                           z, B, C, gamma, beta, eps, relu, y, mean, var, momentum, rm, rv, nbt);
     return pngpd_launch_status();
 }
 
@@ -1157,8 +1227,13 @@ int pngpd_bn1d_bwd(const float *dy, const float *z, const float *y, int B, int C
                    float *dz, float *dgamma, float *dbeta, void *stream) {
     if (!dy || !z || !y || !gamma || !mean || !var || !dz || !dgamma || !dbeta || B <= 0 || C <= 0)
         return PNGPD_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(bn1d_bwd_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream,
-                       dy, z, y, B, C, gamma, mean, var, eps, relu, dz, dgamma, dbeta);
+    const dim3 grid((C + BN1D_CW - 1) / BN1D_CW);
+    if (B <= BN1D_RL * BN1D_NV)
+        hipLaunchKernelGGL(bn1d_bwd_kernel<true>, grid, dim3(1024), 0, (hipStream_t)stream,
+                           dy, z, y, B, C, gamma, mean, var, eps, relu, dz, dgamma, dbeta);
+    else
+        hipLaunchKernelGGL(bn1d_bwd_kernel<false>, grid, dim3(1024), 0, (hipStream_t)stream,
+                           dy, z, y, B, C, gamma, mean, var, eps, relu, dz, dgamma, dbeta);
     return pngpd_launch_status();
 }
 

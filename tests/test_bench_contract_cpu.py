@@ -6,8 +6,34 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _latest_bench_line():
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_final.json")))
+    assert files, "no committed bench line under profiles/"
+    return json.load(open(files[-1])), os.path.basename(files[-1])
+
+
+def test_round2_bench_line_fields():
+    """Fields added in round 2: event timing beside the wall clock, executed training FLOPs,
+    the traffic figure labelled as stored, CPU baselines for the train step and the crop."""
+    line, name = _latest_bench_line()
+    if name < "r02":
+        import pytest
+        pytest.skip("round-1 line")
+    assert abs(line["ms_per_step_events"] - line["ms_per_step"]) / line["ms_per_step"] < 0.02
+    assert "median" in line["timing"]
+    t = line["train"]
+    assert abs(t["ms_per_step_events"] - t["ms_per_step"]) / t["ms_per_step"] < 0.02
+    assert 0.3 < t["tflops_executed_frac_of_fp32_mfma_peak"] < 1.0
+    assert abs(t["value"] - t["global_batch"] / (t["ms_per_step"] * 1e-3)) / t["value"] < 1e-3
+    r = line["roofline"]
+    assert r["traffic"] is None or "STORED" in r["traffic_source"] or "measured" in r["traffic_source"]
+    c = line["cpu_baseline"]
+    assert c["train_step"]["value"] > 0 and c["crop"]["value"] > 0
+
+
 def test_committed_bench_line_has_the_contract_fields():
-    line = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_final.json")))
+    line, _ = _latest_bench_line()
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in line, k
