@@ -20,17 +20,22 @@ CONFIGS = [("C1 shape on GPU: B=64 N=750 k=2", 64, 750, 2),
            ("C4: B=512 N=4096 k=2", 512, 4096, 2)]
 
 
-def timeit(fn, reps):
+def timeit(fn, reps, blocks=5):
+    """Median over ``blocks`` event-timed blocks of ``reps`` calls: a one-off host hiccup early in the process's life
+    (tens of ms, seen once per run at a random leg) lands in one block and does not reach the reported figure."""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps
+    out = []
+    for _ in range(blocks):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        out.append(e0.elapsed_time(e1) / reps)
+    return sorted(out)[len(out) // 2]
 
 
 def main():

@@ -15,5 +15,6 @@ DB=$(find /tmp/pmcF -name "*.db" | head -1)
 ( cd /tmp && timeout 150 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pmcW -o pw -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-train --no-fast --min-seconds 0 > /tmp/pw.log 2>&1; echo "pmcW rc=$?" )
 DB=$(find /tmp/pmcW -name "*.db" | head -1)
 [ -n "$DB" ] && python tools/rocprof_summary.py gpurun_out/${TAG}_pmc_write.md "bench.py PMC pass, WRITE_SIZE (KB)=$DB" > /dev/null
+python tools/pmc_to_json.py gpurun_out/${TAG}_pmc_trunk.json $(find /tmp/pmc2 -name "*.db" | head -1) $(find /tmp/pmcF -name "*.db" | head -1) $(find /tmp/pmcW -name "*.db" | head -1) "$(cat .commit_id 2>/dev/null || echo unknown)" > /dev/null 2>&1; echo "pmc json rc=$?"
 fi
 ls -la gpurun_out | tail -5
