@@ -195,6 +195,29 @@ int pngpd_trunk_bwd_e(const float *x, int B, int N, const float *trans,
                       const float *a1m, const float *a2m, const float *dsc2, const float *w2tp,
                       const float *z2t, const float *g2t, int S, float *pc, float *pR, float *pW2, void *stream);
 
+/* The same passes with their contractions on the bf16 matrix cores (the opt-in reduced-precision training modes,
+ * BASELINE configs[2]; reference call sites as above: pointnet.py:29-33,140-149 under loss.backward(), main_1v.py:75).
+ * nterms = 1 plain bf16 operands, 3 = bf16x3 split products; accumulators, BatchNorm statistics, masks and every
+ * output stay fp32 and keep the layouts of the fp32 entry points.  Operand matrices are pngpd_split_pack_bf16
+ * outputs: w2x of W2 (128,64), Ax of the matrix A (128,128) that pngpd_a_cvec_finalize writes row-major into
+ * `Arow`, w2tx of W2^T as a (64,128) matrix.  Passes D and E always read z2 back (z2t must be non-NULL).         */
+int pngpd_trunk_bn2_stats_bf(const float *x, int B, int N, const float *trans,
+                             const float *w1, const float *b1, const float *s1c, const float *t1c,
+                             const void *w2x, int nterms, int S, float *part, float *z2t, void *stream);
+int pngpd_trunk_bwd_gather_bf(const float *x, int B, int N, const float *trans,
+                              const float *w1, const float *b1, const float *s1c, const float *t1c,
+                              const void *w2x, int nterms, const float *s2c, const float *t2c,
+                              const int *idx, const float *coef, int clouds_per_range, float *Gp, void *stream);
+int pngpd_trunk_bwd_d_bf(const float *x, int B, int N, const float *s2c, const float *t2c,
+                         const float *is2, const float *nm2, const void *Ax, int nterms, const float *cvec,
+                         const float *w3, const int *idx, const float *coef, const float *z2t, int S,
+                         float *g2t, float *pa, float *ps2, void *stream);
+int pngpd_trunk_bwd_e_bf(const float *x, int B, int N, const float *trans,
+                         const float *w1, const float *b1, const float *s1c, const float *t1c,
+                         const float *is1, const float *nm1, const float *is2, const float *nm2,
+                         const float *a1m, const float *a2m, const float *dsc2, const void *w2tx, int nterms,
+                         const float *z2t, const float *g2t, int S, float *pc, float *pR, float *pW2, void *stream);
+
 /* Backward of a Linear layer y = x W^T + b (pointnet.py:35-37,191-193; loss.backward() of main_1v.py:75) in one
  * launch, operands read in place: g (B,Nout) upstream gradient, x (B,K) the layer input, W (Nout,K) ->
  * dW (Nout,K) = g^T x, db (Nout) = sum_b g, dx (B,K) = g W (dx may be NULL).                                */

@@ -49,6 +49,15 @@ SIGNATURES = {
                           [c_f32p] * 3 + [c_void]),
     "pngpd_trunk_bwd_e": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 16 + [ctypes.c_int] +
                           [c_f32p] * 3 + [c_void]),
+    # the same passes on bf16 / bf16x3 operands (nterms 1 / 3)
+    "pngpd_trunk_bn2_stats_bf": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 5 +
+                                 [c_void, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, c_void]),
+    "pngpd_trunk_bwd_gather_bf": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 5 +
+                                  [c_void, ctypes.c_int] + [c_f32p] * 4 + [ctypes.c_int, c_f32p, c_void]),
+    "pngpd_trunk_bwd_d_bf": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 4 +
+                             [c_void, ctypes.c_int] + [c_f32p] * 5 + [ctypes.c_int] + [c_f32p] * 3 + [c_void]),
+    "pngpd_trunk_bwd_e_bf": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 12 +
+                             [c_void, ctypes.c_int, c_f32p, c_f32p, ctypes.c_int] + [c_f32p] * 3 + [c_void]),
     "pngpd_fc_bwd": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p,
                                     c_f32p, c_void]),
     "pngpd_bn1d_fwd_train": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, ctypes.c_float,

@@ -7,6 +7,7 @@
 // row i at a common column offset) conflict-free: row stride 68 / 132 dwords == 4 (mod 64).
 #pragma once
 #include "pngpd_common.h"
+#include "pngpd_bf.h"
 
 #define TP 64
 #define H1S 68
@@ -239,6 +240,43 @@ __device__ __forceinline__ void k128_stream(const float *tile, const float *__re
             if (NPB == 2) acc1 = mfma32(a1[t], wv[t], acc1);
         }
         a0 = n0; a1 = n1;
+    }
+}
+
+// ---- bf16 matrix-core variants (opt-in reduced precision, pngpd_bf.h): the LDS tiles stay fp32, operands are
+// converted (NT = 1) or split hi/lo (NT = 3) when they are read — the same LDS traffic as the fp32 loops, an eighth of
+// the MFMA issue slots per product term.
+// Layer 2 (64 -> 128) for channel block cb: A rows from the fp32 h1 tile, B from split_pack_bf16 fragments (KS = 4).
+template <int NT>
+__device__ __forceinline__ void layer2_compute_bf(const float *h1, const u16 *__restrict__ w2x, int cb, const Lane &L,
+                                                  f32x16 &acc0, f32x16 &acc1) {
+    const float *a0p = h1 + L.j * H1S + L.h * 8;
+    const float *a1p = h1 + (32 + L.j) * H1S + L.h * 8;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        f32x4 wh, wl, ah, al;
+        bf_wfrag<NT>(w2x, 4, cb, ks, L.lane, wh, wl);
+        bf_pack8<NT>(*(const f32x4 *)(a0p + ks * 16), *(const f32x4 *)(a0p + ks * 16 + 4), ah, al);
+        acc0 = bf_mma<NT>(ah, al, wh, wl, acc0);
+        bf_pack8<NT>(*(const f32x4 *)(a1p + ks * 16), *(const f32x4 *)(a1p + ks * 16 + 4), ah, al);
+        acc1 = bf_mma<NT>(ah, al, wh, wl, acc1);
+    }
+}
+
+// K = 128 product of rows [pb*32, pb*32+32) of an h2-shaped fp32 tile against split_pack_bf16 fragments of a (C,128)
+// matrix, channel block cb, accumulated INTO acc.
+template <int NT>
+__device__ __forceinline__ void k128_bf(const float *tile, const u16 *__restrict__ wx, int cb, int pb, const Lane &L,
+                                        f32x16 &acc) {
+    const float *ap = tile + (pb * 32 + L.j) * H2S + L.h * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        f32x4 wh, wl, ah, al;
+        bf_wfrag<NT>(wx, 8, cb, ks, L.lane, wh, wl);
+        bf_pack8<NT>(*(const f32x4 *)(ap + ks * 16), *(const f32x4 *)(ap + ks * 16 + 4), ah, al);
+        acc = bf_mma<NT>(ah, al, wh, wl, acc);
     }
 }
 

@@ -17,7 +17,12 @@
 struct TrainChan {
     const float *w1, *b1, *s1c, *t1c;   // layer 1: (64,3) raw, bias, scale, shift
     const float *w2p, *s2c, *t2c;       // layer 2: raw MFMA_B packed (128,64), scale, shift
+    const u16 *w2x;                     // layer 2 as split_pack_bf16 fragments (NT > 0 kernels only)
 };
+
+// NT (template parameter of passes B, gather, D, E): 0 = exact fp32 on v_mfma_f32_32x32x2_f32 (the default, and the
+// only arithmetic the parity tests pin); 1 / 3 = the contractions on bf16 / bf16x3 operands (pngpd_bf.h), everything
+// else — BatchNorm statistics, masks, sums, accumulators — unchanged in fp32.
 
 // Workgroups per cloud: the caller passes S explicitly (pngpd_trunk_splits() suggests one); nothing here is
 // process-global, so buffer sizes computed by the caller and the launch always agree.
@@ -55,6 +60,7 @@ __global__ __launch_bounds__(256) void cloud_moments_kernel(const float *__restr
 // pass B: BN2 statistics.  part[blk][c][0..1] = sum, sum of squares of z2 = W2 h1 over the
 // workgroup's valid points.
 // ---------------------------------------------------------------------------------------
+template <int NT>
 __global__ __launch_bounds__(256, 2) void trunk_bn2_stats_kernel(
     const float *__restrict__ x, int N, const float *__restrict__ trans, TrainChan P,
     int T, int S, float *__restrict__ part, f32x4 *__restrict__ z2t) {
@@ -73,14 +79,15 @@ __global__ __launch_bounds__(256, 2) void trunk_bn2_stats_kernel(
     }
     float sum = 0.f, sq = 0.f;
     f32x4 w2f[8];   // this wave's layer-2 weight fragments stay in registers for the whole kernel
-    load_w2frag(w2f, P.w2p, L.wave, L);
+    if (NT == 0) load_w2frag(w2f, P.w2p, L.wave, L);
     for (int tile = t0; tile < t1; ++tile) {
         stage_points(xb, N, tile, has_t, tm, xs, nullptr, L.tid);
         __syncthreads();
         layer1_tile(xs, P.w1, P.b1, P.s1c, P.t1c, h1, L);
         __syncthreads();
         f32x16 a0, a1;
-        layer2_compute(h1, w2f, L, a0, a1);
+        if constexpr (NT == 0) layer2_compute(h1, w2f, L, a0, a1);
+        else layer2_compute_bf<NT>(h1, P.w2x, L.wave, L, a0, a1);
         const int nbase = tile * TP;
         if (z2t) {   // z2 is computed ONCE per step, here; passes C, D and E read it back (lane-major tiles, 512 B/point)
             f32x4 *zt = z2t + ((size_t)(b * T + tile) * 8) * 256 + L.tid;
@@ -283,6 +290,7 @@ __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
 // gather pass: Gp[rng][c][k] = sum_{b in range} coef[b][c] * h2[b][k] evaluated at point idx[b][c]
 // workgroup = (64-channel chunk cc, cloud range rng).
 // ---------------------------------------------------------------------------------------
+template <int NT>
 __global__ __launch_bounds__(256, 2) void trunk_bwd_gather_kernel(
     const float *__restrict__ x, int B, int N, const float *__restrict__ trans, TrainChan P,
     const int *__restrict__ idx, const float *__restrict__ coef, int clouds_per_range,
@@ -302,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_gather_kernel(
     for (int i = 0; i < 32; ++i) g[i] = 0.f;
     const int k = L.tid & 127, rh = L.tid >> 7;
     f32x4 w2f[8];
-    load_w2frag(w2f, P.w2p, L.wave, L);
+    if (NT == 0) load_w2frag(w2f, P.w2p, L.wave, L);
     // the arg-max points of cloud b+1 (a dependent idx -> x gather) are fetched while cloud b is processed
     float nx0 = 0.f, nx1 = 0.f, nx2 = 0.f, ncf = 0.f;
     auto fetch = [&](int b) {
@@ -336,7 +344,8 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_gather_kernel(
         {
             f32x16 a0, a1;
             const int cb = L.wave;
-            layer2_compute(h1, w2f, L, a0, a1);
+            if constexpr (NT == 0) layer2_compute(h1, w2f, L, a0, a1);
+            else layer2_compute_bf<NT>(h1, P.w2x, cb, L, a0, a1);
             const float sc = P.s2c[cb * 32 + L.j], sh = P.t2c[cb * 32 + L.j];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -379,6 +388,7 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_gather_kernel(
 struct BwdDParams {
     const float *is2, *nm2;     // zhat2 = z2*is2 + nm2
     const float *Ap;            // (128,128) symmetric, MFMA_B packed
+    const u16 *Ax;              // the same matrix as split_pack_bf16 fragments (NT > 0)
     const float *cvec;          // (128)
     const float *w3;            // (1024,128) raw row-major
     const int *idx;             // (B,1024)
@@ -391,11 +401,12 @@ struct BwdDParams {
 // recomputing layers 1-2: 64 of the 324 MFMAs per wave and tile, the layer-1 VALU work, the h1 tile and one of the
 // three barriers disappear, for 512 B per point of (overlapped) HBM reads.  !LOADZ (the bf16 modes, whose pass C
 // computes z2 on other operands): recompute in fp32 as before.
-template <bool LOADZ>
+template <bool LOADZ, int NT>
 __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
     const float *__restrict__ x, int N, const float *__restrict__ trans, TrainChan P, BwdDParams D,
     int T, int S, const f32x4 *__restrict__ z2t, f32x4 *__restrict__ g2t, float *__restrict__ pa,
     float *__restrict__ ps2) {
+    static_assert(NT == 0 || LOADZ, "the bf16 variants read z2 back");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *h2 = smem;                     // [TP][H2S], rows past N zeroed
     float *h1 = h2 + TP * H2S;            // [TP][H1S]
@@ -494,6 +505,58 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
         f32x16 d0, d1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
+        if constexpr (NT > 0) {
+            // --- the three contractions on bf16 / bf16x3 operands: 16 k indices per instruction ---
+            k128_bf<NT>(h2, D.Ax, cb, 0, L, d0);       // d = h2 A
+            k128_bf<NT>(h2, D.Ax, cb, 1, L, d1);
+            {   // sparse term: 16 hits per k-step; lane (j, h) supplies hits e0 + 8h .. 8h+7
+                const float *w3c = D.w3 + c2;
+                auto sparse = [&](const unsigned short *hl, int n, f32x16 &d) {
+#pragma unroll 1
+                    for (int e0 = 0; e0 < n; e0 += 16) {
+                        float av[8], bv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int e = e0 + 8 * L.h + u;
+                            const int v = (e < BWD_D_HITS) ? hl[e] : 0;
+                            const int c = (e < n) ? (v >> 5) : 0;
+                            const float cf = (e < n) ? cfl[c] : 0.f;
+                            bv[u] = w3c[(size_t)c * 128];
+                            av[u] = ((v & 31) == L.j) ? -cf : 0.f;
+                        }
+                        f32x4 ah, al, bh, bl;
+                        bf_pack8<NT>(av, ah, al);
+                        bf_pack8<NT>(bv, bh, bl);
+                        d = bf_mma<NT>(ah, al, bh, bl, d);
+                    }
+                };
+                sparse(hits, nlo, d0);
+                sparse(hits + BWD_D_HITS, nhi, d1);
+            }
+            {   // Gram: both operands are columns of h2 (k = point 16 st + 8h + u)
+                const float *colp = h2 + (8 * L.h) * H2S + L.j;
+                const int o0 = cb * 32, o1 = ((cb + 1) & 3) * 32, o2 = ((cb + 2) & 3) * 32;
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    float av[8], b1[8], b2[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const float *rp = colp + (16 * st + u) * H2S;
+                        av[u] = rp[o0]; b1[u] = rp[o1];
+                        b2[u] = (cb < 2) ? rp[o2] : 0.f;
+                    }
+                    f32x4 ah, al, bh, bl;
+                    bf_pack8<NT>(av, ah, al);
+                    gm0 = bf_mma<NT>(ah, al, ah, al, gm0);
+                    bf_pack8<NT>(b1, bh, bl);
+                    gm1 = bf_mma<NT>(ah, al, bh, bl, gm1);
+                    if (cb < 2) {
+                        bf_pack8<NT>(b2, bh, bl);
+                        gm2 = bf_mma<NT>(ah, al, bh, bl, gm2);
+                    }
+                }
+            }
+        } else {
         {   // d = h2 A (K = 128).  (Explicitly software-pipelined variants of this loop, of the sparse loop and of the
             // Gram loop were measured: no gain, this pass is bound by its phase structure, not by operand latency.)
             const f32x4 *wp = (const f32x4 *)D.Ap + (size_t)(cb * 16) * 64 + L.lane;
@@ -551,6 +614,7 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
                 }
             }
         }
+        }   // NT == 0
         // epilogue: g2 = (cvec - d) masked by ReLU(bn2) and validity; running sums; lane-major hand-off.
         // (Measured: writing this VALU work interleaved with the Gram MFMAs above — two k-steps, one element pair —
         // is SLOWER, 0.96 vs 0.89 ms: the partner wave on the SIMD already fills the MFMA pipe during the epilogue,
@@ -607,14 +671,16 @@ struct BwdEParams {
     const float *a1m, *a2m;       // (128) a1/M, a2/M
     const float *dsc2;            // (128) gamma2/sigma2
     const float *w2tp;            // W2^T as a (64,128) matrix, MFMA_B packed
+    const u16 *w2tx;              // the same matrix as split_pack_bf16 fragments (NT > 0)
 };
 #define BWD_E_LDS_FLOATS (TP * H1S + TP * H2S + 12 * TP)
 
-template <bool LOADZ>   // LOADZ: z2 read back from pass C's z2t instead of recomputing layer 2 (64 of 192 MFMAs per wave and tile)
+template <bool LOADZ, int NT>   // LOADZ: z2 read back from z2t instead of recomputing layer 2 (64 of 192 MFMAs per wave and tile)
 __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
     const float *__restrict__ x, int N, const float *__restrict__ trans, TrainChan P, BwdEParams E,
     int T, int S, const f32x4 *__restrict__ z2t, const f32x4 *__restrict__ g2t, float *__restrict__ pc,
     float *__restrict__ pR, float *__restrict__ pW2) {
+    static_assert(NT == 0 || LOADZ, "the bf16 variants read z2 back");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *h1 = smem;
     float *dz = h1 + TP * H1S;    // [TP][H2S]
@@ -683,7 +749,8 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
             f32x16 acc, unused;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            k128_stream<1>(dz, E.w2tp, cb1, pb1, L, acc, unused);
+            if constexpr (NT == 0) k128_stream<1>(dz, E.w2tp, cb1, pb1, L, acc, unused);
+            else k128_bf<NT>(dz, E.w2tx, cb1, pb1, L, acc);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int pt = pb1 * 32 + mfma_row(r, L.lane);
@@ -698,7 +765,24 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
             }
         }
         // dW2 += dz^T h1 : contraction over the tile's 64 points (rows past N carry dz == 0)
-        {
+        if constexpr (NT > 0) {
+            const float *dzc = dz + (8 * L.h) * H2S + cb * 32 + L.j, *h1c = h1 + (8 * L.h) * H1S + L.j;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                float av[8], b0[8], b1[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    av[u] = dzc[(16 * st + u) * H2S];
+                    b0[u] = h1c[(16 * st + u) * H1S]; b1[u] = h1c[(16 * st + u) * H1S + 32];
+                }
+                f32x4 ah, al, bh, bl;
+                bf_pack8<NT>(av, ah, al);
+                bf_pack8<NT>(b0, bh, bl);
+                pw0 = bf_mma<NT>(ah, al, bh, bl, pw0);
+                bf_pack8<NT>(b1, bh, bl);
+                pw1 = bf_mma<NT>(ah, al, bh, bl, pw1);
+            }
+        } else {
             const float *dzc = dz + L.h * H2S + cb * 32 + L.j, *h1c = h1 + L.h * H1S + L.j;
             float ca[4], c0[4], c1v[4];
 #pragma unroll
@@ -1067,9 +1151,79 @@ __global__ __launch_bounds__(256) void fc_bwd_kernel(const float *__restrict__ g
 // C ABI
 // ---------------------------------------------------------------------------------------
 static TrainChan make_chan(const float *w1, const float *b1, const float *s1c, const float *t1c,
-                           const float *w2p, const float *s2c, const float *t2c) {
+                           const float *w2p, const float *s2c, const float *t2c, const void *w2x = nullptr) {
     TrainChan P; P.w1 = w1; P.b1 = b1; P.s1c = s1c; P.t1c = t1c; P.w2p = w2p; P.s2c = s2c; P.t2c = t2c;
+    P.w2x = (const u16 *)w2x;
     return P;
+}
+
+// nterms: 0 = fp32 (w2p), 1 / 3 = bf16 / bf16x3 (w2x).  One implementation behind the fp32 and the _bf entry points.
+static int bn2_stats_impl(const float *x, int B, int N, const float *trans, const float *w1, const float *b1,
+                          const float *s1c, const float *t1c, const float *w2p, const void *w2x, int nterms, int S,
+                          float *part, float *z2t, void *stream) {
+    if (!x || !w1 || !b1 || !s1c || !t1c || !(nterms ? w2x : (const void *)w2p) || !part || B <= 0 || N <= 0 ||
+        (nterms != 0 && nterms != 1 && nterms != 3))
+        return PNGPD_ERR_INVALID_ARG;
+    const int T = (N + TP - 1) / TP;
+    if (!splits_ok(S, T)) return PNGPD_ERR_INVALID_ARG;
+    TrainChan P = make_chan(w1, b1, s1c, t1c, w2p, nullptr, nullptr, w2x);
+    const size_t lds = (TP * H1S + 3 * TP) * sizeof(float);
+    const dim3 grid((unsigned)B * S);
+    hipStream_t sm = (hipStream_t)stream;
+    if (nterms == 0)
+        hipLaunchKernelGGL(trunk_bn2_stats_kernel<0>, grid, dim3(256), lds, sm, x, N, trans, P, T, S, part, (f32x4 *)z2t);
+    else if (nterms == 1)
+        hipLaunchKernelGGL(trunk_bn2_stats_kernel<1>, grid, dim3(256), lds, sm, x, N, trans, P, T, S, part, (f32x4 *)z2t);
+    else
+        hipLaunchKernelGGL(trunk_bn2_stats_kernel<3>, grid, dim3(256), lds, sm, x, N, trans, P, T, S, part, (f32x4 *)z2t);
+    return pngpd_launch_status();
+}
+
+static int bwd_gather_impl(const float *x, int B, int N, const float *trans, const float *w1, const float *b1,
+                           const float *s1c, const float *t1c, const float *w2p, const void *w2x, int nterms,
+                           const float *s2c, const float *t2c, const int *idx, const float *coef,
+                           int clouds_per_range, float *Gp, void *stream) {
+    if (!x || !w1 || !b1 || !s1c || !t1c || !(nterms ? w2x : (const void *)w2p) || !s2c || !t2c || !idx || !coef ||
+        !Gp || B <= 0 || N <= 0 || clouds_per_range <= 0 || (nterms != 0 && nterms != 1 && nterms != 3))
+        return PNGPD_ERR_INVALID_ARG;
+    const int R = (B + clouds_per_range - 1) / clouds_per_range;
+    TrainChan P = make_chan(w1, b1, s1c, t1c, w2p, s2c, t2c, w2x);
+    const size_t lds = (TP * H1S + TP * H2S + 3 * TP + 64) * sizeof(float);
+    const void *fn = nterms == 0 ? (const void *)trunk_bwd_gather_kernel<0>
+                   : nterms == 1 ? (const void *)trunk_bwd_gather_kernel<1> : (const void *)trunk_bwd_gather_kernel<3>;
+    int st = pngpd_allow_lds(fn, lds);
+    if (st != PNGPD_OK) return st;
+    const dim3 grid((unsigned)R * 16);
+    hipStream_t sm = (hipStream_t)stream;
+    if (nterms == 0)
+        hipLaunchKernelGGL(trunk_bwd_gather_kernel<0>, grid, dim3(256), lds, sm, x, B, N, trans, P, idx, coef, clouds_per_range, Gp);
+    else if (nterms == 1)
+        hipLaunchKernelGGL(trunk_bwd_gather_kernel<1>, grid, dim3(256), lds, sm, x, B, N, trans, P, idx, coef, clouds_per_range, Gp);
+    else
+        hipLaunchKernelGGL(trunk_bwd_gather_kernel<3>, grid, dim3(256), lds, sm, x, B, N, trans, P, idx, coef, clouds_per_range, Gp);
+    return pngpd_launch_status();
+}
+
+template <bool LOADZ, int NT>
+static int launch_bwd_d(dim3 grid, size_t lds, hipStream_t sm, const float *x, int N, const float *trans,
+                        const TrainChan &P, const BwdDParams &D, int T, int S, const float *z2t, float *g2t,
+                        float *pa, float *ps2) {
+    int st = pngpd_allow_lds((const void *)trunk_bwd_d_kernel<LOADZ, NT>, lds);
+    if (st != PNGPD_OK) return st;
+    hipLaunchKernelGGL((trunk_bwd_d_kernel<LOADZ, NT>), grid, dim3(256), lds, sm,
+                       x, N, trans, P, D, T, S, (const f32x4 *)z2t, (f32x4 *)g2t, pa, ps2);
+    return pngpd_launch_status();
+}
+
+template <bool LOADZ, int NT>
+static int launch_bwd_e(dim3 grid, size_t lds, hipStream_t sm, const float *x, int N, const float *trans,
+                        const TrainChan &P, const BwdEParams &E, int T, int S, const float *z2t, const float *g2t,
+                        float *pc, float *pR, float *pW2) {
+    int st = pngpd_allow_lds((const void *)trunk_bwd_e_kernel<LOADZ, NT>, lds);
+    if (st != PNGPD_OK) return st;
+    hipLaunchKernelGGL((trunk_bwd_e_kernel<LOADZ, NT>), grid, dim3(256), lds, sm,
+                       x, N, trans, P, E, T, S, (const f32x4 *)z2t, (const f32x4 *)g2t, pc, pR, pW2);
+    return pngpd_launch_status();
 }
 
 extern "C" {
@@ -1093,14 +1247,14 @@ int pngpd_cloud_moments(const float *x, int B, int N, double *mom, void *stream)
 int pngpd_trunk_bn2_stats(const float *x, int B, int N, const float *trans,
                           const float *w1, const float *b1, const float *s1c, const float *t1c,
                           const float *w2p, int S, float *part, float *z2t, void *stream) {
-    if (!x || !w1 || !b1 || !s1c || !t1c || !w2p || !part || B <= 0 || N <= 0) return PNGPD_ERR_INVALID_ARG;
-    const int T = (N + TP - 1) / TP;
-    if (!splits_ok(S, T)) return PNGPD_ERR_INVALID_ARG;
-    TrainChan P = make_chan(w1, b1, s1c, t1c, w2p, nullptr, nullptr);
-    const size_t lds = (TP * H1S + 3 * TP) * sizeof(float);
-    hipLaunchKernelGGL(trunk_bn2_stats_kernel, dim3((unsigned)B * S), dim3(256), lds, (hipStream_t)stream,
-                       x, N, trans, P, T, S, part, (f32x4 *)z2t);
-    return pngpd_launch_status();
+    return bn2_stats_impl(x, B, N, trans, w1, b1, s1c, t1c, w2p, nullptr, 0, S, part, z2t, stream);
+}
+
+int pngpd_trunk_bn2_stats_bf(const float *x, int B, int N, const float *trans,
+                             const float *w1, const float *b1, const float *s1c, const float *t1c,
+                             const void *w2x, int nterms, int S, float *part, float *z2t, void *stream) {
+    if (nterms != 1 && nterms != 3) return PNGPD_ERR_INVALID_ARG;
+    return bn2_stats_impl(x, B, N, trans, w1, b1, s1c, t1c, nullptr, w2x, nterms, S, part, z2t, stream);
 }
 
 int pngpd_trunk_fwd_train(const float *x, int B, int N, const float *trans,
@@ -1129,17 +1283,17 @@ int pngpd_trunk_bwd_gather(const float *x, int B, int N, const float *trans,
                            const float *w1, const float *b1, const float *s1c, const float *t1c,
                            const float *w2p, const float *s2c, const float *t2c,
                            const int *idx, const float *coef, int clouds_per_range, float *Gp, void *stream) {
-    if (!x || !w1 || !b1 || !s1c || !t1c || !w2p || !s2c || !t2c || !idx || !coef || !Gp || B <= 0 || N <= 0 ||
-        clouds_per_range <= 0)
-        return PNGPD_ERR_INVALID_ARG;
-    const int R = (B + clouds_per_range - 1) / clouds_per_range;
-    TrainChan P = make_chan(w1, b1, s1c, t1c, w2p, s2c, t2c);
-    const size_t lds = (TP * H1S + TP * H2S + 3 * TP + 64) * sizeof(float);
-    int st = pngpd_allow_lds((const void *)trunk_bwd_gather_kernel, lds);
-    if (st != PNGPD_OK) return st;
-    hipLaunchKernelGGL(trunk_bwd_gather_kernel, dim3((unsigned)R * 16), dim3(256), lds, (hipStream_t)stream,
-                       x, B, N, trans, P, idx, coef, clouds_per_range, Gp);
-    return pngpd_launch_status();
+    return bwd_gather_impl(x, B, N, trans, w1, b1, s1c, t1c, w2p, nullptr, 0, s2c, t2c, idx, coef, clouds_per_range,
+                           Gp, stream);
+}
+
+int pngpd_trunk_bwd_gather_bf(const float *x, int B, int N, const float *trans,
+                              const float *w1, const float *b1, const float *s1c, const float *t1c,
+                              const void *w2x, int nterms, const float *s2c, const float *t2c,
+                              const int *idx, const float *coef, int clouds_per_range, float *Gp, void *stream) {
+    if (nterms != 1 && nterms != 3) return PNGPD_ERR_INVALID_ARG;
+    return bwd_gather_impl(x, B, N, trans, w1, b1, s1c, t1c, nullptr, w2x, nterms, s2c, t2c, idx, coef,
+                           clouds_per_range, Gp, stream);
 }
 
 int pngpd_trunk_bwd_d(const float *x, int B, int N, const float *trans,
@@ -1155,17 +1309,30 @@ int pngpd_trunk_bwd_d(const float *x, int B, int N, const float *trans,
     if (!splits_ok(S, T)) return PNGPD_ERR_INVALID_ARG;
     if (N > (1 << 30)) return PNGPD_ERR_UNSUPPORTED;
     TrainChan P = make_chan(w1, b1, s1c, t1c, w2p, s2c, t2c);
-    BwdDParams D; D.is2 = is2; D.nm2 = nm2; D.Ap = Ap; D.cvec = cvec; D.w3 = w3; D.idx = idx; D.coef = coef;
+    BwdDParams D; D.is2 = is2; D.nm2 = nm2; D.Ap = Ap; D.Ax = nullptr; D.cvec = cvec; D.w3 = w3; D.idx = idx; D.coef = coef;
     const size_t lds = BWD_D_LDS_FLOATS * sizeof(float);
-    int st = pngpd_allow_lds(z2t ? (const void *)trunk_bwd_d_kernel<true> : (const void *)trunk_bwd_d_kernel<false>, lds);
-    if (st != PNGPD_OK) return st;
-    if (z2t)
-        hipLaunchKernelGGL(trunk_bwd_d_kernel<true>, dim3((unsigned)B * S), dim3(256), lds, (hipStream_t)stream,
-                           x, N, trans, P, D, T, S, (const f32x4 *)z2t, (f32x4 *)g2t, pa, ps2);
-    else
-        hipLaunchKernelGGL(trunk_bwd_d_kernel<false>, dim3((unsigned)B * S), dim3(256), lds, (hipStream_t)stream,
-                           x, N, trans, P, D, T, S, (const f32x4 *)nullptr, (f32x4 *)g2t, pa, ps2);
-    return pngpd_launch_status();
+    const dim3 grid((unsigned)B * S);
+    return z2t ? launch_bwd_d<true, 0>(grid, lds, (hipStream_t)stream, x, N, trans, P, D, T, S, z2t, g2t, pa, ps2)
+               : launch_bwd_d<false, 0>(grid, lds, (hipStream_t)stream, x, N, trans, P, D, T, S, nullptr, g2t, pa, ps2);
+}
+
+int pngpd_trunk_bwd_d_bf(const float *x, int B, int N, const float *s2c, const float *t2c,
+                         const float *is2, const float *nm2, const void *Ax, int nterms, const float *cvec,
+                         const float *w3, const int *idx, const float *coef, const float *z2t, int S,
+                         float *g2t, float *pa, float *ps2, void *stream) {
+    if (!x || !s2c || !t2c || !is2 || !nm2 || !Ax || !cvec || !w3 || !idx || !coef || !z2t || !g2t || !pa || !ps2 ||
+        B <= 0 || N <= 0 || (nterms != 1 && nterms != 3))
+        return PNGPD_ERR_INVALID_ARG;
+    const int T = (N + TP - 1) / TP;
+    if (!splits_ok(S, T)) return PNGPD_ERR_INVALID_ARG;
+    if (N > (1 << 30)) return PNGPD_ERR_UNSUPPORTED;
+    TrainChan P = make_chan(nullptr, nullptr, nullptr, nullptr, nullptr, s2c, t2c);   // z2 is read back: layers 1-2 unused
+    BwdDParams D; D.is2 = is2; D.nm2 = nm2; D.Ap = nullptr; D.Ax = (const u16 *)Ax; D.cvec = cvec; D.w3 = w3;
+    D.idx = idx; D.coef = coef;
+    const size_t lds = BWD_D_LDS_FLOATS * sizeof(float);
+    const dim3 grid((unsigned)B * S);
+    return nterms == 1 ? launch_bwd_d<true, 1>(grid, lds, (hipStream_t)stream, x, N, nullptr, P, D, T, S, z2t, g2t, pa, ps2)
+                       : launch_bwd_d<true, 3>(grid, lds, (hipStream_t)stream, x, N, nullptr, P, D, T, S, z2t, g2t, pa, ps2);
 }
 
 int pngpd_trunk_bwd_e(const float *x, int B, int N, const float *trans,
@@ -1180,17 +1347,30 @@ int pngpd_trunk_bwd_e(const float *x, int B, int N, const float *trans,
     if (!splits_ok(S, T)) return PNGPD_ERR_INVALID_ARG;
     TrainChan P = make_chan(w1, b1, s1c, t1c, w2p, nullptr, nullptr);
     BwdEParams E; E.is1 = is1; E.nm1 = nm1; E.is2 = is2; E.nm2 = nm2; E.a1m = a1m; E.a2m = a2m; E.dsc2 = dsc2;
-    E.w2tp = w2tp;
+    E.w2tp = w2tp; E.w2tx = nullptr;
     const size_t lds = BWD_E_LDS_FLOATS * sizeof(float);
-    int st = pngpd_allow_lds(z2t ? (const void *)trunk_bwd_e_kernel<true> : (const void *)trunk_bwd_e_kernel<false>, lds);
-    if (st != PNGPD_OK) return st;
-    if (z2t)
-        hipLaunchKernelGGL(trunk_bwd_e_kernel<true>, dim3((unsigned)B * S), dim3(256), lds, (hipStream_t)stream,
-                           x, N, trans, P, E, T, S, (const f32x4 *)z2t, (const f32x4 *)g2t, pc, pR, pW2);
-    else
-        hipLaunchKernelGGL(trunk_bwd_e_kernel<false>, dim3((unsigned)B * S), dim3(256), lds, (hipStream_t)stream,
-                           x, N, trans, P, E, T, S, (const f32x4 *)nullptr, (const f32x4 *)g2t, pc, pR, pW2);
-    return pngpd_launch_status();
+    const dim3 grid((unsigned)B * S);
+    return z2t ? launch_bwd_e<true, 0>(grid, lds, (hipStream_t)stream, x, N, trans, P, E, T, S, z2t, g2t, pc, pR, pW2)
+               : launch_bwd_e<false, 0>(grid, lds, (hipStream_t)stream, x, N, trans, P, E, T, S, nullptr, g2t, pc, pR, pW2);
+}
+
+int pngpd_trunk_bwd_e_bf(const float *x, int B, int N, const float *trans,
+                         const float *w1, const float *b1, const float *s1c, const float *t1c,
+                         const float *is1, const float *nm1, const float *is2, const float *nm2,
+                         const float *a1m, const float *a2m, const float *dsc2, const void *w2tx, int nterms,
+                         const float *z2t, const float *g2t, int S, float *pc, float *pR, float *pW2, void *stream) {
+    if (!x || !w1 || !b1 || !s1c || !t1c || !is1 || !nm1 || !is2 || !nm2 || !a1m || !a2m || !dsc2 || !w2tx || !z2t ||
+        !g2t || !pc || !pR || !pW2 || B <= 0 || N <= 0 || (nterms != 1 && nterms != 3))
+        return PNGPD_ERR_INVALID_ARG;
+    const int T = (N + TP - 1) / TP;
+    if (!splits_ok(S, T)) return PNGPD_ERR_INVALID_ARG;
+    TrainChan P = make_chan(w1, b1, s1c, t1c, nullptr, nullptr, nullptr);
+    BwdEParams E; E.is1 = is1; E.nm1 = nm1; E.is2 = is2; E.nm2 = nm2; E.a1m = a1m; E.a2m = a2m; E.dsc2 = dsc2;
+    E.w2tp = nullptr; E.w2tx = (const u16 *)w2tx;
+    const size_t lds = BWD_E_LDS_FLOATS * sizeof(float);
+    const dim3 grid((unsigned)B * S);
+    return nterms == 1 ? launch_bwd_e<true, 1>(grid, lds, (hipStream_t)stream, x, N, trans, P, E, T, S, z2t, g2t, pc, pR, pW2)
+                       : launch_bwd_e<true, 3>(grid, lds, (hipStream_t)stream, x, N, trans, P, E, T, S, z2t, g2t, pc, pR, pW2);
 }
 
 int pngpd_fc_bwd(const float *g, const float *x, const float *W, int B, int K, int Nout,

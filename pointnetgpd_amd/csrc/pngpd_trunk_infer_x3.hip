@@ -10,28 +10,12 @@
 // One workgroup = 512 threads = 8 waves (2 per SIMD), one cloud, tiles of 128 points.
 //   LDS: h1 hi/lo [128][72] bf16, h2 hi/lo [128][136] bf16 (+8 halfword row pad: conflict-free
 //   ds_read_b128), xs [3][128] f32, running max [1024] f32  ->  ~112 KB, one workgroup per CU.
-#include "pngpd_common.h"
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned short u16;
+#include "pngpd_bf.h"
 
 #define XP 128          // points per tile
 #define X1S 72          // h1 row stride (halfwords)
 #define X2S 136         // h2 row stride (halfwords)
 #define X3_LDS_BYTES (2 * XP * X1S * 2 + 2 * XP * X2S * 2 + 3 * XP * 4 + 1024 * 4)
-
-__device__ __forceinline__ u16 bf16_bits(float x) { return __builtin_bit_cast(u16, (__bf16)x); }
-__device__ __forceinline__ float bf16_val(u16 b) { return __uint_as_float(((unsigned)b) << 16); }
-
-__device__ __forceinline__ void split2(float x, u16 &hi, u16 &lo) {
-    hi = bf16_bits(x);
-    lo = bf16_bits(x - bf16_val(hi));
-}
-
-__device__ __forceinline__ f32x16 mfma_bf(const f32x4 &a, const f32x4 &b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
-                                                   c, 0, 0, 0);
-}
 
 // (C,K) fp32 row-major -> hi/lo bf16 in 32x32x16 B-fragment order:
 //   out[(((cb*KS + ks)*2 + part)*64 + lane)*8 + t] = part(W[cb*32 + (lane&31)][ks*16 + (lane>>5)*8 + t])

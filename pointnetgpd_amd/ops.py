@@ -228,6 +228,16 @@ def trunk_bn2_stats(x, trans, w1, b1, s1c, t1c, w2p, S, store_z2=True):
     return part, z2t
 
 
+def trunk_bn2_stats_bf(x, trans, w1, b1, s1c, t1c, w2x, S, nterms, store_z2=True):
+    """Pass B with layer 2 on bf16 (nterms 1) / bf16x3 (3) operands; w2x = split_pack_bf16(W2)."""
+    B, _, N = x.shape
+    part = torch.empty(B * S, 128, 2, device=x.device, dtype=torch.float32)
+    z2t = torch.empty(_lib.load().pngpd_trunk_g2t_bytes(B, N) // 4, device=x.device, dtype=torch.float32) \
+        if store_z2 else None
+    _call("pngpd_trunk_bn2_stats_bf", x, x, B, N, trans, w1, b1, s1c, t1c, w2x, int(nterms), int(S), part, z2t)
+    return part, z2t
+
+
 def trunk_fwd_train(x, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, w3sp, S, z2t=None):
     """-> pmax (B,S,1024), parg, psum (B*S,2,1024), psh (B*S,128).  z2t: pass B's stored z2 (read back instead of
     recomputing layers 1-2) or None."""
@@ -255,15 +265,55 @@ def trunk_fwd_train_bf(x, trans, w1, b1, s1c, t1c, w2x, s2c, t2c, w3sx, S, nterm
     return pmax, parg, psum, psh, S
 
 
-def trunk_bwd_gather(x, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, idx, coef, clouds_per_range=None):
-    B, _, N = x.shape
+def _gather_ranges(B, clouds_per_range):
     if clouds_per_range is None:      # 16 workgroups per range: ~256 workgroups at small B, 16 clouds per range at large B
         clouds_per_range = max(1, min(16, B // 16))
-    R = (B + clouds_per_range - 1) // clouds_per_range
+    return int(clouds_per_range), (B + clouds_per_range - 1) // clouds_per_range
+
+
+def trunk_bwd_gather(x, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, idx, coef, clouds_per_range=None):
+    B, _, N = x.shape
+    clouds_per_range, R = _gather_ranges(B, clouds_per_range)
     Gp = torch.empty(R, 1024, 128, device=x.device, dtype=torch.float32)
     _call("pngpd_trunk_bwd_gather", x, x, B, N, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, idx, coef,
           int(clouds_per_range), Gp)
     return Gp
+
+
+def trunk_bwd_gather_bf(x, trans, w1, b1, s1c, t1c, w2x, s2c, t2c, idx, coef, nterms, clouds_per_range=None):
+    B, _, N = x.shape
+    cpr, R = _gather_ranges(B, clouds_per_range)
+    Gp = torch.empty(R, 1024, 128, device=x.device, dtype=torch.float32)
+    _call("pngpd_trunk_bwd_gather_bf", x, x, B, N, trans, w1, b1, s1c, t1c, w2x, int(nterms), s2c, t2c, idx, coef,
+          cpr, Gp)
+    return Gp
+
+
+def unpack_mfma_b_128(Ap):
+    """pngpd_a_cvec_finalize's MFMA_B-packed 128x128 matrix -> row-major (128,128)."""
+    return Ap.view(4, 16, 2, 32, 4).permute(0, 3, 1, 2, 4).reshape(128, 128)
+
+
+def trunk_bwd_d_bf(x, s2c, t2c, is2, nm2, Ax, cvec, w3, idx, coef, S, z2t, nterms):
+    """Pass D on bf16 / bf16x3 operands; Ax = split_pack_bf16 of the (symmetric) matrix A; z2t required."""
+    B, _, N = x.shape
+    g2t = torch.empty(_lib.load().pngpd_trunk_g2t_bytes(B, N) // 4, device=x.device, dtype=torch.float32)
+    pa = torch.empty(B * S, 128, 2, device=x.device, dtype=torch.float32)
+    ps2 = torch.empty(B * S, 12 * 1024, device=x.device, dtype=torch.float32)
+    _call("pngpd_trunk_bwd_d_bf", x, x, B, N, s2c, t2c, is2, nm2, Ax, int(nterms), cvec, w3, idx, coef, z2t, int(S),
+          g2t, pa, ps2)
+    return g2t, pa, ps2
+
+
+def trunk_bwd_e_bf(x, trans, w1, b1, s1c, t1c, is1, nm1, is2, nm2, a1m, a2m, dsc2, w2tx, g2t, S, z2t, nterms):
+    """Pass E on bf16 / bf16x3 operands; w2tx = split_pack_bf16(W2^T as (64,128)); z2t required."""
+    B, _, N = x.shape
+    pc = torch.empty(B * S, 64, 2, device=x.device, dtype=torch.float32)
+    pR = torch.empty(B, S, 64, 3, device=x.device, dtype=torch.float32)
+    pW2 = torch.empty(B * S, 128, 64, device=x.device, dtype=torch.float32)
+    _call("pngpd_trunk_bwd_e_bf", x, x, B, N, trans, w1, b1, s1c, t1c, is1, nm1, is2, nm2, a1m, a2m, dsc2, w2tx,
+          int(nterms), z2t, g2t, int(S), pc, pR, pW2)
+    return pc, pR, pW2
 
 
 def trunk_bwd_d(x, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, is2, nm2, Ap, cvec, w3, idx, coef, S, z2t=None):

@@ -18,20 +18,26 @@ from . import ops
 from .ops import _call
 
 F64 = torch.float64
-# Arithmetic of the main forward pass (pass C, 60 % of a step's matrix FLOPs): "fp32" exact; "bf16x3" opt-in 3-term
-# split-bf16 products (same parity bars as fp32); "bf16" opt-in plain bf16 operands (BASELINE configs[2]; errors
-# measured in tests/test_gpu_bf16.py).  BatchNorm statistics, the closed-form backward and every accumulator stay
-# fp32/fp64 in all modes; the backward passes D/E contract over POINTS and would need transposed bf16 tiles — they
-# run fp32.
+# Arithmetic of the trunk's matrix contractions: "fp32" exact (default); "bf16x3" opt-in 3-term split-bf16 products
+# (same parity bars as fp32); "bf16" opt-in plain bf16 operands (BASELINE configs[2]; errors measured in
+# tests/test_gpu_bf16.py).  In the two opt-in modes EVERY pass contracts on the bf16 matrix cores — pass C
+# (trunk_fwd_train_x3_kernel) and the side passes B / gather / D / E (the NT variants of the fp32 kernels: fp32 LDS
+# tiles, operands converted when they are read).  ``fp32_side_passes=True`` keeps B / gather / D / E on the exact
+# fp32 kernels (round 2's first bf16 mode).  BatchNorm statistics, masks, every accumulator and the parameter-sized
+# algebra between the passes stay fp32 / fp64 in all modes.
 _TRAIN_PRECISION = "fp32"
+_FP32_SIDE_PASSES = False
 _NTERMS = {"bf16x3": 3, "bf16": 1}
 
 
-def set_train_precision(mode):
-    global _TRAIN_PRECISION
+def set_train_precision(mode, fp32_side_passes=False):
+    global _TRAIN_PRECISION, _FP32_SIDE_PASSES
     if mode not in ("fp32", "bf16x3", "bf16"):
         raise ValueError("precision must be 'fp32', 'bf16x3' or 'bf16'")
     _TRAIN_PRECISION = mode
+    _FP32_SIDE_PASSES = bool(fp32_side_passes)
+
+
 DEBUG_STASH = None   # set to a dict to capture backward intermediates (tests/test_gpu_train.py::test_trunk_backward_intermediates)
 
 
@@ -90,8 +96,15 @@ class TrunkTrainFn(torch.autograd.Function):
         w2p = ops.pack_mfma_b(w2)
         # z2 = W2 h1 is computed once, here, and handed to passes C / D / E (512 B per point): in the fp32 mode always
         # (pass C reads it), in the bf16 modes (whose pass C computes layer 2 on other operands) only for a backward
-        part, z2t = ops.trunk_bn2_stats(x, T, w1, b1c, s1c, t1c, w2p, S,
-                                        store_z2=_TRAIN_PRECISION == "fp32" or any(ctx.needs_input_grad))
+        nt = 0 if _TRAIN_PRECISION == "fp32" else _NTERMS[_TRAIN_PRECISION]
+        nt_side = 0 if _FP32_SIDE_PASSES else nt      # arithmetic of passes B / gather / D / E
+        w2x = ops.split_pack_bf16(w2) if nt else None
+        if nt_side:
+            part, z2t = ops.trunk_bn2_stats_bf(x, T, w1, b1c, s1c, t1c, w2x, S, nt_side,
+                                               store_z2=any(ctx.needs_input_grad))
+        else:
+            part, z2t = ops.trunk_bn2_stats(x, T, w1, b1c, s1c, t1c, w2p, S,
+                                            store_z2=nt == 0 or any(ctx.needs_input_grad))
         chan2, stats2 = _e(dev, 4, 128), _e(dev, 256, dtype=F64)
         rm, rv, nbt = _bufs3(bufs2)
         tot2 = _reduce(part, 1, blk, 256)
@@ -104,9 +117,8 @@ class TrunkTrainFn(torch.autograd.Function):
         Sc = S
         if _TRAIN_PRECISION != "fp32":
             w3s = (w3 * sgn[:, None]).contiguous()
-            pmax, parg, psum, psh, Sc = ops.trunk_fwd_train_bf(x, T, w1, b1c, s1c, t1c, ops.split_pack_bf16(w2), s2c,
-                                                               t2c, ops.split_pack_bf16(w3s), S,
-                                                               nterms=_NTERMS[_TRAIN_PRECISION])
+            pmax, parg, psum, psh, Sc = ops.trunk_fwd_train_bf(x, T, w1, b1c, s1c, t1c, w2x, s2c,
+                                                               t2c, ops.split_pack_bf16(w3s), S, nterms=nt)
         else:
             w3sp = ops.pack_mfma_b(w3, scale=sgn)
             pmax, parg, psum, psh = ops.trunk_fwd_train(x, T, w1, b1c, s1c, t1c, w2p, s2c, t2c, w3sp, S, z2t)
@@ -121,6 +133,7 @@ class TrunkTrainFn(torch.autograd.Function):
               idx, zhat)
         ctx.relu_last, ctx.eps, ctx.has_t, ctx.S = relu_last, eps, T is not None, S
         ctx.z2t = z2t          # a plain workspace buffer, not part of the autograd graph
+        ctx.nt_side, ctx.w2x = nt_side, w2x
         ctx.save_for_backward(x, T if T is not None else x.new_empty(0), w1, b1c, g1c, w2, g2c, w3, g3c, mom,
                               chan1, stats1, chan2, stats2, stats3, pooled, idx, zhat, w2p, sh)
         return pooled
@@ -144,18 +157,29 @@ class TrunkTrainFn(torch.autograd.Function):
         Ap, cvec = _e(dev, 128 * 128), _e(dev, 128)
         _call("pngpd_a_cvec_finalize", x, sh, B, N, w3, g3c, stats3, m12, eps, Ap, cvec)
         # ---- arg-extremum gather (sparse term of dW3) and pass D (g2, its BN2 sums, and the Gram of h2)
-        Gp = ops.trunk_bwd_gather(x, T, w1, b1c, s1c, t1c, w2p, s2c, t2c, idx, coef)
-        z2t = ctx.z2t
-        g2t, pa, ps2 = ops.trunk_bwd_d(x, T, w1, b1c, s1c, t1c, w2p, s2c, t2c, is2, nm2, Ap, cvec, w3, idx, coef, S, z2t)
+        z2t, nt = ctx.z2t, ctx.nt_side
+        if nt:
+            Gp = ops.trunk_bwd_gather_bf(x, T, w1, b1c, s1c, t1c, ctx.w2x, s2c, t2c, idx, coef, nt)
+            Ax = ops.split_pack_bf16(ops.unpack_mfma_b_128(Ap).contiguous())
+            g2t, pa, ps2 = ops.trunk_bwd_d_bf(x, s2c, t2c, is2, nm2, Ax, cvec, w3, idx, coef, S, z2t, nt)
+        else:
+            Gp = ops.trunk_bwd_gather(x, T, w1, b1c, s1c, t1c, w2p, s2c, t2c, idx, coef)
+            g2t, pa, ps2 = ops.trunk_bwd_d(x, T, w1, b1c, s1c, t1c, w2p, s2c, t2c, is2, nm2, Ap, cvec, w3, idx, coef,
+                                           S, z2t)
         G, a12, S2c = ops.reduce4((Gp, 1, Gp.shape[0], 1024 * 128), (pa, 1, blk, 256), (ps2, 1, blk, 12 * 1024))
         dW3 = _e(dev, 1024, 128)
         _call("pngpd_dw3_finalize", x, G, S2c, sh, B, N, w3, g3c, stats3, m12, eps, dW3)
         dg2, dbe2, evec = _e(dev, 128), _e(dev, 128), _e(dev, 3, 128)
         _call("pngpd_bwd_e_prep", x, a12, B, N, g2c, stats2, eps, dg2, dbe2, evec)
         # ---- pass E (also contracts dW2 = sum_points dz2 h1^T on the MFMA)
-        w2tp = ops.pack_mfma_b(w2.t().contiguous())
-        pc, pR, pW2 = ops.trunk_bwd_e(x, T, w1, b1c, s1c, t1c, w2p, is1, nm1, is2, nm2, evec[0], evec[1], evec[2],
-                                      w2tp, g2t, S, z2t)
+        if nt:
+            w2tx = ops.split_pack_bf16(w2.t().contiguous())
+            pc, pR, pW2 = ops.trunk_bwd_e_bf(x, T, w1, b1c, s1c, t1c, is1, nm1, is2, nm2, evec[0], evec[1], evec[2],
+                                             w2tx, g2t, S, z2t, nt)
+        else:
+            w2tp = ops.pack_mfma_b(w2.t().contiguous())
+            pc, pR, pW2 = ops.trunk_bwd_e(x, T, w1, b1c, s1c, t1c, w2p, is1, nm1, is2, nm2, evec[0], evec[1], evec[2],
+                                          w2tp, g2t, S, z2t)
         dW2_64, c12, Rb = ops.reduce4((pW2, 1, blk, 128 * 64), (pc, 1, blk, 128), (pR, B, S, 192))
         dW2 = dW2_64[0].to(torch.float32)
         dW1, dg1, dbe1 = _e(dev, 64, 3), _e(dev, 64), _e(dev, 64)
