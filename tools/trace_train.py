@@ -8,6 +8,9 @@ import torch.nn.functional as F
 import bench
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+prec = sys.argv[2] if len(sys.argv) > 2 else "fp32"      # fp32 | bf16x3 | bf16
+from pointnetgpd_amd import train as _train
+_train.set_train_precision(prec)
 dev = torch.device("cuda:0")
 B, N, k = 1024, 1024, 2
 m = bench.build_model(N, k, dev).train()
@@ -20,4 +23,4 @@ for _ in range(steps):
     F.nll_loss(lp, y).backward()
     opt.step()
 torch.cuda.synchronize()
-print("steps", steps)
+print("steps", steps, prec)
