@@ -43,8 +43,8 @@ __global__ void fold_conv_bn_kernel(const float *__restrict__ W, const float *__
 // with v_mfma_f32_32x32x2_f32; A (samples) and B (weight rows) fragments are float4 loads
 // straight from global (both operands are small and L2-resident).
 // ---------------------------------------------------------------------------------------
-// KSPLIT (small batches, latency path): the workgroup owns ONE 32-column block and its four waves each
-// contract a quarter of K (the K = 1024 MFMA chain of one wave is 14 us long); partial tiles meet in LDS.
+// KSPLIT (up to 2048 output tiles): the workgroup owns ONE 32x32 tile and its four waves each contract a quarter of K
+// (the K = 1024 MFMA chain of one wave is 14 us long); partial tiles meet in LDS.
 template <bool KSPLIT>
 __global__ __launch_bounds__(256) void fc_kernel(const float *__restrict__ in, int B, int K,
                                                  const float *__restrict__ W, const float *__restrict__ bias,
@@ -156,7 +156,11 @@ int pngpd_fc_fwd(const float *in, int B, int K, const float *W, const float *bia
     if (epilogue < PNGPD_EPI_NONE || epilogue > PNGPD_EPI_LOG_SOFTMAX) return PNGPD_ERR_INVALID_ARG;
     if (epilogue == PNGPD_EPI_ADD_IDEN3 && Nout != 9) return PNGPD_ERR_INVALID_ARG;
     if (epilogue == PNGPD_EPI_LOG_SOFTMAX && Nout > 32) return PNGPD_ERR_INVALID_ARG;
-    if (B <= 64 && (K & 31) == 0) {   // latency path: few row blocks, split K over the workgroup's waves
+    // Few output tiles (the FC stacks of this model up to B ~ 4096: 512 tiles for 1024x512): one tile per WORKGROUP, K
+    // split over its four waves — 4x the workgroups and a quarter of the dependent-MFMA chain per wave.  (One tile per
+    // wave left half the CUs idle at B = 1024: 27 us per layer.)  Many tiles: one tile per wave, no LDS round trip.
+    const long tiles = (long)((B + 31) / 32) * ((Nout + 31) / 32);
+    if (tiles <= 2048 && (K & 31) == 0) {
         dim3 grid((B + 31) / 32, (Nout + 31) / 32);
         hipLaunchKernelGGL(fc_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, in, B, K, W, bias, Nout,
                            epilogue, out);
