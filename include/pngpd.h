@@ -120,11 +120,12 @@ int pngpd_trunk_fwd_infer_bf(const void *x, int x_is_bf16, int B, int N, const f
 /* the same arithmetic for pass C of the training path (pngpd_trunk_fwd_train below): identical outputs/semantics.
  * w2x = split_pack_bf16(raw W2), w3sx = split_pack_bf16(sign(gamma3)*W3).  S = workgroups per cloud
  * (1 <= S <= ceil(N/128)); pmax/parg (B*S,1024), psum (B*S,2,1024), psh (B*S*2,128).  BatchNorm statistics and every
- * accumulator stay fp32/fp64.                                                                                  */
+ * accumulator stay fp32/fp64.  z2t: pass B's stored z2 (pngpd_trunk_bn2_stats[_bf]) — read back instead of
+ * recomputing layers 1-2 — or NULL.                                                                             */
 int pngpd_trunk_fwd_train_bf(const float *x, int B, int N, const float *trans,
                              const float *w1, const float *b1, const float *s1c, const float *t1c,
                              const void *w2x, const float *s2c, const float *t2c, const void *w3sx, int nterms, int S,
-                             float *pmax, int *parg, float *psum, float *psh, void *stream);
+                             float *pmax, int *parg, float *psum, float *psh, const float *z2t, void *stream);
 
 /* =======================================================================================
  * Training path (batch-statistics BatchNorm, backward).  The trunk's forward/backward is a

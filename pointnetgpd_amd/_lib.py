@@ -34,7 +34,7 @@ SIGNATURES = {
     "pngpd_trunk_fwd_infer_bf": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p] + [c_f32p] * 6 +
                                  [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, c_void, ctypes.c_size_t, c_void]),
     "pngpd_trunk_fwd_train_bf": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 9 +
-                                 [ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_void]),
+                                 [ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_void]),
     # ---- training passes (S = workgroups per cloud is an explicit argument everywhere)
     "pngpd_trunk_splits": (ctypes.c_int, [ctypes.c_int] * 3),
     "pngpd_trunk_g2t_bytes": (ctypes.c_size_t, [ctypes.c_int] * 2),

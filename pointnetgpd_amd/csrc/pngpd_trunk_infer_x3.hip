@@ -224,21 +224,30 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
 // w2x / w3x = split_pack_bf16 of the RAW (128,64) / sign-folded (1024,128) weights.
 // ---------------------------------------------------------------------------------------
 #define X3T_LDS_BYTES (X3_LDS_BYTES + 3 * 1024 * 4)
+#define X3TZ_LDS_BYTES (2 * XP * X2S * 2 + 4 * 1024 * 4)     // LOADZ: no h1 tiles, no staged points
 
-template <int NT>
+// LOADZ: z2 = W2 h1 was stored by pass B (z2t, the lane-major 64-point tiles of pngpd_train.hip) and is read back —
+// no points, no layer 1 (and none of its 96 wave-uniform constants, which used to cost 195 spilled SGPRs), no layer-2
+// MFMAs, no h1 tiles, two barriers per tile instead of three.  A 128-point tile here is two consecutive 64-point tiles
+// there, and the lane ownership is the same: thread (sub-tile tid >> 8, t = tid & 255) of this kernel holds exactly
+// the 32 values thread t of pass B wrote.  T64 = ceil(N / 64): when it is odd the last tile's second half does not
+// exist in z2t; the first half is read twice (duplicates of real points: masked out of the sums by n < N, never a
+// new maximum, and a tie is resolved towards the smaller row).
+template <int NT, bool LOADZ>
 __global__ __launch_bounds__(512, 2) void trunk_fwd_train_x3_kernel(
     const float *__restrict__ x, int N, const float *__restrict__ trans,
     const float *__restrict__ w1, const float *__restrict__ b1, const float *__restrict__ s1c,
     const float *__restrict__ t1c, const u16 *__restrict__ w2x, const float *__restrict__ s2c,
     const float *__restrict__ t2c, const u16 *__restrict__ w3x, int T, int S,
-    float *__restrict__ pmax, int *__restrict__ parg, float *__restrict__ psum, float *__restrict__ psh) {
+    float *__restrict__ pmax, int *__restrict__ parg, float *__restrict__ psum, float *__restrict__ psh,
+    const f32x4 *__restrict__ z2t, int T64) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16 *h1h = (u16 *)smem_raw;
     u16 *h1l = h1h + XP * X1S;
-    u16 *h2h = h1l + XP * X1S;
+    u16 *h2h = LOADZ ? (u16 *)smem_raw : h1l + XP * X1S;
     u16 *h2l = h2h + XP * X2S;
     float *xs = (float *)(h2l + XP * X2S);
-    float *rm = xs + 3 * XP;
+    float *rm = LOADZ ? xs : xs + 3 * XP;
     float hsum = 0.f;   // sum of h2[.][(wave&3)*32 + j] over this wave's valid rows
     int *ri = (int *)(rm + 1024);
     float *ss = (float *)(ri + 1024);
@@ -258,9 +267,21 @@ __global__ __launch_bounds__(512, 2) void trunk_fwd_train_x3_kernel(
     }
     for (int i = tid; i < 1024; i += 512) { rm[i] = -INFINITY; ri[i] = 0; ss[i] = 0.f; sq[i] = 0.f; }
     f32x4 wah[8], wal[8];
+    f32x4 zq[8];
+    auto fetch_z = [&](int tile) {
+        int t64 = 2 * tile + (tid >> 8);
+        t64 = t64 < T64 ? t64 : 2 * tile;
+        const f32x4 *zt = z2t + ((size_t)(b * T64 + t64) * 8) * 256 + (tid & 255);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) zq[i] = zt[(size_t)i * 256];
+    };
+    if (LOADZ) fetch_z(t0);
 
     for (int tile = t0; tile < t1; ++tile) {
         const int nbase = tile * XP;
+        if (LOADZ) {
+            if (tile > t0) __syncthreads();   // every wave is done reading the previous tile's h2
+        } else {
         if (tid < XP) {
             int n = nbase + tid; n = n < N ? n : N - 1;
             float x0 = xb[n], x1 = xb[N + n], x2 = xb[2 * N + n];
@@ -297,11 +318,17 @@ __global__ __launch_bounds__(512, 2) void trunk_fwd_train_x3_kernel(
             }
         }
         __syncthreads();
+        }   // !LOADZ
         {
             const int cb = wave & 3, pb0 = (wave >> 2) * 2;
+            f32x16 a0 = {0}, a1 = {0};
+            if (LOADZ) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { a0[r] = zq[r >> 2][r & 3]; a1[r] = zq[4 + (r >> 2)][r & 3]; }
+                if (tile + 1 < t1) fetch_z(tile + 1);   // in flight during this tile's layer 3
+            } else {
             f32x4 w2h[4], w2l[4];
             load_wx<4, NT>(w2h, w2l, w2x, cb, lane);
-            f32x16 a0 = {0}, a1 = {0};
             const int r0 = (pb0 * 32 + j) * X1S + h * 8, r1 = ((pb0 + 1) * 32 + j) * X1S + h * 8;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -313,6 +340,7 @@ __global__ __launch_bounds__(512, 2) void trunk_fwd_train_x3_kernel(
                     a0 = mfma_bf(al0, w2h[ks], a0); a1 = mfma_bf(al1, w2h[ks], a1);
                 }
             }
+            }   // !LOADZ
             const float sc = s2c[cb * 32 + j], sh = t2c[cb * 32 + j];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -440,15 +468,17 @@ static int launch_infer_bf(const void *x, int B, int N, const float *trans, cons
     return pngpd_launch_status();
 }
 
-template <int NT>
+template <int NT, bool LOADZ>
 static int launch_train_bf(const float *x, int B, int N, const float *trans, const float *w1, const float *b1,
                            const float *s1c, const float *t1c, const u16 *w2x, const float *s2c, const float *t2c,
                            const u16 *w3sx, int T, int S, float *pmax, int *parg, float *psum, float *psh,
-                           hipStream_t stream) {
-    int st = pngpd_allow_lds((const void *)trunk_fwd_train_x3_kernel<NT>, X3T_LDS_BYTES);
+                           const float *z2t, hipStream_t stream) {
+    const size_t lds = LOADZ ? X3TZ_LDS_BYTES : X3T_LDS_BYTES;
+    int st = pngpd_allow_lds((const void *)trunk_fwd_train_x3_kernel<NT, LOADZ>, lds);
     if (st != PNGPD_OK) return st;
-    hipLaunchKernelGGL((trunk_fwd_train_x3_kernel<NT>), dim3((unsigned)B * S), dim3(512), X3T_LDS_BYTES, stream,
-                       x, N, trans, w1, b1, s1c, t1c, w2x, s2c, t2c, w3sx, T, S, pmax, parg, psum, psh);
+    hipLaunchKernelGGL((trunk_fwd_train_x3_kernel<NT, LOADZ>), dim3((unsigned)B * S), dim3(512), lds, stream,
+                       x, N, trans, w1, b1, s1c, t1c, w2x, s2c, t2c, w3sx, T, S, pmax, parg, psum, psh,
+                       (const f32x4 *)z2t, (N + 63) / 64);
     return pngpd_launch_status();
 }
 
@@ -503,17 +533,21 @@ int pngpd_trunk_fwd_infer_bf(const void *x, int x_is_bf16, int B, int N, const f
 int pngpd_trunk_fwd_train_bf(const float *x, int B, int N, const float *trans,
                              const float *w1, const float *b1, const float *s1c, const float *t1c,
                              const void *w2x, const float *s2c, const float *t2c, const void *w3sx, int nterms, int S,
-                             float *pmax, int *parg, float *psum, float *psh, void *stream) {
+                             float *pmax, int *parg, float *psum, float *psh, const float *z2t, void *stream) {
     if (!x || !w1 || !b1 || !s1c || !t1c || !w2x || !s2c || !t2c || !w3sx || !pmax || !parg || !psum || !psh ||
         B <= 0 || N <= 0 || (nterms != 1 && nterms != 3))
         return PNGPD_ERR_INVALID_ARG;
     const int T = (N + XP - 1) / XP;
     if (S < 1 || S > T) return PNGPD_ERR_INVALID_ARG;   // S: the split count the caller sized pmax/parg/psum for
+    const u16 *w2 = (const u16 *)w2x, *w3 = (const u16 *)w3sx;
+    hipStream_t sm = (hipStream_t)stream;
+    if (z2t)
+        return nterms == 3
+            ? launch_train_bf<3, true>(x, B, N, trans, w1, b1, s1c, t1c, w2, s2c, t2c, w3, T, S, pmax, parg, psum, psh, z2t, sm)
+            : launch_train_bf<1, true>(x, B, N, trans, w1, b1, s1c, t1c, w2, s2c, t2c, w3, T, S, pmax, parg, psum, psh, z2t, sm);
     return nterms == 3
-        ? launch_train_bf<3>(x, B, N, trans, w1, b1, s1c, t1c, (const u16 *)w2x, s2c, t2c, (const u16 *)w3sx, T, S,
-                             pmax, parg, psum, psh, (hipStream_t)stream)
-        : launch_train_bf<1>(x, B, N, trans, w1, b1, s1c, t1c, (const u16 *)w2x, s2c, t2c, (const u16 *)w3sx, T, S,
-                             pmax, parg, psum, psh, (hipStream_t)stream);
+        ? launch_train_bf<3, false>(x, B, N, trans, w1, b1, s1c, t1c, w2, s2c, t2c, w3, T, S, pmax, parg, psum, psh, nullptr, sm)
+        : launch_train_bf<1, false>(x, B, N, trans, w1, b1, s1c, t1c, w2, s2c, t2c, w3, T, S, pmax, parg, psum, psh, nullptr, sm);
 }
 
 }  // extern "C"

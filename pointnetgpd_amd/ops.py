@@ -251,9 +251,10 @@ def trunk_fwd_train(x, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, w3sp, S, z2t=None
     return pmax, parg, psum, psh
 
 
-def trunk_fwd_train_bf(x, trans, w1, b1, s1c, t1c, w2x, s2c, t2c, w3sx, S, nterms=3):
+def trunk_fwd_train_bf(x, trans, w1, b1, s1c, t1c, w2x, s2c, t2c, w3sx, S, nterms=3, z2t=None):
     """bf16 matrix-core variant of trunk_fwd_train (nterms 3 = bf16x3, 1 = plain bf16); returns (pmax (B,Sx,1024),
-    parg, psum (B*Sx,2,1024), psh (B*Sx*2,128), Sx) with Sx = min(S, ceil(N/128)) (128-point tiles)."""
+    parg, psum (B*Sx,2,1024), psh (B*Sx*2,128), Sx) with Sx = min(S, ceil(N/128)) (128-point tiles).  z2t: pass B's
+    stored z2, read back instead of recomputing layers 1-2, or None."""
     B, _, N = x.shape
     S = max(1, min(int(S), (N + 127) // 128))
     pmax = torch.empty(B, S, 1024, device=x.device, dtype=torch.float32)
@@ -261,7 +262,7 @@ def trunk_fwd_train_bf(x, trans, w1, b1, s1c, t1c, w2x, s2c, t2c, w3sx, S, nterm
     psum = torch.empty(B * S, 2, 1024, device=x.device, dtype=torch.float32)
     psh = torch.empty(B * S * 2, 128, device=x.device, dtype=torch.float32)
     _call("pngpd_trunk_fwd_train_bf", x, x, B, N, trans, w1, b1, s1c, t1c, w2x, s2c, t2c, w3sx, int(nterms), int(S),
-          pmax, parg, psum, psh)
+          pmax, parg, psum, psh, z2t)
     return pmax, parg, psum, psh, S
 
 

@@ -100,8 +100,10 @@ class TrunkTrainFn(torch.autograd.Function):
         nt_side = 0 if _FP32_SIDE_PASSES else nt      # arithmetic of passes B / gather / D / E
         w2x = ops.split_pack_bf16(w2) if nt else None
         if nt_side:
+            # bf16x3: pass C reads z2 back (measured 4.80 -> 4.77 ms at B=N=1024; with plain bf16 the 0.5 GB read costs
+            # more than the layers it saves, 3.60 -> 3.69 ms, so that mode recomputes and stores z2 only for a backward)
             part, z2t = ops.trunk_bn2_stats_bf(x, T, w1, b1c, s1c, t1c, w2x, S, nt_side,
-                                               store_z2=any(ctx.needs_input_grad))
+                                               store_z2=nt == 3 or any(ctx.needs_input_grad))
         else:
             part, z2t = ops.trunk_bn2_stats(x, T, w1, b1c, s1c, t1c, w2p, S,
                                             store_z2=nt == 0 or any(ctx.needs_input_grad))
@@ -118,7 +120,8 @@ class TrunkTrainFn(torch.autograd.Function):
         if _TRAIN_PRECISION != "fp32":
             w3s = (w3 * sgn[:, None]).contiguous()
             pmax, parg, psum, psh, Sc = ops.trunk_fwd_train_bf(x, T, w1, b1c, s1c, t1c, w2x, s2c,
-                                                               t2c, ops.split_pack_bf16(w3s), S, nterms=nt)
+                                                               t2c, ops.split_pack_bf16(w3s), S, nterms=nt,
+                                                               z2t=z2t if (nt_side == nt and nt == 3) else None)
         else:
             w3sp = ops.pack_mfma_b(w3, scale=sgn)
             pmax, parg, psum, psh = ops.trunk_fwd_train(x, T, w1, b1c, s1c, t1c, w2p, s2c, t2c, w3sp, S, z2t)

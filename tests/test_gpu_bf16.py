@@ -171,3 +171,42 @@ def test_bf_side_passes_match_fp32_passes(nt, tol, bf16_modes, cuda_device, monk
                                                            w2tx, g2t, S, z2, nt), out)
     print(f"[nterms={nt}] side passes on bf16 operands vs the fp32 passes on the same inputs: worst output "
           f"{worst[0]} rel {worst[1]:.2e} (bound {tol})")
+
+
+@pytest.mark.parametrize("nt", [3, 1])
+@pytest.mark.parametrize("B,N", [(6, 150), (4, 750), (3, 64)])
+def test_bf_pass_c_reads_z2_back(nt, B, N, bf16_modes, cuda_device, monkeypatch):
+    """Pass C on bf16 operands with z2 read back from pass B's store (LOADZ) against the same kernel recomputing
+    layers 1-2: same maxima, arg-maxima and sums.  N = 150: an odd number of 64-point tiles (the second half of the
+    last 128-point tile does not exist in z2t); N = 64: a single half tile."""
+    from pointnetgpd_amd import ops
+    pn, train = bf16_modes
+    x = synth_cloud(B, N, 515 + N, "diverse").to(cuda_device)
+    y = (torch.arange(B) % 2).long().to(cuda_device)
+    mm = build_model(N, 2, 33, 7003).train().to(cuda_device)
+    rec = []
+
+    def wrap(*a, _o=ops.trunk_fwd_train_bf, **kw):
+        out = _o(*a, **kw)
+        rec.append((a, kw, out))
+        return out
+
+    monkeypatch.setattr(ops, "trunk_fwd_train_bf", wrap)
+    train.set_train_precision("bf16x3" if nt == 3 else "bf16")
+    try:
+        logp, _ = mm(x)
+        F.nll_loss(logp, y).backward()          # a backward follows: pass B stores z2 in both modes
+    finally:
+        train.set_train_precision("fp32")
+    monkeypatch.undo()
+    assert len(rec) == 2
+    for a, kw, out in rec:
+        xx, T, w1, b1c, s1c, t1c, w2x, s2c, t2c, w3sx, S = a
+        part, z2t = ops.trunk_bn2_stats_bf(xx, T, w1, b1c, s1c, t1c, w2x, ops.train_splits(B, N), nt, store_z2=True)
+        got = ops.trunk_fwd_train_bf(xx, T, w1, b1c, s1c, t1c, w2x, s2c, t2c, w3sx, S, nterms=nt, z2t=z2t)
+        ref = ops.trunk_fwd_train_bf(xx, T, w1, b1c, s1c, t1c, w2x, s2c, t2c, w3sx, S, nterms=nt, z2t=None)
+        tol = 1e-5 if nt == 3 else 1e-4      # pass B and pass C accumulate layer 2 in the same order: ~bit-equal
+        assert (got[0] - ref[0]).abs().max().item() <= tol * ref[0].abs().max().item()
+        assert (got[1] != ref[1]).float().mean().item() < 2e-3
+        for g, r in zip(got[2:4], ref[2:4]):
+            assert ((g - r).norm() / r.norm()).item() < 1e-4
