@@ -297,18 +297,20 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_gather_kernel(
     float *__restrict__ Gp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *h1 = smem;
-    float *h2 = h1 + TP * H1S;
-    float *xs = h2 + TP * H2S;
-    float *cf = xs + 3 * TP;   // [64]
+    float *xcf = h1 + TP * H1S;   // 2 x ([3][TP] points, [TP] coef): double-buffered by cloud parity
     const Lane L;
     const int cc = blockIdx.x & 15, rng = blockIdx.x >> 4;
     const int b0 = rng * clouds_per_range;
     const int b1 = (b0 + clouds_per_range < B) ? b0 + clouds_per_range : B;
     const bool has_t = trans != nullptr;
-    float g[32];
+    // G accumulates in the MFMA layout of layer 2's output: lane (column j of channel block cb = wave, rows
+    // mfma_row(r, lane) of both row halves) owns G[row][cb*32 + j] — h2 never goes through LDS, and a cloud costs two
+    // barriers (points staged / h1 written) instead of four.
+    f32x16 g0, g1;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) g[i] = 0.f;
-    const int k = L.tid & 127, rh = L.tid >> 7;
+    for (int r = 0; r < 16; ++r) { g0[r] = 0.f; g1[r] = 0.f; }
+    const int cb = L.wave;
+    const float sc = P.s2c[cb * 32 + L.j], sh = P.t2c[cb * 32 + L.j];
     f32x4 w2f[8];
     if (NT == 0) load_w2frag(w2f, P.w2p, L.wave, L);
     // the arg-max points of cloud b+1 (a dependent idx -> x gather) are fetched while cloud b is processed
@@ -324,6 +326,7 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_gather_kernel(
     };
     fetch(b0);
     for (int b = b0; b < b1; ++b) {
+        float *xs = xcf + ((b - b0) & 1) * 4 * TP, *cf = xs + 3 * TP;
         if (L.tid < TP) {
             float x0 = nx0, x1 = nx1, x2 = nx2;
             const float cfv = ncf;
@@ -338,33 +341,28 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_gather_kernel(
             xs[L.tid] = x0; xs[TP + L.tid] = x1; xs[2 * TP + L.tid] = x2;
             cf[L.tid] = cfv;
         }
-        __syncthreads();
+        __syncthreads();   // also: every wave has finished cloud b-1's layer 2 (the last reader of h1)
         layer1_tile(xs, P.w1, P.b1, P.s1c, P.t1c, h1, L);
         __syncthreads();
-        {
-            f32x16 a0, a1;
-            const int cb = L.wave;
-            if constexpr (NT == 0) layer2_compute(h1, w2f, L, a0, a1);
-            else layer2_compute_bf<NT>(h1, P.w2x, cb, L, a0, a1);
-            const float sc = P.s2c[cb * 32 + L.j], sh = P.t2c[cb * 32 + L.j];
+        f32x16 a0, a1;
+        if constexpr (NT == 0) layer2_compute(h1, w2f, L, a0, a1);
+        else layer2_compute_bf<NT>(h1, P.w2x, cb, L, a0, a1);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = mfma_row(r, L.lane);
-                h2[row * H2S + cb * 32 + L.j] = fmaxf(fmaf(a0[r], sc, sh), 0.f);
-                h2[(32 + row) * H2S + cb * 32 + L.j] = fmaxf(fmaf(a1[r], sc, sh), 0.f);
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int row = mfma_row(r, L.lane);
+            g0[r] = fmaf(cf[row], fmaxf(fmaf(a0[r], sc, sh), 0.f), g0[r]);
+            g1[r] = fmaf(cf[32 + row], fmaxf(fmaf(a1[r], sc, sh), 0.f), g1[r]);
         }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            const int r = rh * 32 + i;
-            g[i] = fmaf(cf[r], h2[r * H2S + k], g[i]);
-        }
-        __syncthreads();
+        // no end-of-cloud barrier: xs/cf are double-buffered (cloud b+1 writes the other half; cloud b+2 rewrites this
+        // half only after barrier 1 of cloud b+1, which every wave reaches after this epilogue)
     }
-    float *o = Gp + ((size_t)rng * 1024 + cc * 64 + rh * 32) * 128 + k;
+    float *o = Gp + ((size_t)rng * 1024 + cc * 64) * 128 + cb * 32 + L.j;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) o[(size_t)i * 128] = g[i];
+    for (int r = 0; r < 16; ++r) {
+        const int row = mfma_row(r, L.lane);
+        o[(size_t)row * 128] = g0[r];
+        o[(size_t)(32 + row) * 128] = g1[r];
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1188,7 +1186,7 @@ static int bwd_gather_impl(const float *x, int B, int N, const float *trans, con
         return PNGPD_ERR_INVALID_ARG;
     const int R = (B + clouds_per_range - 1) / clouds_per_range;
     TrainChan P = make_chan(w1, b1, s1c, t1c, w2p, s2c, t2c, w2x);
-    const size_t lds = (TP * H1S + TP * H2S + 3 * TP + 64) * sizeof(float);
+    const size_t lds = (TP * H1S + 8 * TP) * sizeof(float);
     const void *fn = nterms == 0 ? (const void *)trunk_bwd_gather_kernel<0>
                    : nterms == 1 ? (const void *)trunk_bwd_gather_kernel<1> : (const void *)trunk_bwd_gather_kernel<3>;
     int st = pngpd_allow_lds(fn, lds);

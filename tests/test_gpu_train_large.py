@@ -125,21 +125,18 @@ def test_trunk_intermediates_large(cuda_device):
     dev = cuda_device
     Pd = {n: v.to(dev) for n, v in P.items()}
     _, sv = trunk_fwd(x.double().to(dev), T.to(dev), Pd, relu_last=False)
+    flips = (feat["idx"].long() != sv["idx"])
+    assert flips.double().mean().item() < 1e-3
+    # An arg-max that flips at an fp32 near-tie moves one upstream gradient entry to another point with (to round-off)
+    # the same z value: both are valid sub-gradients, but they differ by O(1) in that point's rows (one flip in 262,144
+    # maxima is already 2.7e-3 of the norm of g2).  The backward under test is therefore compared with the fp64
+    # backward evaluated AT THE SAME arg-max points.
+    sv["idx"] = feat["idx"].long()
     g = trunk_bwd(feat["dp"], Pd, sv)
     dbg = g["_dbg"]
-    flips = (feat["idx"].long() != dbg["idx"])
-    assert flips.double().mean().item() < 1e-3
-    # an arg-max that flips at an fp32 near-tie moves one upstream gradient entry to another point: a legitimate O(1)
-    # difference in that cloud's g2 rows (one flip in 262,144 maxima is already 2.7e-3 of the norm), so the per-point
-    # buffer is compared on the clouds whose arg-max sets agree
-    same = ~flips.reshape(B, -1).any(1).cpu()
-    assert same.double().mean().item() > 0.9
     for kx in ["dg3", "dbe3", "S2", "sh", "G", "A", "cvec", "a1", "a2", "c1", "c2", "Rb", "g2buf"]:
-        tol = 5e-3 if kx in ("a1", "a2", "c1", "c2", "Rb") else 1e-3
-        a, b = feat[kx].cpu(), dbg[kx].cpu()
-        if kx == "g2buf":
-            a, b = a.reshape(B, N, -1)[same], b.reshape(B, N, -1)[same]
-        r = _rel(a, b)
+        tol = 5e-3 if kx in ("a1", "a2", "c1", "c2", "Rb") else 1e-3       # cancelling batch sums: 5e-3
+        r = _rel(feat[kx].cpu(), dbg[kx].cpu())
         assert r < tol, (kx, r)
     for kx, ky in [("dW1", "W1"), ("dW2", "W2"), ("dW3", "W3"), ("dT", "T")]:
         r = _rel(feat[kx].cpu(), g[ky].cpu())
