@@ -380,8 +380,9 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_gather_kernel(
 //        in both kernels: value v = 4*rq + e of thread tid is point block v>>4, mfma register v&15) — 8
 //        coalesced 16-B stores per lane here, 8 coalesced 16-B loads there, no transposition through LDS.
 //   pa   [blk][128][2] = sum g2, sum g2*zhat2
-//   ps2  [blk][4 waves][3][16][64] : raw accumulators of the Gram blocks (w,w), (w,w+1 mod 4), (w,w+2 | w<2);
-//        the remaining blocks follow by symmetry (s2_at() in pngpd_train_glue.hip).
+//   ps2  [blk][4 waves][3][16][64] : raw accumulators of the Gram blocks (w,w), (w,w+1 mod 4) and, in slot 2, the
+//        partial of block (w,w+2) over the tile's first 32 points (w < 2) / of block (w-2,w) over its last 32 points
+//        (w >= 2); the remaining blocks follow by symmetry (s2_at() in pngpd_train_glue.hip adds the two partials).
 // ---------------------------------------------------------------------------------------
 struct BwdDParams {
     const float *is2, *nm2;     // zhat2 = z2*is2 + nm2
@@ -531,26 +532,28 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
                 sparse(hits, nlo, d0);
                 sparse(hits + BWD_D_HITS, nhi, d1);
             }
-            {   // Gram: both operands are columns of h2 (k = point 16 st + 8h + u)
+            {   // Gram: both operands are columns of h2 (k = point 16 st + 8h + u); the third block is split over the
+                // points between waves cb and cb+2 exactly as in the fp32 loop below
                 const float *colp = h2 + (8 * L.h) * H2S + L.j;
                 const int o0 = cb * 32, o1 = ((cb + 1) & 3) * 32, o2 = ((cb + 2) & 3) * 32;
 #pragma unroll
                 for (int st = 0; st < 4; ++st) {
+                    const bool third = (cb < 2) ? (st < 2) : (st >= 2);
                     float av[8], b1[8], b2[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const float *rp = colp + (16 * st + u) * H2S;
                         av[u] = rp[o0]; b1[u] = rp[o1];
-                        b2[u] = (cb < 2) ? rp[o2] : 0.f;
+                        b2[u] = third ? rp[o2] : 0.f;
                     }
                     f32x4 ah, al, bh, bl;
                     bf_pack8<NT>(av, ah, al);
                     gm0 = bf_mma<NT>(ah, al, ah, al, gm0);
                     bf_pack8<NT>(b1, bh, bl);
                     gm1 = bf_mma<NT>(ah, al, bh, bl, gm1);
-                    if (cb < 2) {
+                    if (third) {
                         bf_pack8<NT>(b2, bh, bl);
-                        gm2 = bf_mma<NT>(ah, al, bh, bl, gm2);
+                        gm2 = (cb < 2) ? bf_mma<NT>(ah, al, bh, bl, gm2) : bf_mma<NT>(bh, bl, ah, al, gm2);
                     }
                 }
             }
@@ -592,25 +595,25 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
             sparse(hits, nlo, d0);
             sparse(hits + BWD_D_HITS, nhi, d1);
         }
-        // Gram of the tile: D[i][j] += A[i][k = point] B[k = point][j], both operands read column-wise from h2
+        // Gram of the tile: D[i][j] += A[i][k = point] B[k = point][j], both operands read column-wise from h2.
+        // 10 blocks over 4 waves: every wave takes (cb,cb) and (cb,cb+1); the two remaining blocks (0,2) and (1,3) are
+        // split over the POINTS — wave cb < 2 contracts the tile's first 32 points of block (cb,cb+2), wave cb+2 the
+        // last 32 of the same block (s2_at() adds the two partial slots) — so each wave issues 80 MFMAs per tile
+        // instead of 96 / 64.
         {
             const float *colp = h2 + L.h * H2S + L.j;
             const int o0 = cb * 32, o1 = ((cb + 1) & 3) * 32, o2 = ((cb + 2) & 3) * 32;
-            if (cb < 2) {
+            auto gram = [&](int st0, int third) {   // third: 0 none, 1 block (cb, cb+2), 2 block (cb-2, cb)
 #pragma unroll 4
-                for (int st = 0; st < 32; ++st) {
-                    const float *rp = colp + 2 * st * H2S;
-                    const float av = rp[o0];
-                    gm0 = mfma32(av, av, gm0); gm1 = mfma32(av, rp[o1], gm1); gm2 = mfma32(av, rp[o2], gm2);
-                }
-            } else {
-#pragma unroll 4
-                for (int st = 0; st < 32; ++st) {
+                for (int st = st0; st < st0 + 16; ++st) {
                     const float *rp = colp + 2 * st * H2S;
                     const float av = rp[o0];
                     gm0 = mfma32(av, av, gm0); gm1 = mfma32(av, rp[o1], gm1);
+                    if (third == 1) gm2 = mfma32(av, rp[o2], gm2);
+                    if (third == 2) gm2 = mfma32(rp[o2], av, gm2);
                 }
-            }
+            };
+            if (cb < 2) { gram(0, 1); gram(16, 0); } else { gram(0, 0); gram(16, 2); }
         }
         }   // NT == 0
         // epilogue: g2 = (cvec - d) masked by ReLU(bn2) and validity; running sums; lane-major hand-off.
@@ -652,7 +655,7 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
         for (int r = 0; r < 16; ++r) {
             o[r * 64] = gm0[r];
             o[1024 + r * 64] = gm1[r];
-            o[2048 + r * 64] = gm2[r];   // zeros for waves 2,3
+            o[2048 + r * 64] = gm2[r];   // waves 2,3: the second-half partial of block (cb-2, cb)
         }
     }
 }

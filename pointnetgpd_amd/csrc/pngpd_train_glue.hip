@@ -265,7 +265,8 @@ __global__ __launch_bounds__(1024) void reduce_partials_multi_kernel(ReduceSegs 
 }
 
 // Element (k, j) of S2 = sum_points h2 h2^T from the 10 accumulator blocks pass D keeps (S2c f64 [12][16][64]:
-// slot 3w+q of wave w = block (w, (w+q) mod 4), q < 3 for w < 2 and q < 2 otherwise, raw MFMA register layout
+// slot 3w+q of wave w = block (w, (w+q) mod 4) for q < 2; slot 3w+2 = the partial of block (w, w+2) [w < 2] or of
+// block (w-2, w) [w >= 2] over half of each tile's points — the two are added here; raw MFMA register layout
 // D[i = (r&3) + 8 (r>>2) + 4 (lane>>5)][j = lane & 31]); the other six blocks are transposes.
 __device__ __forceinline__ double s2_at(const double *__restrict__ S2c, int k, int j) {
     int a = k >> 5, b = j >> 5, i = k & 31, jj = j & 31;
@@ -277,7 +278,10 @@ __device__ __forceinline__ double s2_at(const double *__restrict__ S2c, int k, i
         q = (b - a) & 3;
     }
     const int r = (i & 3) + 4 * (i >> 3), h = (i >> 2) & 1;
-    return S2c[((size_t)(a * 3 + q) * 16 + r) * 64 + h * 32 + jj];
+    const size_t e = (size_t)r * 64 + h * 32 + jj;
+    double v = S2c[(size_t)(a * 3 + q) * 1024 + e];
+    if (q == 2) v += S2c[(size_t)((a + 2) * 3 + 2) * 1024 + e];   // block (a, a+2): wave a+2 holds the other half of the points
+    return v;
 }
 
 // ---------------------------------------------------------------------------------------

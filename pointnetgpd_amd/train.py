@@ -218,6 +218,8 @@ def _s2_full(S2c, dev):
             for h in range(2):
                 rows = (r & 3) + 8 * (r >> 2) + 4 * h
                 blk[rows] = blocks[w, q, :, h, :]
+                if q == 2:      # block (w, w+2): wave w+2 holds the partial over the other half of the points
+                    blk[rows] += blocks[w + 2, 2, :, h, :]
             out[a * 32:(a + 1) * 32, b * 32:(b + 1) * 32] = blk
             out[b * 32:(b + 1) * 32, a * 32:(a + 1) * 32] = blk.t()
     return out
