@@ -16,5 +16,7 @@ timeout 120 python tools/bench_loader.py 2>/dev/null > gpurun_out/${TAG}_bench_l
 timeout 100 python tools/bench_pass.py 2>/dev/null > gpurun_out/${TAG}_bench_pass.txt
 bash tools/prof_round.sh ${TAG} gpg > /tmp/prof.log 2>&1; grep "rc=" /tmp/prof.log
 bash tools/trace_train.sh ${TAG} > /tmp/tr.log 2>&1; grep "rc=" /tmp/tr.log
+bash tools/trace_train.sh ${TAG} bf16 > /tmp/tr.log 2>&1; grep "rc=" /tmp/tr.log
+bash tools/trace_train.sh ${TAG} bf16x3 > /tmp/tr.log 2>&1; grep "rc=" /tmp/tr.log
 bash tools/pmc_round.sh ${TAG} hbm > /tmp/pmc.log 2>&1; grep "rc=" /tmp/pmc.log
 ls gpurun_out | grep ${TAG}
