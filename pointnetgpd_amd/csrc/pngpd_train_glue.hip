@@ -8,15 +8,17 @@
 
 #define NT 256
 
-__device__ __forceinline__ double block_sum(double v, double *red) {   // red: [NT] shared
+__device__ __forceinline__ double block_sum(double v, double *red) {   // red: [>= NT/64] shared; fixed tree: deterministic
+    // wave tree by shuffles, then the NT/64 wave partials through LDS: 2 barriers (an LDS tree costs 10 per call, and
+    // bn1_finalize makes 12 calls)
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
     const int tid = threadIdx.x;
-    red[tid] = v;
+    if ((tid & 63) == 0) red[tid >> 6] = v;
     __syncthreads();
-    for (int s = NT / 2; s > 0; s >>= 1) {
-        if (tid < s) red[tid] += red[tid + s];
-        __syncthreads();
-    }
-    const double r = red[0];
+    double r = 0.0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) r += red[w];
     __syncthreads();
     return r;
 }
@@ -186,12 +188,14 @@ __global__ __launch_bounds__(1024) void bn3_bwd_prep_kernel(
     const float *__restrict__ dp, const float *__restrict__ pooled, const float *__restrict__ zhat, int B,
     double M, const float *__restrict__ g3, const double *__restrict__ stats, double eps, int relu_last,
     float *__restrict__ coef, float *__restrict__ dg3, float *__restrict__ dbe3, double *__restrict__ m12) {
-    __shared__ double r1[32][33], r2[32][33];
-    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cx;
+    // block = 16 channels x 64 row lanes (64 workgroups); the row loop is unrolled so that 8 rows' loads are in flight
+    __shared__ double r1[64][17], r2[64][17];
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cx;
     const double s3 = (double)g3[c] / sqrt(stats[1024 + c] + eps);
     double a1 = 0.0, a2 = 0.0;
-    for (int b = ry; b < B; b += 32) {
+#pragma unroll 8
+    for (int b = ry; b < B; b += 64) {
         const size_t i = (size_t)b * 1024 + c;
         float d = dp[i];
         if (relu_last && !(pooled[i] > 0.f)) d = 0.f;
@@ -203,8 +207,8 @@ __global__ __launch_bounds__(1024) void bn3_bwd_prep_kernel(
     __syncthreads();
     if (ry == 0) {
         double t1 = 0.0, t2 = 0.0;
-#pragma unroll
-        for (int i = 0; i < 32; ++i) { t1 += r1[i][cx]; t2 += r2[i][cx]; }
+#pragma unroll 8
+        for (int i = 0; i < 64; ++i) { t1 += r1[i][cx]; t2 += r2[i][cx]; }
         dbe3[c] = (float)t1;
         dg3[c] = (float)t2;
         m12[c] = t1 / M;
@@ -286,26 +290,61 @@ __device__ __forceinline__ double s2_at(const double *__restrict__ S2c, int k, i
 
 // ---------------------------------------------------------------------------------------
 // dW3[c][j] = G[c][j] - s3 (m1 sh[j] + (m2/sig3) (W3 Sc)[c][j]),  Sc = S2 - sh sh^T / M
-// block = one channel c, 128 threads = j
+// block = DW3_CPB channels c, 128 threads = j.  Thread j walks column j of S2 block by block (the storage orientation
+// of a 32x32 block is decided once per block, not per element) and every element it fetches serves all DW3_CPB
+// channels of the block (one channel per block with a per-element s2_at() was 46 us for 17 M fp64 FMAs).
 // ---------------------------------------------------------------------------------------
+#define DW3_CPB 4
 __global__ __launch_bounds__(128) void dw3_finalize_kernel(
     const double *__restrict__ G, const double *__restrict__ S2c, const double *__restrict__ sh, double M,
     const float *__restrict__ w3, const float *__restrict__ g3, const double *__restrict__ stats,
     const double *__restrict__ m12, double eps, float *__restrict__ dW3) {
-    __shared__ double wrow[128];
-    __shared__ double red[128];
-    const int c = blockIdx.x, j = threadIdx.x;
-    wrow[j] = (double)w3[(size_t)c * 128 + j];
-    red[j] = wrow[j] * sh[j];
+    __shared__ double wrow[DW3_CPB][128];
+    __shared__ double red[DW3_CPB][128];
+    const int c0 = blockIdx.x * DW3_CPB, j = threadIdx.x;
+    const double shj = sh[j];
+#pragma unroll
+    for (int u = 0; u < DW3_CPB; ++u) {
+        wrow[u][j] = (double)w3[(size_t)(c0 + u) * 128 + j];
+        red[u][j] = wrow[u][j] * shj;
+    }
     __syncthreads();
-    for (int s = 64; s > 0; s >>= 1) { if (j < s) red[j] += red[j + s]; __syncthreads(); }
-    const double ws = red[0];
-    double dot = 0.0;
-    for (int k = 0; k < 128; ++k) dot += wrow[k] * s2_at(S2c, k, j);
-    const double w3sc = dot - ws * sh[j] / M;
-    const double sig = sqrt(stats[1024 + c] + eps);
-    const double s3 = (double)g3[c] / sig;
-    dW3[(size_t)c * 128 + j] = (float)(G[(size_t)c * 128 + j] - s3 * (m12[c] * sh[j] + (m12[1024 + c] / sig) * w3sc));
+    for (int s = 64; s > 0; s >>= 1) {
+        if (j < s) {
+#pragma unroll
+            for (int u = 0; u < DW3_CPB; ++u) red[u][j] += red[u][j + s];
+        }
+        __syncthreads();
+    }
+    double dot[DW3_CPB];
+#pragma unroll
+    for (int u = 0; u < DW3_CPB; ++u) dot[u] = 0.0;
+    const int bb = j >> 5, jj = j & 31;
+    for (int a = 0; a < 4; ++a) {          // rows k = 32 a + i of column j: block (a, bb) of S2
+        const int d = (bb - a) & 3;
+        const bool tr = d == 3 || (d == 2 && a >= 2);          // stored as the transposed block (bb, a)
+        const int ra = tr ? bb : a, q = tr ? ((a - bb) & 3) : d;
+        const double *p0 = S2c + (size_t)(ra * 3 + q) * 1024;
+        const double *p1 = (q == 2) ? S2c + (size_t)((ra + 2) * 3 + 2) * 1024 : nullptr;   // the other half of the points
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) {
+            // stored element (row, col) at ((row&3) + 4 (row>>3)) * 64 + ((row>>2)&1) * 32 + col
+            const int row = tr ? jj : i, col = tr ? i : jj;
+            const int e = ((row & 3) + 4 * (row >> 3)) * 64 + ((row >> 2) & 1) * 32 + col;
+            double v = p0[e];
+            if (p1) v += p1[e];
+#pragma unroll
+            for (int u = 0; u < DW3_CPB; ++u) dot[u] = fma(wrow[u][a * 32 + i], v, dot[u]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < DW3_CPB; ++u) {
+        const int c = c0 + u;
+        const double w3sc = dot[u] - red[u][0] * shj / M;
+        const double sig = sqrt(stats[1024 + c] + eps);
+        const double s3 = (double)g3[c] / sig;
+        dW3[(size_t)c * 128 + j] = (float)(G[(size_t)c * 128 + j] - s3 * (m12[c] * shj + (m12[1024 + c] / sig) * w3sc));
+    }
 }
 
 // A = W3^T diag(g3 m2/sig3^2) W3 (written MFMA_B-packed, fp32), cvec = A mh - W3^T (s3 m1).
@@ -488,7 +527,7 @@ int pngpd_bn3_bwd_prep(const float *dp, const float *pooled, const float *zhat, 
                        double *m12, void *stream) {
     if (!dp || !pooled || !zhat || !g3 || !stats || !coef || !dg3 || !dbe3 || !m12 || B <= 0 || N <= 0)
         return PNGPD_ERR_INVALID_ARG;
-    LAUNCH(bn3_bwd_prep_kernel, dim3(32), dim3(1024), dp, pooled, zhat, B, (double)B * N, g3, stats,
+    LAUNCH(bn3_bwd_prep_kernel, dim3(64), dim3(1024), dp, pooled, zhat, B, (double)B * N, g3, stats,
            (double)eps, relu_last, coef, dg3, dbe3, m12);
 }
 
@@ -533,7 +572,7 @@ int pngpd_dw3_finalize(const double *G, const double *S2c, const double *sh, int
                        void *stream) {
     if (!G || !S2c || !sh || !w3 || !g3 || !stats || !m12 || !dW3 || B <= 0 || N <= 0)
         return PNGPD_ERR_INVALID_ARG;
-    LAUNCH(dw3_finalize_kernel, dim3(1024), dim3(128), G, S2c, sh, (double)B * N, w3, g3, stats, m12,
+    LAUNCH(dw3_finalize_kernel, dim3(1024 / DW3_CPB), dim3(128), G, S2c, sh, (double)B * N, w3, g3, stats, m12,
            (double)eps, dW3);
 }
 
