@@ -120,12 +120,12 @@ int pngpd_trunk_fwd_infer_bf(const void *x, int x_is_bf16, int B, int N, const f
 /* the same arithmetic for pass C of the training path (pngpd_trunk_fwd_train below): identical outputs/semantics.
  * w2x = split_pack_bf16(raw W2), w3sx = split_pack_bf16(sign(gamma3)*W3).  S = workgroups per cloud
  * (1 <= S <= ceil(N/128)); pmax/parg (B*S,1024), psum (B*S,2,1024), psh (B*S*2,128).  BatchNorm statistics and every
- * accumulator stay fp32/fp64.  z2t: pass B's stored z2 (pngpd_trunk_bn2_stats[_bf]) — read back instead of
- * recomputing layers 1-2 — or NULL.                                                                             */
+ * accumulator stay fp32/fp64.  z2t: the z2 tiles pngpd_trunk_bn2_stats_bf stored WITH THE SAME nterms (fp32 tiles
+ * for 3, bf16 tiles for 1) — read back instead of recomputing layers 1-2 — or NULL.                             */
 int pngpd_trunk_fwd_train_bf(const float *x, int B, int N, const float *trans,
                              const float *w1, const float *b1, const float *s1c, const float *t1c,
                              const void *w2x, const float *s2c, const float *t2c, const void *w3sx, int nterms, int S,
-                             float *pmax, int *parg, float *psum, float *psh, const float *z2t, void *stream);
+                             float *pmax, int *parg, float *psum, float *psh, const void *z2t, void *stream);
 
 /* =======================================================================================
  * Training path (batch-statistics BatchNorm, backward).  The trunk's forward/backward is a
@@ -200,24 +200,28 @@ int pngpd_trunk_bwd_e(const float *x, int B, int N, const float *trans,
  * BASELINE configs[2]; reference call sites as above: pointnet.py:29-33,140-149 under loss.backward(), main_1v.py:75).
  * nterms = 1 plain bf16 operands, 3 = bf16x3 split products; accumulators, BatchNorm statistics, masks and every
  * output stay fp32 and keep the layouts of the fp32 entry points.  Operand matrices are pngpd_split_pack_bf16
- * outputs: w2x of W2 (128,64), Ax of the matrix A (128,128) that pngpd_a_cvec_finalize writes row-major into
- * `Arow`, w2tx of W2^T as a (64,128) matrix.  Passes D and E always read z2 back (z2t must be non-NULL).         */
+ * outputs: w2x of W2 (128,64), Ax of the symmetric matrix A (128,128) of pngpd_a_cvec_finalize (unpacked from its
+ * MFMA_B-packed `Ap` to row-major first), w2tx of W2^T as a (64,128) matrix.  Passes D and E always read z2 back (z2t must be non-NULL).
+ * Tile storage: with nterms = 3 z2t / g2t are the fp32 tiles of the fp32 entry points (pngpd_trunk_g2t_bytes);
+ * with nterms = 1 (plain bf16, BASELINE configs[2] "bf16 storage") they are bf16 tiles of HALF that size —
+ * [(b*T + tile)][4][256] x 16 bytes, value v = 8i + e of thread t is half-word e of quad i — written by
+ * pngpd_trunk_bn2_stats_bf / pngpd_trunk_bwd_d_bf and read by pngpd_trunk_fwd_train_bf / _bwd_d_bf / _bwd_e_bf.  */
 int pngpd_trunk_bn2_stats_bf(const float *x, int B, int N, const float *trans,
                              const float *w1, const float *b1, const float *s1c, const float *t1c,
-                             const void *w2x, int nterms, int S, float *part, float *z2t, void *stream);
+                             const void *w2x, int nterms, int S, float *part, void *z2t, void *stream);
 int pngpd_trunk_bwd_gather_bf(const float *x, int B, int N, const float *trans,
                               const float *w1, const float *b1, const float *s1c, const float *t1c,
                               const void *w2x, int nterms, const float *s2c, const float *t2c,
                               const int *idx, const float *coef, int clouds_per_range, float *Gp, void *stream);
 int pngpd_trunk_bwd_d_bf(const float *x, int B, int N, const float *s2c, const float *t2c,
                          const float *is2, const float *nm2, const void *Ax, int nterms, const float *cvec,
-                         const float *w3, const int *idx, const float *coef, const float *z2t, int S,
-                         float *g2t, float *pa, float *ps2, void *stream);
+                         const float *w3, const int *idx, const float *coef, const void *z2t, int S,
+                         void *g2t, float *pa, float *ps2, void *stream);
 int pngpd_trunk_bwd_e_bf(const float *x, int B, int N, const float *trans,
                          const float *w1, const float *b1, const float *s1c, const float *t1c,
                          const float *is1, const float *nm1, const float *is2, const float *nm2,
                          const float *a1m, const float *a2m, const float *dsc2, const void *w2tx, int nterms,
-                         const float *z2t, const float *g2t, int S, float *pc, float *pR, float *pW2, void *stream);
+                         const void *z2t, const void *g2t, int S, float *pc, float *pR, float *pW2, void *stream);
 
 /* Backward of a Linear layer y = x W^T + b (pointnet.py:35-37,191-193; loss.backward() of main_1v.py:75) in one
  * launch, operands read in place: g (B,Nout) upstream gradient, x (B,K) the layer input, W (Nout,K) ->

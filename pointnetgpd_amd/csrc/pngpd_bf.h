@@ -60,3 +60,44 @@ __device__ __forceinline__ void bf_wfrag(const u16 *__restrict__ wx, int KS, int
     wh = p[0];
     if (NT == 3) wl = p[64]; else wl = wh;
 }
+
+// ---- bf16 storage of the lane-major z2 / g2 tiles (plain-bf16 training mode, NT == 1) --------------------------------
+// fp32 tiles: [(b*T + tile)][8][256] float4, value v = 4q + e of thread tid.  bf16 tiles hold the same 32 values per
+// thread as [(b*T + tile)][4][256] uint4: value v = 8i + e8 is half-word e8 of quad i — half the bytes, four 16-byte
+// accesses per lane instead of eight.
+__device__ __forceinline__ uint4 bf_tile_pack(const float (&v)[8]) {
+    uint4 o;
+    o.x = (unsigned)bf16_bits(v[0]) | ((unsigned)bf16_bits(v[1]) << 16);
+    o.y = (unsigned)bf16_bits(v[2]) | ((unsigned)bf16_bits(v[3]) << 16);
+    o.z = (unsigned)bf16_bits(v[4]) | ((unsigned)bf16_bits(v[5]) << 16);
+    o.w = (unsigned)bf16_bits(v[6]) | ((unsigned)bf16_bits(v[7]) << 16);
+    return o;
+}
+__device__ __forceinline__ void bf_tile_unpack(const uint4 &q, float (&v)[8]) {
+    v[0] = __uint_as_float(q.x << 16); v[1] = __uint_as_float(q.x & 0xffff0000u);
+    v[2] = __uint_as_float(q.y << 16); v[3] = __uint_as_float(q.y & 0xffff0000u);
+    v[4] = __uint_as_float(q.z << 16); v[5] = __uint_as_float(q.z & 0xffff0000u);
+    v[6] = __uint_as_float(q.w << 16); v[7] = __uint_as_float(q.w & 0xffff0000u);
+}
+// the thread's 32 tile values <-> two MFMA register sets (a0 = values 0..15, a1 = values 16..31)
+__device__ __forceinline__ void bf_tile_load(const uint4 *__restrict__ t, f32x16 &a0, f32x16 &a1) {   // t: + i*256 per quad
+    uint4 q[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = t[(size_t)i * 256];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float v[8];
+        bf_tile_unpack(q[i], v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { if (i < 2) a0[8 * i + e] = v[e]; else a1[8 * (i - 2) + e] = v[e]; }
+    }
+}
+__device__ __forceinline__ void bf_tile_store(uint4 *__restrict__ t, const f32x16 &a0, const f32x16 &a1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (i < 2) ? a0[8 * i + e] : a1[8 * (i - 2) + e];
+        t[(size_t)i * 256] = bf_tile_pack(v);
+    }
+}

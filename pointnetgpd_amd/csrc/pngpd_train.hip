@@ -90,11 +90,15 @@ __global__ __launch_bounds__(256, 2) void trunk_bn2_stats_kernel(
         else layer2_compute_bf<NT>(h1, P.w2x, L.wave, L, a0, a1);
         const int nbase = tile * TP;
         if (z2t) {   // z2 is computed ONCE per step, here; passes C, D and E read it back (lane-major tiles, 512 B/point)
+            if constexpr (NT == 1) {   // plain-bf16 mode: bf16 tiles, 256 B/point (pngpd_bf.h)
+                bf_tile_store((uint4 *)z2t + ((size_t)(b * T + tile) * 4) * 256 + L.tid, a0, a1);
+            } else {
             f32x4 *zt = z2t + ((size_t)(b * T + tile) * 8) * 256 + L.tid;
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
                 zt[(size_t)rq * 256] = f32x4{a0[4 * rq], a0[4 * rq + 1], a0[4 * rq + 2], a0[4 * rq + 3]};
                 zt[(size_t)(4 + rq) * 256] = f32x4{a1[4 * rq], a1[4 * rq + 1], a1[4 * rq + 2], a1[4 * rq + 3]};
+            }
             }
         }
 #pragma unroll
@@ -440,7 +444,12 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
     for (int tile = t0; tile < t1; ++tile) {
         const int nbase = tile * TP;
         f32x4 zq[8];
-        if (LOADZ) {
+        uint4 zb[4];
+        if (NT == 1) {            // bf16 tiles (plain-bf16 mode)
+            const uint4 *zt = (const uint4 *)z2t + ((size_t)(b * T + tile) * 4) * 256 + L.tid;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) zb[i] = zt[(size_t)i * 256];
+        } else if (LOADZ) {
             const f32x4 *zt = z2t + ((size_t)(b * T + tile) * 8) * 256 + L.tid;
 #pragma unroll
             for (int i = 0; i < 8; ++i) zq[i] = zt[(size_t)i * 256];
@@ -487,7 +496,15 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
         nlo = __builtin_amdgcn_readfirstlane(nlo);
         nhi = __builtin_amdgcn_readfirstlane(nhi);
         f32x16 z0, z1;   // raw z2 of (this lane's rows, channel c2): ReLU mask and zhat2 are derived in the epilogue
-        if (LOADZ) {
+        if (NT == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v[8];
+                bf_tile_unpack(zb[i], v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { if (i < 2) z0[8 * i + e] = v[e]; else z1[8 * (i - 2) + e] = v[e]; }
+            }
+        } else if (LOADZ) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { z0[r] = zq[r >> 2][r & 3]; z1[r] = zq[4 + (r >> 2)][r & 3]; }
         } else {
@@ -622,6 +639,7 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
         // and fillers between the dependent Gram MFMAs only delay them.)
         {
             f32x4 *gt = g2t + ((size_t)(b * T + tile) * 8) * 256 + L.tid;
+            f32x16 gb0, gb1;   // NT == 1: the tile leaves as bf16 (the sums below take the unrounded values)
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
                 f32x4 o0, o1;
@@ -635,10 +653,14 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
                     a1s += g0 + g1;
                     a2s = fmaf(g0, fmaf(z0[r], is2, nm2), fmaf(g1, fmaf(z1[r], is2, nm2), a2s));
                     o0[e] = g0; o1[e] = g1;
+                    if (NT == 1) { gb0[r] = g0; gb1[r] = g1; }
                 }
-                gt[(size_t)rq * 256] = o0;
-                gt[(size_t)(4 + rq) * 256] = o1;
+                if (NT != 1) {
+                    gt[(size_t)rq * 256] = o0;
+                    gt[(size_t)(4 + rq) * 256] = o1;
+                }
             }
+            if constexpr (NT == 1) bf_tile_store((uint4 *)g2t + ((size_t)(b * T + tile) * 4) * 256 + L.tid, gb0, gb1);
         }
         // no end-of-tile barrier: the next tile's stage_points/census touch only xs/hcnt, whose readers all sit
         // before this tile's second barrier; h1, hits and h2 are rewritten after the next tile's first barrier.
@@ -712,7 +734,13 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
         const int nbase = tile * TP;
         float *xs = xbuf + ((tile - t0) & 1) * 6 * TP, *xo = xs + 3 * TP;
         f32x4 gq[8], zq[8];   // this lane's 32 g2 (and z2) values of the tile (g2 rows past N hold zeros)
-        {
+        uint4 gb[4], zb[4];   // NT == 1: the same values as bf16 tiles
+        if (NT == 1) {
+            const uint4 *gt = (const uint4 *)g2t + ((size_t)(b * T + tile) * 4) * 256 + L.tid;
+            const uint4 *zt = (const uint4 *)z2t + ((size_t)(b * T + tile) * 4) * 256 + L.tid;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { gb[i] = gt[(size_t)i * 256]; zb[i] = zt[(size_t)i * 256]; }
+        } else {
             const f32x4 *gt = g2t + ((size_t)(b * T + tile) * 8) * 256 + L.tid;
 #pragma unroll
             for (int i = 0; i < 8; ++i) gq[i] = gt[(size_t)i * 256];
@@ -727,18 +755,34 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
         layer1_tile(xs, P.w1, P.b1, P.s1c, P.t1c, h1, L);
         if (!LOADZ) __syncthreads();   // layer 2 reads h1; with LOADZ the dz tile below depends on registers only
         {
-            f32x16 a0, a1;
-            if (LOADZ) {
+            f32x16 a0, a1, gv0, gv1;
+            if (NT == 1) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { a0[r] = zq[r >> 2][r & 3]; a1[r] = zq[4 + (r >> 2)][r & 3]; }
+                for (int i = 0; i < 4; ++i) {
+                    float vz[8], vg[8];
+                    bf_tile_unpack(zb[i], vz);
+                    bf_tile_unpack(gb[i], vg);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        if (i < 2) { a0[8 * i + e] = vz[e]; gv0[8 * i + e] = vg[e]; }
+                        else { a1[8 * (i - 2) + e] = vz[e]; gv1[8 * (i - 2) + e] = vg[e]; }
+                    }
+                }
             } else {
-                layer2_compute(h1, w2f, L, a0, a1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { gv0[r] = gq[r >> 2][r & 3]; gv1[r] = gq[4 + (r >> 2)][r & 3]; }
+                if (LOADZ) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { a0[r] = zq[r >> 2][r & 3]; a1[r] = zq[4 + (r >> 2)][r & 3]; }
+                } else {
+                    layer2_compute(h1, w2f, L, a0, a1);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mfma_row(r, L.lane);
                 const bool v0 = nbase + row < N, v1 = nbase + 32 + row < N;
-                const float g0 = gq[r >> 2][r & 3], g1 = gq[4 + (r >> 2)][r & 3];
+                const float g0 = gv0[r], g1 = gv1[r];
                 const float z0 = fmaf(a0[r], is2, nm2), z1 = fmaf(a1[r], is2, nm2);
                 dz[row * H2S + c2] = v0 ? dsc * (g0 - a1m - z0 * a2m) : 0.f;
                 dz[(32 + row) * H2S + c2] = v1 ? dsc * (g1 - a1m - z1 * a2m) : 0.f;
@@ -1253,9 +1297,9 @@ int pngpd_trunk_bn2_stats(const float *x, int B, int N, const float *trans,
 
 int pngpd_trunk_bn2_stats_bf(const float *x, int B, int N, const float *trans,
                              const float *w1, const float *b1, const float *s1c, const float *t1c,
-                             const void *w2x, int nterms, int S, float *part, float *z2t, void *stream) {
+                             const void *w2x, int nterms, int S, float *part, void *z2t, void *stream) {
     if (nterms != 1 && nterms != 3) return PNGPD_ERR_INVALID_ARG;
-    return bn2_stats_impl(x, B, N, trans, w1, b1, s1c, t1c, nullptr, w2x, nterms, S, part, z2t, stream);
+    return bn2_stats_impl(x, B, N, trans, w1, b1, s1c, t1c, nullptr, w2x, nterms, S, part, (float *)z2t, stream);
 }
 
 int pngpd_trunk_fwd_train(const float *x, int B, int N, const float *trans,
@@ -1319,8 +1363,10 @@ int pngpd_trunk_bwd_d(const float *x, int B, int N, const float *trans,
 
 int pngpd_trunk_bwd_d_bf(const float *x, int B, int N, const float *s2c, const float *t2c,
                          const float *is2, const float *nm2, const void *Ax, int nterms, const float *cvec,
-                         const float *w3, const int *idx, const float *coef, const float *z2t, int S,
-                         float *g2t, float *pa, float *ps2, void *stream) {
+                         const float *w3, const int *idx, const float *coef, const void *z2tv, int S,
+                         void *g2tv, float *pa, float *ps2, void *stream) {
+    const float *z2t = (const float *)z2tv;
+    float *g2t = (float *)g2tv;
     if (!x || !s2c || !t2c || !is2 || !nm2 || !Ax || !cvec || !w3 || !idx || !coef || !z2t || !g2t || !pa || !ps2 ||
         B <= 0 || N <= 0 || (nterms != 1 && nterms != 3))
         return PNGPD_ERR_INVALID_ARG;
@@ -1359,7 +1405,8 @@ int pngpd_trunk_bwd_e_bf(const float *x, int B, int N, const float *trans,
                          const float *w1, const float *b1, const float *s1c, const float *t1c,
                          const float *is1, const float *nm1, const float *is2, const float *nm2,
                          const float *a1m, const float *a2m, const float *dsc2, const void *w2tx, int nterms,
-                         const float *z2t, const float *g2t, int S, float *pc, float *pR, float *pW2, void *stream) {
+                         const void *z2tv, const void *g2tv, int S, float *pc, float *pR, float *pW2, void *stream) {
+    const float *z2t = (const float *)z2tv, *g2t = (const float *)g2tv;
     if (!x || !w1 || !b1 || !s1c || !t1c || !is1 || !nm1 || !is2 || !nm2 || !a1m || !a2m || !dsc2 || !w2tx || !z2t ||
         !g2t || !pc || !pR || !pW2 || B <= 0 || N <= 0 || (nterms != 1 && nterms != 3))
         return PNGPD_ERR_INVALID_ARG;

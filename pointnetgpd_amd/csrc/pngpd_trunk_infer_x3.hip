@@ -268,12 +268,19 @@ __global__ __launch_bounds__(512, 2) void trunk_fwd_train_x3_kernel(
     for (int i = tid; i < 1024; i += 512) { rm[i] = -INFINITY; ri[i] = 0; ss[i] = 0.f; sq[i] = 0.f; }
     f32x4 wah[8], wal[8];
     f32x4 zq[8];
+    uint4 zb[4];          // NT == 1: pass B stored bf16 tiles (pngpd_bf.h), four quads per lane instead of eight
     auto fetch_z = [&](int tile) {
         int t64 = 2 * tile + (tid >> 8);
         t64 = t64 < T64 ? t64 : 2 * tile;
-        const f32x4 *zt = z2t + ((size_t)(b * T64 + t64) * 8) * 256 + (tid & 255);
+        if (NT == 1) {
+            const uint4 *zt = (const uint4 *)z2t + ((size_t)(b * T64 + t64) * 4) * 256 + (tid & 255);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) zq[i] = zt[(size_t)i * 256];
+            for (int i = 0; i < 4; ++i) zb[i] = zt[(size_t)i * 256];
+        } else {
+            const f32x4 *zt = z2t + ((size_t)(b * T64 + t64) * 8) * 256 + (tid & 255);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) zq[i] = zt[(size_t)i * 256];
+        }
     };
     if (LOADZ) fetch_z(t0);
 
@@ -323,8 +330,18 @@ __global__ __launch_bounds__(512, 2) void trunk_fwd_train_x3_kernel(
             const int cb = wave & 3, pb0 = (wave >> 2) * 2;
             f32x16 a0 = {0}, a1 = {0};
             if (LOADZ) {
+                if (NT == 1) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { a0[r] = zq[r >> 2][r & 3]; a1[r] = zq[4 + (r >> 2)][r & 3]; }
+                    for (int i = 0; i < 4; ++i) {
+                        float v[8];
+                        bf_tile_unpack(zb[i], v);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { if (i < 2) a0[8 * i + e] = v[e]; else a1[8 * (i - 2) + e] = v[e]; }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { a0[r] = zq[r >> 2][r & 3]; a1[r] = zq[4 + (r >> 2)][r & 3]; }
+                }
                 if (tile + 1 < t1) fetch_z(tile + 1);   // in flight during this tile's layer 3
             } else {
             f32x4 w2h[4], w2l[4];
@@ -533,7 +550,8 @@ int pngpd_trunk_fwd_infer_bf(const void *x, int x_is_bf16, int B, int N, const f
 int pngpd_trunk_fwd_train_bf(const float *x, int B, int N, const float *trans,
                              const float *w1, const float *b1, const float *s1c, const float *t1c,
                              const void *w2x, const float *s2c, const float *t2c, const void *w3sx, int nterms, int S,
-                             float *pmax, int *parg, float *psum, float *psh, const float *z2t, void *stream) {
+                             float *pmax, int *parg, float *psum, float *psh, const void *z2tv, void *stream) {
+    const float *z2t = (const float *)z2tv;
     if (!x || !w1 || !b1 || !s1c || !t1c || !w2x || !s2c || !t2c || !w3sx || !pmax || !parg || !psum || !psh ||
         B <= 0 || N <= 0 || (nterms != 1 && nterms != 3))
         return PNGPD_ERR_INVALID_ARG;

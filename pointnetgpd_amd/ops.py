@@ -228,12 +228,27 @@ def trunk_bn2_stats(x, trans, w1, b1, s1c, t1c, w2p, S, store_z2=True):
     return part, z2t
 
 
+def _tile_buffer(x, nterms):
+    """z2 / g2 tile storage of the bf16 passes: fp32 tiles (bf16x3) or bf16 tiles of half the size (plain bf16)."""
+    B, _, N = x.shape
+    nbytes = _lib.load().pngpd_trunk_g2t_bytes(B, N)
+    if int(nterms) == 1:
+        return torch.empty(nbytes // 4, device=x.device, dtype=torch.int16)
+    return torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+
+
+def tiles_bf16_to_f32(t16):
+    """bf16 tiles [(b*T+tile)][4][256][8] -> the fp32 tile layout [(b*T+tile)][8][256][4] (tests / debugging)."""
+    v = (t16.view(-1, 4, 256, 8).to(torch.int32) << 16).view(torch.float32)
+    return v.view(-1, 4, 256, 2, 4).permute(0, 1, 3, 2, 4).reshape(-1)
+
+
 def trunk_bn2_stats_bf(x, trans, w1, b1, s1c, t1c, w2x, S, nterms, store_z2=True):
-    """Pass B with layer 2 on bf16 (nterms 1) / bf16x3 (3) operands; w2x = split_pack_bf16(W2)."""
+    """Pass B with layer 2 on bf16 (nterms 1) / bf16x3 (3) operands; w2x = split_pack_bf16(W2).  The z2 tiles are
+    fp32 for nterms 3 and bf16 (int16 tensor, half the bytes) for nterms 1."""
     B, _, N = x.shape
     part = torch.empty(B * S, 128, 2, device=x.device, dtype=torch.float32)
-    z2t = torch.empty(_lib.load().pngpd_trunk_g2t_bytes(B, N) // 4, device=x.device, dtype=torch.float32) \
-        if store_z2 else None
+    z2t = _tile_buffer(x, nterms) if store_z2 else None
     _call("pngpd_trunk_bn2_stats_bf", x, x, B, N, trans, w1, b1, s1c, t1c, w2x, int(nterms), int(S), part, z2t)
     return part, z2t
 
@@ -257,6 +272,8 @@ def trunk_fwd_train_bf(x, trans, w1, b1, s1c, t1c, w2x, s2c, t2c, w3sx, S, nterm
     stored z2, read back instead of recomputing layers 1-2, or None."""
     B, _, N = x.shape
     S = max(1, min(int(S), (N + 127) // 128))
+    if z2t is not None and z2t.dtype != (torch.int16 if int(nterms) == 1 else torch.float32):
+        raise RuntimeError("z2t: expected the tiles pngpd_trunk_bn2_stats_bf stored with the same nterms")
     pmax = torch.empty(B, S, 1024, device=x.device, dtype=torch.float32)
     parg = torch.empty(B, S, 1024, device=x.device, dtype=torch.int32)
     psum = torch.empty(B * S, 2, 1024, device=x.device, dtype=torch.float32)
@@ -298,7 +315,9 @@ def unpack_mfma_b_128(Ap):
 def trunk_bwd_d_bf(x, s2c, t2c, is2, nm2, Ax, cvec, w3, idx, coef, S, z2t, nterms):
     """Pass D on bf16 / bf16x3 operands; Ax = split_pack_bf16 of the (symmetric) matrix A; z2t required."""
     B, _, N = x.shape
-    g2t = torch.empty(_lib.load().pngpd_trunk_g2t_bytes(B, N) // 4, device=x.device, dtype=torch.float32)
+    if z2t is None or z2t.dtype != (torch.int16 if int(nterms) == 1 else torch.float32):
+        raise RuntimeError("z2t: expected the tiles pngpd_trunk_bn2_stats_bf stored with the same nterms")
+    g2t = _tile_buffer(x, nterms)
     pa = torch.empty(B * S, 128, 2, device=x.device, dtype=torch.float32)
     ps2 = torch.empty(B * S, 12 * 1024, device=x.device, dtype=torch.float32)
     _call("pngpd_trunk_bwd_d_bf", x, x, B, N, s2c, t2c, is2, nm2, Ax, int(nterms), cvec, w3, idx, coef, z2t, int(S),
@@ -309,6 +328,9 @@ def trunk_bwd_d_bf(x, s2c, t2c, is2, nm2, Ax, cvec, w3, idx, coef, S, z2t, nterm
 def trunk_bwd_e_bf(x, trans, w1, b1, s1c, t1c, is1, nm1, is2, nm2, a1m, a2m, dsc2, w2tx, g2t, S, z2t, nterms):
     """Pass E on bf16 / bf16x3 operands; w2tx = split_pack_bf16(W2^T as (64,128)); z2t required."""
     B, _, N = x.shape
+    want = torch.int16 if int(nterms) == 1 else torch.float32
+    if z2t is None or z2t.dtype != want or g2t.dtype != want:
+        raise RuntimeError("z2t / g2t: expected the tiles the bf16 passes stored with the same nterms")
     pc = torch.empty(B * S, 64, 2, device=x.device, dtype=torch.float32)
     pR = torch.empty(B, S, 64, 3, device=x.device, dtype=torch.float32)
     pW2 = torch.empty(B * S, 128, 64, device=x.device, dtype=torch.float32)

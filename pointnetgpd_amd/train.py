@@ -196,7 +196,8 @@ class TrunkTrainFn(torch.autograd.Function):
                                     G=G[0].view(1024, 128), cvec=cvec, a1=a12v.view(128, 2)[:, 0],
                                     a2=a12v.view(128, 2)[:, 1], c1=c12v.view(64, 2)[:, 0],
                                     c2=c12v.view(64, 2)[:, 1], Rb=Rb.view(B, 64, 3), dW1=dW1, dW2=dW2, dW3=dW3, dT=dT,
-                                    g2buf=g2t_to_rows(g2t, B, N), idx=idx, coef=coef,
+                                    g2buf=g2t_to_rows(ops.tiles_bf16_to_f32(g2t) if g2t.dtype == torch.int16 else g2t,
+                                                      B, N), idx=idx, coef=coef,
                                     A=Ap.view(4, 16, 2, 32, 4).permute(0, 3, 1, 2, 4).reshape(128, 128)))
         z = lambda n: torch.zeros(n, device=dev, dtype=torch.float32)   # conv bias ahead of train-mode BN: exactly 0
         return (None, dT,

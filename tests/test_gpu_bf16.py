@@ -143,6 +143,9 @@ def test_bf_side_passes_match_fp32_passes(nt, tol, bf16_modes, cuda_device, monk
     def check(tag, got, ref):
         nonlocal worst
         for i, (g, r) in enumerate(zip(got, ref)):
+            if g.dtype == torch.int16:          # plain bf16: the z2 / g2 tiles are stored as bf16 (half the bytes)
+                assert g.numel() * 2 == r.numel() * 4 // 2
+                g = ops.tiles_bf16_to_f32(g)
             e = rel(g, r)
             if e > worst[1]:
                 worst = (f"{tag}[{i}]", e)
@@ -164,11 +167,25 @@ def test_bf_side_passes_match_fp32_passes(nt, tol, bf16_modes, cuda_device, monk
         (a, kw, out) = rec["trunk_bwd_d"][bi]
         xx, T, w1, b1c, s1c, t1c, w2p, s2c, t2c, is2, nm2, Ap, cvec, w3, idx, coef, S, z2 = a
         Ax = ops.split_pack_bf16(ops.unpack_mfma_b_128(Ap).contiguous())
-        check(f"{trunk}.D(g2t,pa,ps2)", ops.trunk_bwd_d_bf(xx, s2c, t2c, is2, nm2, Ax, cvec, w3, idx, coef, S, z2, nt), out)
+        # identical inputs on both sides.  bf16x3: the recorded fp32 tiles go to both.  Plain bf16 stores its tiles as
+        # bf16, so there the bf16 pass B's tiles are fed to the bf16 passes and, widened back to fp32 tiles, to the
+        # fp32 passes (otherwise a ReLU mask derived from a rounded z2 near zero would differ, not the arithmetic)
+        if nt == 1:
+            z_bf, z_ref = z2t, ops.tiles_bf16_to_f32(z2t)
+            out = ops.trunk_bwd_d(xx, T, w1, b1c, s1c, t1c, w2p, s2c, t2c, is2, nm2, Ap, cvec, w3, idx, coef, S, z_ref)
+        else:
+            z_bf = z_ref = z2
+        d_out = ops.trunk_bwd_d_bf(xx, s2c, t2c, is2, nm2, Ax, cvec, w3, idx, coef, S, z_bf, nt)
+        check(f"{trunk}.D(g2t,pa,ps2)", d_out, out)
         (a, kw, out) = rec["trunk_bwd_e"][bi]
         xx, T, w1, b1c, s1c, t1c, w2p, is1, nm1, is2, nm2, a1m, a2m, dsc2, w2tp, g2t, S, z2 = a
+        if nt == 1:
+            g_bf, g_ref = d_out[0], ops.tiles_bf16_to_f32(d_out[0])
+            out = ops.trunk_bwd_e(xx, T, w1, b1c, s1c, t1c, w2p, is1, nm1, is2, nm2, a1m, a2m, dsc2, w2tp, g_ref, S, z_ref)
+        else:
+            g_bf = g2t
         check(f"{trunk}.E(pc,pR,pW2)", ops.trunk_bwd_e_bf(xx, T, w1, b1c, s1c, t1c, is1, nm1, is2, nm2, a1m, a2m, dsc2,
-                                                           w2tx, g2t, S, z2, nt), out)
+                                                           w2tx, g_bf, S, z_bf, nt), out)
     print(f"[nterms={nt}] side passes on bf16 operands vs the fp32 passes on the same inputs: worst output "
           f"{worst[0]} rel {worst[1]:.2e} (bound {tol})")
 
@@ -205,8 +222,10 @@ def test_bf_pass_c_reads_z2_back(nt, B, N, bf16_modes, cuda_device, monkeypatch)
         part, z2t = ops.trunk_bn2_stats_bf(xx, T, w1, b1c, s1c, t1c, w2x, ops.train_splits(B, N), nt, store_z2=True)
         got = ops.trunk_fwd_train_bf(xx, T, w1, b1c, s1c, t1c, w2x, s2c, t2c, w3sx, S, nterms=nt, z2t=z2t)
         ref = ops.trunk_fwd_train_bf(xx, T, w1, b1c, s1c, t1c, w2x, s2c, t2c, w3sx, S, nterms=nt, z2t=None)
-        tol = 1e-5 if nt == 3 else 1e-4      # pass B and pass C accumulate layer 2 in the same order: ~bit-equal
+        # bf16x3: pass B and pass C accumulate layer 2 in the same order (~bit-equal); plain bf16: the stored z2 is
+        # rounded to bf16 (2^-9), which moves near-tied arg-maxima
+        tol, flips, stol = (1e-5, 2e-3, 1e-4) if nt == 3 else (2e-2, 0.15, 2e-2)
         assert (got[0] - ref[0]).abs().max().item() <= tol * ref[0].abs().max().item()
-        assert (got[1] != ref[1]).float().mean().item() < 2e-3
+        assert (got[1] != ref[1]).float().mean().item() < flips
         for g, r in zip(got[2:4], ref[2:4]):
-            assert ((g - r).norm() / r.norm()).item() < 1e-4
+            assert ((g - r).norm() / r.norm()).item() < stol
