@@ -100,10 +100,11 @@ class TrunkTrainFn(torch.autograd.Function):
         nt_side = 0 if _FP32_SIDE_PASSES else nt      # arithmetic of passes B / gather / D / E
         w2x = ops.split_pack_bf16(w2) if nt else None
         if nt_side:
-            # bf16x3: pass C reads z2 back (measured 4.80 -> 4.77 ms at B=N=1024; with plain bf16 the 0.5 GB read costs
-            # more than the layers it saves, 3.60 -> 3.69 ms, so that mode recomputes and stores z2 only for a backward)
-            part, z2t = ops.trunk_bn2_stats_bf(x, T, w1, b1c, s1c, t1c, w2x, S, nt_side,
-                                               store_z2=nt == 3 or any(ctx.needs_input_grad))
+            # z2 is computed once, here, and read back by passes C / D / E: fp32 tiles in bf16x3 mode, bf16 tiles (half
+            # the bytes) in plain-bf16 mode.  Measured at B=N=1024: reading back instead of recomputing layers 1-2 in
+            # pass C is worth 4.80 -> 4.77 ms (bf16x3) and 3.12 -> 3.06 ms (bf16, bf16 tiles; with fp32 tiles it LOST,
+            # 3.60 -> 3.69 ms)
+            part, z2t = ops.trunk_bn2_stats_bf(x, T, w1, b1c, s1c, t1c, w2x, S, nt_side, store_z2=True)
         else:
             part, z2t = ops.trunk_bn2_stats(x, T, w1, b1c, s1c, t1c, w2p, S,
                                             store_z2=nt == 0 or any(ctx.needs_input_grad))
@@ -121,7 +122,7 @@ class TrunkTrainFn(torch.autograd.Function):
             w3s = (w3 * sgn[:, None]).contiguous()
             pmax, parg, psum, psh, Sc = ops.trunk_fwd_train_bf(x, T, w1, b1c, s1c, t1c, w2x, s2c,
                                                                t2c, ops.split_pack_bf16(w3s), S, nterms=nt,
-                                                               z2t=z2t if (nt_side == nt and nt == 3) else None)
+                                                               z2t=z2t if nt_side == nt else None)
         else:
             w3sp = ops.pack_mfma_b(w3, scale=sgn)
             pmax, parg, psum, psh = ops.trunk_fwd_train(x, T, w1, b1c, s1c, t1c, w2p, s2c, t2c, w3sp, S, z2t)
