@@ -1,6 +1,8 @@
 // libpngpd — training path of the per-point MLP trunk (batch-statistics BatchNorm + max-pool)
-// as a sequence of recompute passes; no (B,C,N) activation is ever stored except the
-// (B,N,128) layer-2 gradient handed from backward pass D to pass E.
+// as a sequence of passes over the cloud.  Two (B,N,128) tensors are kept between passes, both in a lane-major
+// tile layout their consumers read without any shuffle: z2 = W2 h1 (written once by pass B, read by C, D, E) and the
+// layer-2 gradient g2 (pass D -> pass E); h1 is recomputed from the 12-byte point, the 1024-channel layer is never
+// stored.
 //
 // Replaces, in train mode, the autograd graph of
 //   PointNetGPD/model/pointnet.py:29-33 (STN3d trunk) and :140-149 (PointNetfeat trunk)
@@ -400,10 +402,11 @@ struct BwdDParams {
 #define BWD_D_HITS 1032   // per list: up to 1024 hits + read-ahead padding of the 8-hit sparse step
 #define BWD_D_LDS_FLOATS (TP * H2S + TP * H1S + 3 * TP + 1024 + 1024 + BWD_D_HITS + 16)
 
-// LOADZ: the raw layer-2 output z2 was stored by pass C (z2t, lane-major tiles) and is read back here instead of
+// LOADZ: the raw layer-2 output z2 was stored by pass B (z2t, lane-major tiles) and is read back here instead of
 // recomputing layers 1-2: 64 of the 324 MFMAs per wave and tile, the layer-1 VALU work, the h1 tile and one of the
-// three barriers disappear, for 512 B per point of (overlapped) HBM reads.  !LOADZ (the bf16 modes, whose pass C
-// computes z2 on other operands): recompute in fp32 as before.
+// three barriers disappear, for 512 B per point of (overlapped) HBM reads.  !LOADZ (a caller without a z2t): recompute
+// in fp32.  NT: 0 = fp32 MFMA; 1 / 3 = the three contractions on bf16 / bf16x3 operands (NT = 1 also keeps the z2 / g2
+// tiles in bf16, pngpd_bf.h).
 template <bool LOADZ, int NT>
 __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
     const float *__restrict__ x, int N, const float *__restrict__ trans, TrainChan P, BwdDParams D,

@@ -94,8 +94,7 @@ class TrunkTrainFn(torch.autograd.Function):
         s1c, t1c, is1, nm1 = chan1[0], chan1[1], chan1[2], chan1[3]
         # ---- pass B + BN2
         w2p = ops.pack_mfma_b(w2)
-        # z2 = W2 h1 is computed once, here, and handed to passes C / D / E (512 B per point): in the fp32 mode always
-        # (pass C reads it), in the bf16 modes (whose pass C computes layer 2 on other operands) only for a backward
+        # z2 = W2 h1 is computed once, here, and handed to passes C / D / E (512 B per point; 256 B in plain-bf16 mode)
         nt = 0 if _TRAIN_PRECISION == "fp32" else _NTERMS[_TRAIN_PRECISION]
         nt_side = 0 if _FP32_SIDE_PASSES else nt      # arithmetic of passes B / gather / D / E
         w2x = ops.split_pack_bf16(w2) if nt else None
