@@ -41,6 +41,16 @@ def set_train_precision(mode, fp32_side_passes=False):
 DEBUG_STASH = None   # set to a dict to capture backward intermediates (tests/test_gpu_train.py::test_trunk_backward_intermediates)
 
 
+_PM_ONE = {}
+
+
+def _pm_one(dev):
+    t = _PM_ONE.get(dev)
+    if t is None:
+        t = _PM_ONE[dev] = (torch.tensor(1.0, device=dev), torch.tensor(-1.0, device=dev))
+    return t
+
+
 def _e(dev, *shape, dtype=torch.float32):
     return torch.empty(*shape, device=dev, dtype=dtype)
 
@@ -115,7 +125,7 @@ class TrunkTrainFn(torch.autograd.Function):
         _bump(bufs2)
         s2c, t2c, is2, nm2 = chan2[0], chan2[1], chan2[2], chan2[3]
         # ---- pass C + BN3 + pool
-        sgn = torch.where(g3c >= 0, 1.0, -1.0).to(torch.float32)
+        sgn = torch.where(g3c >= 0, *_pm_one(dev))        # cached 0-dim +1 / -1: no per-step scalar fills
         Sc = S
         if _TRAIN_PRECISION != "fp32":
             w3s = (w3 * sgn[:, None]).contiguous()
