@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PNGPD_ABI_VERSION 2
+#define PNGPD_ABI_VERSION 3
 
 enum {
     PNGPD_OK = 0,
@@ -285,6 +285,90 @@ int pngpd_bwd_e_prep(const double *a12, int B, int N, const float *g2, const dou
 int pngpd_dw1_finalize(const double *Rb, const float *trans, const double *mom, int B, int N, const double *c12,
                        const double *stats1, const float *w1, const float *b1, const float *g1, float eps,
                        float *dW1, float *dg1, float *dbe1, float *dT, void *stream);
+
+/* =======================================================================================
+ * One entry per direction of the training graph (pngpd_train_step.hip).
+ *
+ * A training step of the reference (main_1v.py:72-76: forward, nll_loss, loss.backward(), optimizer.step()) walks
+ * the trunk of STN3d (pointnet.py:29-33), its FC stack (:35-43), the trunk of PointNetfeat (:140-149) and the head
+ * of PointNetCls (:191-194).  Each of those four pieces is ONE call here per direction: the entry enqueues every
+ * pass / finalize kernel of the piece on `stream` in the order — and with the arithmetic — of the per-pass entry
+ * points above (results are bit-identical to calling those one by one), using caller-provided buffers:
+ *   save     what the forward leaves for the backward; must persist (and not be written) between the two calls
+ *   scratch  transient; only has to outlive the kernels one call enqueues (a single per-stream buffer will do)
+ * sizes: pngpd_*_train_save_bytes / _scratch_bytes of the same descriptor (only the dimension / mode fields are read).
+ * No allocation, no synchronisation, no retained pointers.  Gradient outputs are written, not accumulated.
+ * ======================================================================================= */
+typedef struct pngpd_trunk_train {
+    const float *x;        /* (B,3,N) clouds                                                                       */
+    const float *trans;    /* (B,3,3) per-cloud input transform (PointNetfeat, pointnet.py:140-143) or NULL (STN3d) */
+    int B, N;
+    int S;                 /* workgroups per cloud, 1 <= S <= ceil(N/64) (pngpd_trunk_splits)                        */
+    int relu_last;         /* ReLU after bn3 (STN3d trunk, pointnet.py:31) or not (PointNetfeat, :147)               */
+    int precision;         /* arithmetic of the contractions: 0 fp32 (exact), 3 bf16x3, 1 plain bf16                 */
+    int fp32_side;         /* precision != 0: keep passes B / gather / D / E on the fp32 kernels                     */
+    int need_bwd;          /* forward: a backward will follow (keep z2 and the transposed layer-2 weights)           */
+    float eps, momentum;   /* of the three BatchNorm1d layers                                                        */
+    const float *w1, *b1, *g1, *be1;   /* conv1.weight (64,3), conv1.bias, bn1.weight, bn1.bias                      */
+    const float *w2, *b2, *g2, *be2;   /* conv2 (128,64) ...                                                         */
+    const float *w3, *b3, *g3, *be3;   /* conv3 (1024,128) ...                                                       */
+    float *rm1, *rv1; long long *nbt1; /* bnX.running_mean / running_var / num_batches_tracked, updated in place by  */
+    float *rm2, *rv2; long long *nbt2; /* the forward like nn.BatchNorm1d (momentum, unbiased variance); all nullable */
+    float *rm3, *rv3; long long *nbt3;
+    float *pooled;         /* (B,1024) forward output: max over N of bn3(conv3(..)) [ReLU]                           */
+    int *idx;              /* (B,1024) forward output: arg-extremum point of every (cloud, channel)                  */
+    float *zhat;           /* (B,1024) forward output: normalised pre-affine value at that point                     */
+    const float *dp;       /* (B,1024) backward input: dL/dpooled                                                    */
+    float *dW1, *db1, *dg1, *dbe1;     /* backward outputs, shaped like the parameters; the conv-bias gradients are  */
+    float *dW2, *db2, *dg2, *dbe2;     /* exactly zero ahead of a train-mode BatchNorm and are written as zeros (db*  */
+    float *dW3, *db3, *dg3, *dbe3;     /* may be NULL)                                                               */
+    float *dT;             /* (B,3,3) dL/dtrans or NULL                                                              */
+    void *save;    size_t save_bytes;
+    void *scratch; size_t scratch_bytes;
+} pngpd_trunk_train_t;
+
+size_t pngpd_trunk_train_save_bytes(const pngpd_trunk_train_t *a);      /* reads B, N, S, precision, fp32_side */
+size_t pngpd_trunk_train_scratch_bytes(const pngpd_trunk_train_t *a);
+/* forward: x [, trans], parameters -> pooled, idx, zhat; running statistics updated */
+int pngpd_trunk_train_fwd(const pngpd_trunk_train_t *a, void *stream);
+/* backward: dp + the forward's pooled / idx / zhat / save -> dW*, db*, dg*, dbe* [, dT] */
+int pngpd_trunk_train_bwd(const pngpd_trunk_train_t *a, void *stream);
+
+typedef struct pngpd_head_train {
+    const float *inp;      /* (B,K0) pooled features                                                                 */
+    int B, K0, H1, H2, k;  /* fc1 (H1,K0), fc2 (H2,H1), fc3 (k,H2): 1024 / 512 / 256 / 9 or classes                  */
+    int epilogue;          /* PNGPD_EPI_ADD_IDEN3 (pointnet.py:37-43), PNGPD_EPI_LOG_SOFTMAX (:194) or PNGPD_EPI_NONE */
+    float eps, momentum;
+    const float *W1, *b1, *g1, *be1;   /* fc1.weight, fc1.bias, bn.weight, bn.bias                                   */
+    const float *W2, *b2, *g2, *be2;
+    const float *W3, *b3;
+    float *rm1, *rv1; long long *nbt1;
+    float *rm2, *rv2; long long *nbt2;
+    float *out;            /* (B,k) forward output (read again by the backward of log_softmax)                       */
+    const float *gout;     /* (B,k) backward input: dL/dout                                                          */
+    float *dinp;           /* (B,K0) backward output or NULL                                                         */
+    float *dW1, *db1, *dg1, *dbe1, *dW2, *db2, *dg2, *dbe2, *dW3, *db3;
+    void *save;    size_t save_bytes;
+    void *scratch; size_t scratch_bytes;   /* backward only */
+} pngpd_head_train_t;
+
+size_t pngpd_struct_bytes(int which);   /* sizeof of pngpd_trunk_train_t (0) / pngpd_head_train_t (1): FFI self-check */
+size_t pngpd_head_train_save_bytes(const pngpd_head_train_t *a);        /* reads B, H1, H2 */
+size_t pngpd_head_train_scratch_bytes(const pngpd_head_train_t *a);     /* reads B, H1, H2, k */
+int pngpd_head_train_fwd(const pngpd_head_train_t *a, void *stream);
+int pngpd_head_train_bwd(const pngpd_head_train_t *a, void *stream);
+
+/* Adam (main_1v.py:61 `optim.Adam(model.parameters(), lr=args.lr)`; torch defaults otherwise) over ONE flat
+ * parameter / gradient / first-moment / second-moment buffer of n fp32 values (16-byte aligned), one launch:
+ *   g' = gscale*g [/ max(*gdiv_dev, 1): a device-resident divisor, e.g. the all-reduced sample count];
+ *   m += (g'-m)(1-beta1);  v = beta2 v + (1-beta2) g'^2;
+ *   p -= lr/(1-beta1^t) * m / (sqrt(v)/sqrt(1-beta2^t) + eps)
+ * t = `step` (>= 1, the count of THIS update) unless step_dev != NULL, lr likewise overridden by lr_dev: device-resident
+ * scalars (fp32) for captured graphs; pngpd_adam_step_inc advances step_dev by one.                                  */
+int pngpd_adam_flat(float *p, const float *g, float *m, float *v, long long n, float lr, const float *lr_dev,
+                    float beta1, float beta2, float eps, float step, const float *step_dev, float gscale,
+                    const float *gdiv_dev, void *stream);
+int pngpd_adam_step_inc(float *step_dev, void *stream);
 
 /* =======================================================================================
  * Batched in-gripper crop + resample (upstream of the scorer).

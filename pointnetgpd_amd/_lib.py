@@ -9,13 +9,38 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PNGPD_LIB") or os.path.join(_HERE, "libpngpd.so")   # PNGPD_LIB: A/B builds only
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 _load_error = None
 
 c_f32p = ctypes.c_void_p
 c_void = ctypes.c_void_p
+
+_P, _I, _F, _Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+
+class TrunkTrainArgs(ctypes.Structure):
+    """``pngpd_trunk_train_t`` of include/pngpd.h (field for field)."""
+    _fields_ = ([("x", _P), ("trans", _P), ("B", _I), ("N", _I), ("S", _I), ("relu_last", _I), ("precision", _I),
+                 ("fp32_side", _I), ("need_bwd", _I), ("eps", _F), ("momentum", _F)] +
+                [(n, _P) for n in ("w1", "b1", "g1", "be1", "w2", "b2", "g2", "be2", "w3", "b3", "g3", "be3",
+                                   "rm1", "rv1", "nbt1", "rm2", "rv2", "nbt2", "rm3", "rv3", "nbt3",
+                                   "pooled", "idx", "zhat", "dp",
+                                   "dW1", "db1", "dg1", "dbe1", "dW2", "db2", "dg2", "dbe2", "dW3", "db3", "dg3", "dbe3",
+                                   "dT")] +
+                [("save", _P), ("save_bytes", _Z), ("scratch", _P), ("scratch_bytes", _Z)])
+
+
+class HeadTrainArgs(ctypes.Structure):
+    """``pngpd_head_train_t`` of include/pngpd.h (field for field)."""
+    _fields_ = ([("inp", _P), ("B", _I), ("K0", _I), ("H1", _I), ("H2", _I), ("k", _I), ("epilogue", _I),
+                 ("eps", _F), ("momentum", _F)] +
+                [(n, _P) for n in ("W1", "b1", "g1", "be1", "W2", "b2", "g2", "be2", "W3", "b3",
+                                   "rm1", "rv1", "nbt1", "rm2", "rv2", "nbt2", "out", "gout", "dinp",
+                                   "dW1", "db1", "dg1", "dbe1", "dW2", "db2", "dg2", "dbe2", "dW3", "db3")] +
+                [("save", _P), ("save_bytes", _Z), ("scratch", _P), ("scratch_bytes", _Z)])
+
 
 # name -> (restype, argtypes); mirrors include/pngpd.h one-to-one (checked by tests).
 SIGNATURES = {
@@ -87,6 +112,20 @@ SIGNATURES = {
                                         c_void, c_void, c_void, c_void]),
     "pngpd_dw1_finalize": (ctypes.c_int, [c_void, c_void, c_void, ctypes.c_int, ctypes.c_int] + [c_void] * 5 +
                            [ctypes.c_float] + [c_void] * 4 + [c_void]),
+    # ---- one entry per direction of the training graph + flat Adam
+    "pngpd_struct_bytes": (ctypes.c_size_t, [ctypes.c_int]),
+    "pngpd_trunk_train_save_bytes": (ctypes.c_size_t, [c_void]),
+    "pngpd_trunk_train_scratch_bytes": (ctypes.c_size_t, [c_void]),
+    "pngpd_trunk_train_fwd": (ctypes.c_int, [c_void, c_void]),
+    "pngpd_trunk_train_bwd": (ctypes.c_int, [c_void, c_void]),
+    "pngpd_head_train_save_bytes": (ctypes.c_size_t, [c_void]),
+    "pngpd_head_train_scratch_bytes": (ctypes.c_size_t, [c_void]),
+    "pngpd_head_train_fwd": (ctypes.c_int, [c_void, c_void]),
+    "pngpd_head_train_bwd": (ctypes.c_int, [c_void, c_void]),
+    "pngpd_adam_flat": (ctypes.c_int, [c_void] * 4 + [ctypes.c_longlong, ctypes.c_float, c_void, ctypes.c_float,
+                                                      ctypes.c_float, ctypes.c_float, ctypes.c_float, c_void,
+                                                      ctypes.c_float, c_void, c_void]),
+    "pngpd_adam_step_inc": (ctypes.c_int, [c_void, c_void]),
     # ---- crop / resample
     "pngpd_crop_count_compact": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, ctypes.c_int,
                                                 ctypes.c_int, c_void, c_void, c_void]),

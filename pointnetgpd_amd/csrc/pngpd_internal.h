@@ -1,0 +1,25 @@
+// Library-internal launch helpers shared by pngpd_train_glue.hip (kernels) and pngpd_train_step.hip (the fused
+// per-direction training entries).  Not part of the C ABI.
+#pragma once
+#include "pngpd_common.h"
+
+enum { RF_F64 = 0, RF_F32 = 1, RF_BN2 = 2, RF_BN3 = 3, RF_EPREP = 4, RF_ZERO = 5 };
+
+// One segment of reduce_fin_kernel: in (outer, R, n[, planes]) fp32 partials; operands of the finalize kinds:
+//   RF_BN2:   p0 = b2, p1 = g2, p2 = be2, rm / rv / nbt, f0 = chan2 (4,128), s0 = stats2 f64[256]
+//   RF_BN3:   p0 = b3, p1 = g3, rm / rv / nbt, s0 = stats3 f64[2048]
+//   RF_EPREP: p0 = g2, d0 = stats2, f0 = dg2, f1 = dbe2, f2 = evec (3,128)
+//   RF_ZERO:  f0 (64), f1 (128), f2 (1024) zero-filled (any may be NULL)
+struct RFSeg {
+    const float *in; void *out; int outer, R, n, bpo, kind;
+    const float *p0, *p1, *p2; const double *d0;
+    float *rm, *rv; long long *nbt;
+    float *f0, *f1, *f2; double *s0;
+};
+struct RFArgs { RFSeg seg[4]; int first[5]; double M, eps, momentum; };
+int pngpd_reduce_fin_launch(RFArgs &A, int nseg, void *stream);
+
+#define PACK_MAX_JOBS 6
+struct PackJob { const float *W; const float *sgn_src; void *out; int C, K, transpose, src_packed, fmt; };
+struct PackArgs { PackJob job[PACK_MAX_JOBS]; int first[PACK_MAX_JOBS + 1]; };
+int pngpd_train_pack_launch(PackArgs &A, int njobs, void *stream);

@@ -5,6 +5,7 @@
 // autograd by tests/train_algo_prototype.py).  Everything here is tiny (<= 1024x128 matrices); the point is
 // to replace ~500 launch-bound framework ops per step by ~40 kernels on the same stream.
 #include "pngpd_common.h"
+#include "pngpd_internal.h"
 
 #define NT 256
 
@@ -116,13 +117,12 @@ __global__ __launch_bounds__(NT) void bn1_finalize_kernel(
 // BN2: tot (128,2) f64 = sum / sum of squares of z2 (pngpd_reduce_partials of the pass-B partials)
 //   -> chan (4,128) f32 = s2c,t2c,is2,nm2 ; stats f64 = mu2r[128], var2[128]
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void bn2_finalize_kernel(
-    const double *__restrict__ tot, double M, const float *__restrict__ b2,
-    const float *__restrict__ g2, const float *__restrict__ be2, double eps, double momentum,
-    float *rm, float *rv, long long *nbt, float *__restrict__ chan, double *__restrict__ stats) {
-    const int c = threadIdx.x;
-    const double mu = tot[c * 2] / M;
-    double var = tot[c * 2 + 1] / M - mu * mu;
+__device__ __forceinline__ void bn2_fin(int c, double sum, double sq, double M, const float *__restrict__ b2,
+                                        const float *__restrict__ g2, const float *__restrict__ be2, double eps,
+                                        double momentum, float *rm, float *rv, long long *nbt,
+                                        float *__restrict__ chan, double *__restrict__ stats) {
+    const double mu = sum / M;
+    double var = sq / M - mu * mu;
     var = var > 0.0 ? var : 0.0;
     const double is = 1.0 / sqrt(var + eps);
     const double sc = (double)g2[c] * is;
@@ -136,23 +136,37 @@ __global__ __launch_bounds__(128) void bn2_finalize_kernel(
     if (c == 0 && nbt) *nbt += 1;
 }
 
+__global__ __launch_bounds__(128) void bn2_finalize_kernel(
+    const double *__restrict__ tot, double M, const float *__restrict__ b2,
+    const float *__restrict__ g2, const float *__restrict__ be2, double eps, double momentum,
+    float *rm, float *rv, long long *nbt, float *__restrict__ chan, double *__restrict__ stats) {
+    const int c = threadIdx.x;
+    bn2_fin(c, tot[c * 2], tot[c * 2 + 1], M, b2, g2, be2, eps, momentum, rm, rv, nbt, chan, stats);
+}
+
 // ---------------------------------------------------------------------------------------
 // BN3: tot (2,1024) f64 (pngpd_reduce_partials of the pass-C psum) -> stats f64 = mu3s[1024], var3[1024]
 // (of the sign-folded z3s)
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void bn3_finalize_kernel(
-    const double *__restrict__ tot /* (2,1024) */, double M, const float *__restrict__ b3,
-    const float *__restrict__ g3, double momentum, float *rm, float *rv, long long *nbt,
-    double *__restrict__ stats) {
-    const int c = blockIdx.x * NT + threadIdx.x;
-    const double mu = tot[c] / M;
-    double var = tot[1024 + c] / M - mu * mu;
+__device__ __forceinline__ void bn3_fin(int c, double sum, double sq, double M, const float *__restrict__ b3,
+                                        const float *__restrict__ g3, double momentum, float *rm, float *rv,
+                                        long long *nbt, double *__restrict__ stats) {
+    const double mu = sum / M;
+    double var = sq / M - mu * mu;
     var = var > 0.0 ? var : 0.0;
     stats[c] = mu;
     stats[1024 + c] = var;
     const double sgn = g3[c] >= 0.f ? 1.0 : -1.0;
     running_update(rm, rv, c, sgn * mu + (double)b3[c], var, M, momentum);
     if (c == 0 && nbt) *nbt += 1;
+}
+
+__global__ __launch_bounds__(NT) void bn3_finalize_kernel(
+    const double *__restrict__ tot /* (2,1024) */, double M, const float *__restrict__ b3,
+    const float *__restrict__ g3, double momentum, float *rm, float *rv, long long *nbt,
+    double *__restrict__ stats) {
+    const int c = blockIdx.x * NT + threadIdx.x;
+    bn3_fin(c, tot[c], tot[1024 + c], M, b3, g3, momentum, rm, rv, nbt, stats);
 }
 
 // pooled[b][c] = (relu?)(g3 * zhat + be3), zhat = sgn*(max_s pmax - mu3s)/sig3 ; idx = arg of the max
@@ -393,14 +407,19 @@ __global__ __launch_bounds__(512) void a_cvec_finalize_kernel(
 
 // a12 (128,2) f64 = sum g2, sum g2*zhat2  ->  dg2 = a2, dbe2 = a1 and the pass-E vectors
 //   evec (3,128) f32 = a1/M, a2/M, g2/sig2.
+__device__ __forceinline__ void e_prep_fin(int o, double a1, double a2, double M, const float *__restrict__ g2,
+                                           const double *__restrict__ stats2, double eps, float *__restrict__ dg2,
+                                           float *__restrict__ dbe2, float *__restrict__ evec) {
+    dg2[o] = (float)a2; dbe2[o] = (float)a1;
+    evec[o] = (float)(a1 / M); evec[128 + o] = (float)(a2 / M);
+    evec[256 + o] = (float)((double)g2[o] / sqrt(stats2[128 + o] + eps));
+}
+
 __global__ __launch_bounds__(128) void bwd_e_prep_kernel(
     const double *__restrict__ a12, double M, const float *__restrict__ g2, const double *__restrict__ stats2,
     double eps, float *__restrict__ dg2, float *__restrict__ dbe2, float *__restrict__ evec) {
     const int o = threadIdx.x;
-    const double a1 = a12[o * 2], a2 = a12[o * 2 + 1];
-    dg2[o] = (float)a2; dbe2[o] = (float)a1;
-    evec[o] = (float)(a1 / M); evec[128 + o] = (float)(a2 / M);
-    evec[256 + o] = (float)((double)g2[o] / sqrt(stats2[128 + o] + eps));
+    e_prep_fin(o, a12[o * 2], a12[o * 2 + 1], M, g2, stats2, eps, dg2, dbe2, evec);
 }
 
 // dW1[c][j] = s1 (Rp[c][j] - c1 mx[j] - (c2/sig1) (W1 Cx)[c][j]),  Rp = sum_b Rb[b] T_b  (or sum_b Rb[b])
@@ -479,6 +498,191 @@ __global__ __launch_bounds__(64) void dtrans_finalize_kernel(
         dT[(size_t)b * 9 + c] = (float)s;
     }
 }
+
+// ---------------------------------------------------------------------------------------
+// Fused reduce + finalize: the deterministic fp64 reduction of up to four partial buffers of ONE training pass
+// (the reduce_partials_multi_kernel scheme: 32 columns x 32 row lanes per workgroup, fixed-order LDS tree) with the
+// per-channel finalize of the pass applied by the workgroup that owns the channel's totals — one launch where the
+// step used to make two to four (reduce, finalize, cast, fills).  The arithmetic of every output is the arithmetic
+// of the separate kernels above (same reduction order, same bn2_fin / bn3_fin / e_prep_fin), so both ways of
+// sequencing a step give bit-identical results.
+//   RF_F64 / RF_F32  out[o][j] = sum_r in[o][r][j]            (fp64 / rounded once to fp32)
+//   RF_BN2           in (blk,128,2) pass-B partials -> bn2_fin per channel      (pngpd_bn2_finalize)
+//   RF_BN3           in (blk,2,1024) pass-C partials -> bn3_fin per channel     (pngpd_bn3_finalize)
+//   RF_EPREP         in (blk,128,2) pass-D partials -> e_prep_fin per channel   (pngpd_bwd_e_prep)
+//   RF_ZERO          no input: f0[64] = f1[128] = f2[1024] = 0 (the exactly-zero gradients of conv biases ahead of a
+//                    train-mode BatchNorm)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void reduce_fin_kernel(RFArgs A) {
+    __shared__ double red[32][33];
+    __shared__ double tot[32];
+    int g = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) g += ((int)blockIdx.x >= A.first[i]) ? 1 : 0;
+    const RFSeg sg = A.seg[g];
+    const int lb = blockIdx.x - A.first[g];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    if (sg.kind == RF_ZERO) {
+        const int t = threadIdx.x;
+        if (t < 64 && sg.f0) sg.f0[t] = 0.f;
+        if (t < 128 && sg.f1) sg.f1[t] = 0.f;
+        if (sg.f2) sg.f2[t] = 0.f;
+        return;
+    }
+    const int o = lb / sg.bpo, jb = lb - o * sg.bpo;
+    const int j = jb * 32 + cx;
+    const int planes = sg.kind == RF_BN3 ? 2 : 1;
+    const size_t stride = (size_t)sg.n * planes;
+    double t[2] = {0.0, 0.0};
+    for (int pl = 0; pl < planes; ++pl) {
+        double s = 0.0;
+        if (j < sg.n) {
+            const float *p = sg.in + (size_t)o * sg.R * stride + (size_t)pl * sg.n + j;
+            for (int r = ry; r < sg.R; r += 32) s += (double)p[(size_t)r * stride];
+        }
+        if (pl) __syncthreads();
+        red[ry][cx] = s;
+        __syncthreads();
+        if (ry == 0) {
+            double a = 0.0;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) a += red[i][cx];
+            t[pl] = a;
+        }
+    }
+    if (sg.kind == RF_F64) {
+        if (ry == 0 && j < sg.n) ((double *)sg.out)[(size_t)o * sg.n + j] = t[0];
+    } else if (sg.kind == RF_F32) {
+        if (ry == 0 && j < sg.n) ((float *)sg.out)[(size_t)o * sg.n + j] = (float)t[0];
+    } else if (sg.kind == RF_BN3) {
+        if (ry == 0 && j < sg.n) bn3_fin(j, t[0], t[1], A.M, sg.p0, sg.p1, A.momentum, sg.rm, sg.rv, sg.nbt, sg.s0);
+    } else {   // RF_BN2 / RF_EPREP: columns (2c, 2c+1) = the two sums of channel c
+        if (ry == 0) tot[cx] = t[0];
+        __syncthreads();
+        if (ry == 0 && cx < 16) {
+            const int c = jb * 16 + cx;
+            if (sg.kind == RF_BN2)
+                bn2_fin(c, tot[2 * cx], tot[2 * cx + 1], A.M, sg.p0, sg.p1, sg.p2, A.eps, A.momentum, sg.rm, sg.rv,
+                        sg.nbt, sg.f0, sg.s0);
+            else
+                e_prep_fin(c, tot[2 * cx], tot[2 * cx + 1], A.M, sg.p0, sg.d0, A.eps, sg.f0, sg.f1, sg.f2);
+        }
+    }
+}
+
+int pngpd_reduce_fin_launch(RFArgs &A, int nseg, void *stream) {
+    int total = 0;
+    for (int g = 0; g < 4; ++g) {
+        A.first[g] = total;
+        if (g >= nseg) { A.seg[g] = RFSeg{}; A.seg[g].bpo = 1; continue; }
+        RFSeg &s = A.seg[g];
+        if (s.kind == RF_ZERO) { s.bpo = 1; total += 1; continue; }
+        if (!s.in || s.outer <= 0 || s.R <= 0 || s.n <= 0) return PNGPD_ERR_INVALID_ARG;
+        s.bpo = (s.n + 31) / 32;
+        total += s.outer * s.bpo;
+    }
+    A.first[4] = total;
+    if (total == 0) return PNGPD_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(reduce_fin_kernel, dim3(total), dim3(1024), 0, (hipStream_t)stream, A);
+    return pngpd_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------
+// Weight re-layout for the training passes, every matrix of a trunk in ONE launch (the step used to make one
+// fold_conv_bn / split_pack launch per matrix plus a transposed copy and a sign tensor):
+//   logical matrix Mx (C,K) = W (transpose: W is (K,C) row-major and Mx = W^T; src_packed: W is the MFMA_B-packed
+//   128x128 matrix pngpd_a_cvec_finalize writes), rows scaled by sign(sgn_src[c]) (+1 for >= 0: the sign fold of W3),
+//   written MFMA_B-packed fp32 (fmt 0, pngpd_fold_conv_bn's layout) or as split_pack_bf16 fragments (fmt 1).
+// ---------------------------------------------------------------------------------------
+__global__ void train_pack_kernel(PackArgs A) {
+    int g = 0;
+#pragma unroll
+    for (int i = 1; i < PACK_MAX_JOBS; ++i) g += ((int)blockIdx.x >= A.first[i]) ? 1 : 0;
+    const PackJob jb = A.job[g];
+    const int idx = (blockIdx.x - A.first[g]) * 256 + threadIdx.x;
+    if (idx >= jb.C * jb.K) return;
+    const int c = idx / jb.K, k = idx - c * jb.K;
+    float v;
+    if (jb.src_packed) {
+        const int cb = c >> 5, jj = c & 31, kb = k >> 3, h = (k >> 2) & 1, t = k & 3;
+        v = jb.W[(((cb * (jb.K >> 3) + kb) * 64) + h * 32 + jj) * 4 + t];
+    } else {
+        v = jb.transpose ? jb.W[(size_t)k * jb.C + c] : jb.W[idx];
+    }
+    if (jb.sgn_src) v = jb.sgn_src[c] >= 0.f ? v : -v;
+    if (jb.fmt == 0) {
+        const int cb = c >> 5, j = c & 31, kb = k >> 3, h = (k >> 2) & 1, t = k & 3;
+        ((float *)jb.out)[(((cb * (jb.K >> 3) + kb) * 64) + h * 32 + j) * 4 + t] = v;
+    } else {
+        const unsigned short hi = __builtin_bit_cast(unsigned short, (__bf16)v);
+        const float hv = __uint_as_float(((unsigned)hi) << 16);
+        const unsigned short lo = __builtin_bit_cast(unsigned short, (__bf16)(v - hv));
+        const int cb = c >> 5, j = c & 31, ks = k >> 4, h = (k >> 3) & 1, t = k & 7, KS = jb.K >> 4;
+        const size_t base = ((size_t)(cb * KS + ks) * 2) * 64 * 8 + (size_t)(h * 32 + j) * 8 + t;
+        ((unsigned short *)jb.out)[base] = hi;
+        ((unsigned short *)jb.out)[base + 64 * 8] = lo;
+    }
+}
+
+int pngpd_train_pack_launch(PackArgs &A, int njobs, void *stream) {
+    if (njobs <= 0 || njobs > PACK_MAX_JOBS) return PNGPD_ERR_INVALID_ARG;
+    int total = 0;
+    for (int g = 0; g < PACK_MAX_JOBS; ++g) {
+        A.first[g] = total;
+        if (g >= njobs) { A.job[g] = PackJob{}; continue; }
+        const PackJob &j = A.job[g];
+        if (!j.W || !j.out || j.C <= 0 || j.K <= 0 || (j.C & 31) || (j.K & (j.fmt ? 15 : 7))) return PNGPD_ERR_INVALID_ARG;
+        total += (j.C * j.K + 255) / 256;
+    }
+    A.first[PACK_MAX_JOBS] = total;
+    hipLaunchKernelGGL(train_pack_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, A);
+    return pngpd_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------
+// Adam over ONE flat parameter / gradient / moment buffer (main_1v.py:61 `optim.Adam(model.parameters(), lr)` —
+// torch's defaults: betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad), the single-tensor update of
+// torch/optim/adam.py in fp32:
+//   m += (g - m)(1 - b1);  v = b2 v + (1 - b2) g g;  p -= (lr / (1 - b1^t)) m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// lr_dev / step_dev (nullable) are device-resident values for captured graphs (StepLR rewrites lr in place;
+// step_dev holds the step count t of THIS update as a float, advanced by pngpd_adam_step_inc).  The gradient is first
+// multiplied by gscale and, if gdiv_dev is given, divided by max(*gdiv_dev, 1) — the all-reduced kept-sample count of
+// a data-parallel step, which never has to visit the host.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_flat_kernel(float *__restrict__ p, const float *__restrict__ g,
+                                                        float *__restrict__ m, float *__restrict__ v, long n,
+                                                        float lr_host, const float *__restrict__ lr_dev, float b1,
+                                                        float b2, float eps, float step_host,
+                                                        const float *__restrict__ step_dev, float gscale,
+                                                        const float *__restrict__ gdiv_dev) {
+    if (gdiv_dev) gscale /= fmaxf(*gdiv_dev, 1.f);
+    const float lr = lr_dev ? *lr_dev : lr_host;
+    const float t = step_dev ? *step_dev : step_host;
+    const float bc1 = 1.f - powf(b1, t), bc2s = sqrtf(1.f - powf(b2, t));
+    const float step_size = lr / bc1;
+    const long i0 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 + 4 <= n) {
+        f32x4 pv = *(f32x4 *)(p + i0), gv = *(const f32x4 *)(g + i0), mv = *(f32x4 *)(m + i0), vv = *(f32x4 *)(v + i0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gg = gv[e] * gscale;
+            mv[e] = mv[e] + (gg - mv[e]) * (1.f - b1);
+            vv[e] = vv[e] * b2 + (1.f - b2) * gg * gg;
+            pv[e] = pv[e] - step_size * (mv[e] / (sqrtf(vv[e]) / bc2s + eps));
+        }
+        *(f32x4 *)(p + i0) = pv; *(f32x4 *)(m + i0) = mv; *(f32x4 *)(v + i0) = vv;
+    } else {
+        for (long i = i0; i < n; ++i) {
+            const float gg = g[i] * gscale;
+            const float mm = m[i] + (gg - m[i]) * (1.f - b1);
+            const float vq = v[i] * b2 + (1.f - b2) * gg * gg;
+            m[i] = mm; v[i] = vq;
+            p[i] = p[i] - step_size * (mm / (sqrtf(vq) / bc2s + eps));
+        }
+    }
+}
+
+__global__ void adam_step_inc_kernel(float *step) { *step += 1.f; }
 
 // ---------------------------------------------------------------------------------------
 // C ABI
@@ -594,6 +798,22 @@ int pngpd_dw1_finalize(const double *Rb, const float *trans, const double *mom, 
     if (st != PNGPD_OK || !dT) return st;
     LAUNCH(dtrans_finalize_kernel, dim3(B), dim3(64), Rb, trans, mom, (double)B * N, c12, stats1, w1, b1, g1,
            (double)eps, dT);
+}
+
+int pngpd_adam_flat(float *p, const float *g, float *m, float *v, long long n, float lr, const float *lr_dev,
+                    float beta1, float beta2, float eps, float step, const float *step_dev, float gscale,
+                    const float *gdiv_dev, void *stream) {
+    if (!p || !g || !m || !v || n <= 0 || (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15))
+        return PNGPD_ERR_INVALID_ARG;
+    if (!step_dev && step < 1.f) return PNGPD_ERR_INVALID_ARG;
+    const long quads = ((long)n + 3) / 4;
+    LAUNCH(adam_flat_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), p, g, m, v, (long)n, lr, lr_dev, beta1,
+           beta2, eps, step, step_dev, gscale, gdiv_dev);
+}
+
+int pngpd_adam_step_inc(float *step_dev, void *stream) {
+    if (!step_dev) return PNGPD_ERR_INVALID_ARG;
+    LAUNCH(adam_step_inc_kernel, dim3(1), dim3(1), step_dev);
 }
 
 }  // extern "C"

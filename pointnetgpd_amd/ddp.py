@@ -1,32 +1,46 @@
-"""Data-parallel training helper: one process per GPU, gradients averaged with ONE flat all-reduce
-(RCCL over xGMI on MI355X — backend "nccl" is RCCL on ROCm; "gloo" for the CPU tests).
+"""Data-parallel training helper: one process per GPU, gradients combined with RCCL all-reduces over xGMI
+(backend "nccl" IS RCCL on ROCm; "gloo" for the CPU tests).
 
 Replaces the reference's single-process ``nn.DataParallel(model, device_ids=[0,1,2,3])``
 (PointNetGPD/main_1v.py:158-165, main_fullv.py:104-111):
 
-* DataParallel re-broadcasts the 6.4 MB of parameters on every forward and reduces gradients onto
-  device 0; here every rank owns a replica, parameters are broadcast once, and the 1,604,363
-  gradients travel as one 6.4 MB bucket (at 8 GPUs a ring all-reduce moves 2*(7/8)*6.4 MB per GPU —
-  tens of microseconds on 7x153 GB/s xGMI links, small against a ~15 ms step).
-* BatchNorm statistics stay per replica, exactly as under DataParallel; running
-  statistics of rank 0 are broadcast before each forward (``broadcast_buffers``), which is what
-  DataParallel's replica-0-wins behaviour amounts to.
+* DataParallel re-broadcasts the 6.4 MB of parameters on every forward and reduces gradients onto device 0; here
+  every rank owns a replica, parameters are broadcast once, and the 1,604,363 gradients travel in place.
+* **Per-sample mean over the GLOBAL batch**, as DataParallel's gathered ``nll_loss`` gives: ranks back-propagate the
+  SUM of their samples' losses, the all-reduce adds gradients and kept-sample counts, and the optimizer divides by the
+  global count.  ``my_collate`` drops ``None`` samples independently on every rank, so per-rank batches are ragged; a
+  rank left with fewer than two samples (train-mode BatchNorm needs two) contributes zeros and still joins every
+  collective — nobody hangs.
+* With ``optim.FlatAdam`` attached the gradients already live in one flat buffer: the all-reduce runs on slices of it
+  (no gather / scatter copies) in TWO buckets — the PointNetCls head + PointNetfeat trunk slice leaves as soon as the
+  backward has produced ``d loss / d trans`` (a tensor hook on the STN output), overlapping the STN backward; the
+  STN slice (plus the sample count) follows at the end.
+* BatchNorm statistics stay per replica, exactly as under DataParallel.  Train-mode forwards never
+  read running statistics, so nothing is broadcast per step: ``sync_buffers()`` makes rank 0's running statistics
+  everyone's before ``eval()`` / a checkpoint — the observable behaviour of DataParallel's replica-0-wins.
 """
 import torch
 import torch.distributed as dist
 
 
 class GradAverager:
-    def __init__(self, model, process_group=None, broadcast_buffers=True):
+    def __init__(self, model, process_group=None, optimizer=None):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.model = model
         self.group = process_group
         self.world = dist.get_world_size(process_group)
-        self.broadcast_buffers = broadcast_buffers
         self.params = [p for p in model.parameters() if p.requires_grad]
+        self.opt = None
+        self._pending = []
+        self._hooked = False
+        self._early = None          # (offset, length) of the bucket that can leave mid-backward
+        self._late = None
         self.sync_parameters()
+        if optimizer is not None:
+            self.attach(optimizer)
 
+    # ---- replicas ---------------------------------------------------------------------------------------------
     def sync_parameters(self):
         """Rank 0's parameters and buffers become everyone's (done once, and after a checkpoint load)."""
         with torch.no_grad():
@@ -38,8 +52,8 @@ class GradAverager:
 
     def sync_buffers(self):
         """Rank 0's BatchNorm buffers become everyone's: ONE broadcast of the 7,936 running statistics (flattened)
-        and one of the 10 ``num_batches_tracked`` counters — not 30 small collectives per forward."""
-        if not self.broadcast_buffers or self.world == 1:
+        and one of the 10 ``num_batches_tracked`` counters.  Call before ``eval()`` / saving, not per step."""
+        if self.world == 1:
             return
         with torch.no_grad():
             bufs = list(self.model.buffers())
@@ -48,11 +62,95 @@ class GradAverager:
                 flat = torch.cat([b.reshape(-1) for b in group])
                 dist.broadcast(flat, src=0, group=self.group)
                 torch._foreach_copy_(group, [c.view_as(b) for c, b in zip(flat.split([b.numel() for b in group]), group)])
+                torch.autograd.graph.increment_version(group)
+
+    # ---- flat-buffer mode -------------------------------------------------------------------------------------
+    def attach(self, optimizer):
+        """Use ``optimizer``'s (optim.FlatAdam) flat gradient buffer for the collectives, in two buckets."""
+        self.opt = optimizer
+        self._count = torch.zeros(64, device=optimizer.device, dtype=torch.float32)
+        stn = getattr(getattr(self.model, "feat", None), "stn", None)
+        if stn is not None:
+            lo, n = optimizer.segment(list(stn.parameters()))
+            rest = [p for p in self.model.parameters() if not any(p is q for q in stn.parameters())]
+            lo2, n2 = optimizer.segment(rest)
+            if lo + n <= lo2 or lo2 + n2 <= lo:          # the two slices do not interleave
+                self._late, self._early = (lo, n), (lo2, n2)
+                if not self._hooked:
+                    stn.register_forward_hook(self._stn_forward_hook)
+                    self._hooked = True
+        if self._early is None:
+            self._late, self._early = (0, optimizer.numel), None
+
+    def _stn_forward_hook(self, module, inputs, output):
+        if self.opt is not None and self.world > 1 and torch.is_tensor(output) and output.requires_grad:
+            output.register_hook(self._early_ready)
+
+    def _early_ready(self, grad):
+        # d loss / d trans exists: the PointNetCls head and the PointNetfeat trunk have written their gradient slices
+        if self._early is not None and not self._skip:
+            lo, n = self._early
+            self._pending.append(dist.all_reduce(self.opt.flat_g[lo:lo + n], op=dist.ReduceOp.SUM, group=self.group,
+                                                 async_op=True))
+        return None
+
+    _skip = False
+
+    def backward(self, loss_sum, n_local):
+        """Back-propagate this rank's SUMMED loss (``n_local`` kept samples; ``loss_sum`` None or n_local < 2: the rank
+        sits this step out with zero gradients) and combine gradients across ranks.  Returns the global kept-sample
+        count as a 0-dim device tensor; the optimizer divides by it (``FlatAdam.step(grad_div=count)``), or call
+        ``finish()`` for plain ``p.grad`` means."""
+        self._pending = []
+        sit_out = loss_sum is None or n_local < 2
+        if self.opt is not None:
+            self._skip = False
+            if sit_out:
+                self.opt.flat_g.zero_()
+                self._skip = True            # no hook will fire: send the early bucket here
+                if self._early is not None:
+                    lo, n = self._early
+                    self._pending.append(dist.all_reduce(self.opt.flat_g[lo:lo + n], op=dist.ReduceOp.SUM,
+                                                         group=self.group, async_op=True))
+            else:
+                loss_sum.backward()
+            self._count.zero_()
+            self._count[0] = float(0 if sit_out else n_local)
+            lo, n = self._late
+            self._pending.append(dist.all_reduce(self.opt.flat_g[lo:lo + n], op=dist.ReduceOp.SUM, group=self.group,
+                                                 async_op=True))
+            self._pending.append(dist.all_reduce(self._count, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            for w in self._pending:
+                w.wait()                     # stream-ordered for NCCL/RCCL: no host block
+            self._pending = []
+            return self._count[0]
+        # generic parameters (CPU tests, foreign optimizers): one flat bucket built here, count in its last slot
+        if sit_out:
+            for p in self.params:
+                p.grad = torch.zeros_like(p)
+        else:
+            loss_sum.backward()
+        grads = []
+        for p in self.params:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            grads.append(p.grad)
+        cnt = torch.tensor([float(0 if sit_out else n_local)], device=grads[0].device, dtype=grads[0].dtype)
+        flat = torch.cat([g.reshape(-1) for g in grads] + [cnt])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        total = flat[-1].clamp_min(1.0)
+        flat[:-1].div_(total)
+        torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat[:-1].split([g.numel() for g in grads]), grads)])
+        return None                          # gradients are already the global per-sample mean
 
     def average_gradients(self):
-        """All-reduce(sum)/world of every parameter gradient through one flat bucket: one gather kernel, one
-        collective, one scale, one multi-tensor scatter."""
+        """All-reduce(sum)/world of every parameter gradient (equal per-rank batches; kept for callers that run
+        ``loss.backward()`` themselves): in place on the flat buffer when one is attached, else through one bucket."""
         if self.world == 1:
+            return
+        if self.opt is not None:
+            dist.all_reduce(self.opt.flat_g, op=dist.ReduceOp.SUM, group=self.group)
+            self.opt.flat_g.div_(self.world)
             return
         grads = []
         for p in self.params:

@@ -16,11 +16,16 @@ training, summed for eval; whole-module pickles ``<model-path>/<tag>_<epoch>.mod
 What changes: the reference's ``nn.DataParallel`` over ids [0,1,2,3] (``--gpu -1``) becomes one
 process per GPU under ``torchrun`` with an RCCL gradient all-reduce (``pointnetgpd_amd.ddp``);
 ``torch.load`` passes ``weights_only=False`` (whole-module pickles fail otherwise on torch >= 2.6).
-Additive flags: ``--seed --num-workers --synthetic --max-batches --persistent-optimizer``.
+On ``--cuda`` the optimizer is ``optim.FlatAdam`` — the same Adam (main_1v.py:61) over one flat HBM buffer, one
+launch per step, gradients written in place by the fused backward.  Running accuracy is accumulated on the device
+and read at ``--log-interval`` / epoch end instead of the reference's per-batch ``.cpu()`` (main_1v.py:78).
+Additive flags: ``--seed --num-workers --synthetic --max-batches --persistent-optimizer --precision --hip-graph
+--device-data``.
 """
 import argparse
 import json
 import os
+import pickle
 import time
 
 import numpy as np
@@ -73,6 +78,10 @@ def build_parser():
     p.add_argument("--device-data", action="store_true",
                    help="single-GPU --cuda: keep every cloud resident in HBM and crop/resample "
                         "training batches on the GPU (device_loader.DeviceGraspLoader) instead of DataLoader workers")
+    p.add_argument("--precision", choices=["fp32", "bf16x3", "bf16"], default="fp32",
+                   help="--cuda: arithmetic of the trunk contractions. fp32 = exact (default); bf16x3 = 3-term split "
+                        "bf16 products on the bf16 matrix cores (meets the fp32 parity bars); bf16 = plain bf16 "
+                        "operands and bf16 z2/g2 tiles (BASELINE configs[2]; does NOT meet 1e-3 in training)")
     p.add_argument("--log-dir", type=str, default="./assets/log/")
     return p
 
@@ -107,6 +116,11 @@ def worker_init_fn(pid):
 
 def my_collate(batch):
     batch = list(filter(lambda x: x is not None, batch))            # main_1v.py:48-50
+    if not batch:
+        # every sample of this (per-rank) batch was dropped: the reference's default_collate raises on the empty
+        # list; under one-process-per-GPU the peers would then wait in their collectives forever — hand the loop an
+        # empty batch instead (it sits the step out)
+        return None
     return torch.utils.data.dataloader.default_collate(batch)
 
 
@@ -172,22 +186,43 @@ def _make_loaders(cfg, args, world=1):
     return (torch.utils.data.DataLoader(tr, **common_tr), torch.utils.data.DataLoader(te, **common), sampler)
 
 
+class _RefPathPickler(pickle._Pickler):
+    """Pure-Python pickler (its ``save_global`` is overridable) that names this package's ``model.pointnet`` classes
+    by the REFERENCE's module path: no ``__module__`` rewriting, no ``sys.modules`` entry needed at save time, no
+    process-global state, thread-safe."""
+
+    def save_global(self, obj, name=None):
+        from .model import pointnet as pn
+        if isinstance(obj, type) and obj.__module__ == pn.__name__ and "." not in obj.__qualname__:
+            # the GLOBAL opcode (valid in every protocol) with the reference's module path
+            self.write(pickle.GLOBAL + b"model.pointnet\n" + obj.__qualname__.encode("utf-8") + b"\n")
+            self.memoize(obj)
+            return
+        return super().save_global(obj, name)
+
+    dispatch = dict(pickle._Pickler.dispatch)
+    dispatch[type] = save_global
+
+
+class _RefPathPickleModule:
+    """The ``pickle_module`` handed to ``torch.save`` (which only needs ``Pickler`` and ``__name__``)."""
+    __name__ = "pickle"
+    Pickler = _RefPathPickler
+
+
 def save_model(model, path):
     """Whole-module pickle like the reference's ``torch.save(model, path)`` (main_1v.py:177-178), written so that BOTH
     implementations can load it: the classes are pickled under the reference's module path ``model.pointnet`` (which
-    ``install_reference_aliases`` maps to this package, and which IS the reference's own module in its scripts —
-    kinect2grasp.py / main_test.py); the per-instance cache of folded inference weights is never pickled."""
-    from . import install_reference_aliases
-    from .model import pointnet as pn
-    install_reference_aliases()
-    classes = [c for c in vars(pn).values() if isinstance(c, type) and c.__module__ == pn.__name__]
+    ``install_reference_aliases`` maps to this package on load, and which IS the reference's own module in its
+    scripts — kinect2grasp.py / main_test.py); the per-instance cache of folded inference weights is never pickled.
+    A failure is reported, not raised: only rank 0 saves, and an exception here would strand the other ranks at the
+    next barrier."""
     try:
-        for c in classes:
-            c.__module__ = "model.pointnet"
-        torch.save(model, path)          # _HipModule.__getstate__ leaves the fold cache out
-    finally:
-        for c in classes:
-            c.__module__ = pn.__name__
+        torch.save(model, path, pickle_module=_RefPathPickleModule)   # _HipModule.__getstate__ drops the fold cache
+        return True
+    except Exception as e:      # noqa: BLE001
+        print(f"WARNING: could not save {path}: {type(e).__name__}: {e}")
+        return False
 
 
 def run(variant, argv=None):
@@ -223,6 +258,13 @@ def run(variant, argv=None):
         model = PointNetCls(num_points=cfg["num_points"], input_chann=3, k=cfg["k"])
     model = model.to(device)
     averager = ddp.GradAverager(model) if world > 1 else None
+    if args.cuda:
+        from . import train as _train
+        from .model import pointnet as _pn
+        _train.set_train_precision(args.precision)
+        _pn.set_inference_precision(args.precision)
+    elif args.precision != "fp32":
+        raise SystemExit("--precision needs --cuda (the CPU path is the plain ATen composite)")
 
     state = {"optimizer": None, "scheduler": None, "graph": None}
     use_graph = bool(args.hip_graph and args.cuda and averager is None)
@@ -230,12 +272,16 @@ def run(variant, argv=None):
         print("--hip-graph ignored (needs --cuda and a single process)")
 
     def new_optimizer():
-        if use_graph:      # capturable Adam with the lr in a device tensor: StepLR fills it in place
-            state["optimizer"] = optim.Adam(model.parameters(), lr=torch.tensor(float(args.lr), device=device),
-                                            capturable=True, fused=True)
+        if args.cuda:
+            # the same Adam (main_1v.py:61) over one flat buffer: one launch per step, gradients written in place by
+            # the fused backward; for a captured graph the lr lives in a device tensor (StepLR fills it in place)
+            from .optim import FlatAdam
+            lr = torch.tensor(float(args.lr), device=device) if use_graph else args.lr
+            state["optimizer"] = FlatAdam(model.parameters(), lr=lr, capturable=use_graph)
+            if averager is not None:
+                averager.attach(state["optimizer"])
         else:
-            # same Adam (main_1v.py:61); on the GPU the fused implementation: 2 launches instead of ~45
-            state["optimizer"] = optim.Adam(model.parameters(), lr=args.lr, fused=bool(args.cuda))
+            state["optimizer"] = optim.Adam(model.parameters(), lr=args.lr)
         state["scheduler"] = StepLR(state["optimizer"], step_size=30, gamma=0.5)
         state["graph"] = None
 
@@ -255,46 +301,75 @@ def run(variant, argv=None):
         torch.set_grad_enabled(True)
         if sampler is not None:
             sampler.set_epoch(epoch)
-        correct, dataset_size = 0, 0
-        for batch_idx, (data, target) in enumerate(train_loader):
+        # running accuracy stays on the device: one host read at the end of the epoch instead of the reference's
+        # per-batch ``.cpu()`` (main_1v.py:78), which serialises host and device every step
+        correct, dataset_size = torch.zeros((), dtype=torch.long, device=device), 0
+        loss = None
+        for batch_idx, batch in enumerate(train_loader):
             if args.max_batches and batch_idx >= args.max_batches:
                 break
-            dataset_size += data.shape[0]
-            data, target = data.float(), target.long().squeeze()
-            data, target = data.to(device), target.to(device)
-            if use_graph and data.shape[0] == args.rank_batch and target.dim() == 1:
+            n_local = 0 if batch is None else int(batch[0].shape[0])
+            if n_local:
+                data, target = batch[0].float(), batch[1].long().reshape(-1)
+                data, target = data.to(device), target.to(device)
+            dataset_size += n_local
+            runnable = n_local >= 2          # train-mode BatchNorm needs two samples (as nn.BatchNorm1d enforces)
+            output = None
+            if averager is not None:
+                # global per-sample mean (what DataParallel's gathered nll_loss computes): back-propagate the SUM
+                # of this rank's losses; the all-reduce adds gradients and kept-sample counts.  A rank whose batch
+                # was dropped to < 2 samples sends zeros and still joins the collectives.
+                optimizer.zero_grad()
+                loss_sum = None
+                if runnable:
+                    output, _ = model(data)
+                    loss_sum = F.nll_loss(output, target, reduction="sum")
+                    loss = loss_sum.detach() / n_local
+                total = averager.backward(loss_sum, n_local)
+                if total is not None:
+                    optimizer.step(grad_div=total)
+                else:
+                    optimizer.step()
+            elif not runnable:
+                if n_local == 1:
+                    raise ValueError("Expected more than 1 value per channel when training, got a batch of 1 "
+                                     "(the reference's BatchNorm1d raises here too)")
+                continue
+            elif use_graph and n_local == args.rank_batch:
                 if state["graph"] is None:
                     from .train import GraphedTrainStep
                     state["graph"] = GraphedTrainStep(model, data.shape[0], data.shape[2], optimizer=optimizer)
                 loss, output = state["graph"](data, target)
             else:
-                if averager is not None:
-                    averager.sync_buffers()
                 optimizer.zero_grad()
                 output, _ = model(data)
                 loss = F.nll_loss(output, target)
                 loss.backward()
-                if averager is not None:
-                    averager.average_gradients()
                 optimizer.step()
-            pred = output.data.max(1, keepdim=True)[1]
-            correct += pred.eq(target.view_as(pred)).long().cpu().sum()
-            if batch_idx % args.log_interval == 0 and rank == 0:
+            if output is not None:
+                pred = output.data.max(1, keepdim=True)[1]
+                correct += pred.eq(target.view_as(pred)).sum()
+            if batch_idx % args.log_interval == 0 and rank == 0 and loss is not None:
                 percentage = 100. * batch_idx * args.batch_size / len(train_loader.dataset)   # global samples
                 print(f"Train Epoch: {epoch} [{batch_idx * args.batch_size}/{len(train_loader.dataset)} "
                       f"({percentage}%)]\tLoss: {loss.item()}\t{args.tag}")
                 logger.add_scalar("train_loss", loss.cpu().item(), batch_idx + epoch * len(train_loader))
-        return float(correct) / float(max(dataset_size, 1))
+        return float(correct.item()) / float(max(dataset_size, 1))
 
     def test():
+        if averager is not None:
+            averager.sync_buffers()      # rank 0's running statistics everywhere (DataParallel: replica 0 wins)
         model.eval()
         torch.set_grad_enabled(False)
         test_loss, correct, dataset_size, res = 0, 0, 0, []
-        for batch_idx, (data, target, obj_name) in enumerate(test_loader):
+        for batch_idx, batch in enumerate(test_loader):
             if args.max_batches and batch_idx >= args.max_batches:
                 break
+            if batch is None:
+                continue
+            data, target, obj_name = batch
             dataset_size += data.shape[0]
-            data, target = data.float().to(device), target.long().squeeze().to(device)
+            data, target = data.float().to(device), target.long().reshape(-1).to(device)
             output, _ = model(data)
             test_loss += F.nll_loss(output, target, reduction="sum").cpu().item()   # size_average=False
             pred = output.data.max(1, keepdim=True)[1]

@@ -212,9 +212,8 @@ class STN3d(_HipModule):
     def _forward_hip_train(self, x):
         _check_train_batch(x)
         pooled = train.trunk_train(self, x.contiguous(), None, relu_last=True)   # x already fp32 (PointNetfeat)
-        g = train.fc_bn_relu_train(self.fc1, self.bn4, pooled)
-        g = train.fc_bn_relu_train(self.fc2, self.bn5, g)
-        return train.fc_epilogue_train(self.fc3, g, ops.EPI_ADD_IDEN3).view(-1, 3, 3)
+        return train.head_train(self.fc1, self.bn4, self.fc2, self.bn5, self.fc3, pooled,
+                                ops.EPI_ADD_IDEN3).view(-1, 3, 3)
 
     def _forward_hip_infer(self, x):
         dev = x.device
@@ -283,9 +282,8 @@ class PointNetCls(_HipModule):
         g, trans = self.feat(x)
         if g.is_cuda:
             if self.training:
-                g = train.fc_bn_relu_train(self.fc1, self.bn1, g)
-                g = train.fc_bn_relu_train(self.fc2, self.bn2, g)
-                return train.fc_epilogue_train(self.fc3, g, ops.EPI_LOG_SOFTMAX), trans
+                return train.head_train(self.fc1, self.bn1, self.fc2, self.bn2, self.fc3, g,
+                                        ops.EPI_LOG_SOFTMAX), trans
             (w1, b1), (w2, b2), (w3, b3) = _fc_infer_weights(self, [("fc1", "bn1"), ("fc2", "bn2"), ("fc3", None)],
                                                              g.device)
             g = ops.fc_fwd(g, w1, b1, ops.EPI_RELU)

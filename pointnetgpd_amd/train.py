@@ -1,5 +1,14 @@
-"""Train-mode forward/backward of the hot path as ``torch.autograd.Function``s over the libpngpd
-training passes (include/pngpd.h "Training path").
+"""Train-mode forward/backward of the hot path as ``torch.autograd.Function``s over libpngpd
+(include/pngpd.h "Training path").
+
+Two ways of sequencing the same kernels, bit-identical in their results:
+
+* ``"fused"`` (default): one C-ABI call per direction of each of the four pieces of the graph — the two trunks
+  (``pngpd_trunk_train_fwd/_bwd``) and the two FC stacks (``pngpd_head_train_fwd/_bwd``); a training step is eight
+  foreign calls, so the reference's own recipe (batch 64, main_1v.py:18-33) is no longer bound by host sequencing.
+* ``"passes"``: every pass / finalize kernel called one by one from Python (``TrunkTrainFn`` / ``LinearBnReluFn`` /
+  ``LinearEpiFn`` below) — the executable specification of the fused entries, and the form the kernel-level tests
+  hook into (``DEBUG_STASH``, recorded launches).
 
 Everything batch-sized AND the parameter-sized fp64 algebra between the passes (BatchNorm statistics ->
 affine forms, running-stat updates, reduction of per-workgroup partials, closed-form weight gradients) runs
@@ -12,9 +21,11 @@ The algebra is derived in DESIGN.md ("Training passes") and verified against aut
 (pointnet.py:27-45,137-154,189-194 under main_1v.py:72-76): batch-statistics BatchNorm with eps 1e-5,
 running statistics updated with momentum 0.1 and the unbiased variance, num_batches_tracked += 1.
 """
+import ctypes
+
 import torch
 
-from . import ops
+from . import _lib, ops
 from .ops import _call
 
 F64 = torch.float64
@@ -38,6 +49,17 @@ def set_train_precision(mode, fp32_side_passes=False):
     _FP32_SIDE_PASSES = bool(fp32_side_passes)
 
 
+_SEQUENCING = "fused"
+
+
+def set_sequencing(mode):
+    """"fused": one C-ABI call per trunk / head direction (default); "passes": pass-by-pass from Python."""
+    global _SEQUENCING
+    if mode not in ("fused", "passes"):
+        raise ValueError("sequencing must be 'fused' or 'passes'")
+    _SEQUENCING = mode
+
+
 DEBUG_STASH = None   # set to a dict to capture backward intermediates (tests/test_gpu_train.py::test_trunk_backward_intermediates)
 
 
@@ -47,6 +69,9 @@ _PM_ONE = {}
 def _pm_one(dev):
     t = _PM_ONE.get(dev)
     if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            # never cache tensors that would live in a capturing graph's private pool
+            return torch.tensor(1.0, device=dev), torch.tensor(-1.0, device=dev)
         t = _PM_ONE[dev] = (torch.tensor(1.0, device=dev), torch.tensor(-1.0, device=dev))
     return t
 
@@ -116,7 +141,7 @@ class TrunkTrainFn(torch.autograd.Function):
             part, z2t = ops.trunk_bn2_stats_bf(x, T, w1, b1c, s1c, t1c, w2x, S, nt_side, store_z2=True)
         else:
             part, z2t = ops.trunk_bn2_stats(x, T, w1, b1c, s1c, t1c, w2p, S,
-                                            store_z2=nt == 0 or any(ctx.needs_input_grad))
+                                            store_z2=nt == 0 or any(ctx.needs_input_grad))   # fp32 pass C always reads z2 back
         chan2, stats2 = _e(dev, 4, 128), _e(dev, 256, dtype=F64)
         rm, rv, nbt = _bufs3(bufs2)
         tot2 = _reduce(part, 1, blk, 256)
@@ -286,13 +311,218 @@ class LinearEpiFn(torch.autograd.Function):
         return dinp, dW, db, None
 
 
+
+# ---------------------------------------------------------------------------------------------------------------
+# fused sequencing: one foreign call per direction (pngpd_train_step.hip)
+# ---------------------------------------------------------------------------------------------------------------
+_PREC_CODE = {"fp32": 0, "bf16x3": 3, "bf16": 1}
+_TRUNK_GRAD_LAYOUT = (("dW1", 192), ("db1", 64), ("dg1", 64), ("dbe1", 64),
+                      ("dW2", 8192), ("db2", 128), ("dg2", 128), ("dbe2", 128),
+                      ("dW3", 131072), ("db3", 1024), ("dg3", 1024), ("dbe3", 1024))
+_SIZE_CACHE = {}
+
+
+def _stream_ptr(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _ccall(fn_name, args, dev):
+    fn = _FNS.get(fn_name)
+    if fn is None:
+        fn = _FNS[fn_name] = getattr(_lib.load(), fn_name)
+    if torch.cuda.current_device() == dev.index:
+        code = fn(ctypes.addressof(args), _stream_ptr(dev))
+    else:
+        with torch.cuda.device(dev):
+            code = fn(ctypes.addressof(args), _stream_ptr(dev))
+    if code != 0:
+        _lib.check(code, fn_name)
+
+
+_FNS = {}
+
+
+def _dp(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _grad_out(param):
+    """The persistent gradient view a flat optimizer (optim.FlatAdam) registered on ``param``, or None."""
+    return getattr(param, "_pngpd_grad", None)
+
+
+class FusedTrunkFn(torch.autograd.Function):
+    """The trunk of STN3d / PointNetfeat in train mode through pngpd_trunk_train_fwd / _bwd: x (B,3,N) [, trans
+    (B,3,3)] -> pooled (B,1024).  ``grad_outs``: None, or the 12 persistent gradient tensors of the parameters (a flat
+    optimizer's views) — the backward then writes them in place and returns no parameter gradients."""
+
+    @staticmethod
+    def forward(ctx, x, trans, W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, g3, be3, relu_last, eps, momentum,
+                bufs1, bufs2, bufs3, grad_outs):
+        B, _, N = x.shape
+        dev = x.device
+        x = x.contiguous()
+        T = trans.detach().contiguous() if trans is not None else None
+        P = [t.detach().contiguous() for t in (W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, g3, be3)]
+        for t in [x] + P + ([T] if T is not None else []):
+            if not t.is_cuda or t.dtype != torch.float32:
+                raise RuntimeError("trunk_train: expected float32 CUDA tensors")
+        a = _lib.TrunkTrainArgs()
+        a.x, a.trans, a.B, a.N = x.data_ptr(), _dp(T), B, N
+        a.S = ops.train_splits(B, N)
+        a.relu_last = int(bool(relu_last))
+        a.precision = _PREC_CODE[_TRAIN_PRECISION]
+        a.fp32_side = int(_FP32_SIDE_PASSES)
+        need_bwd = any(ctx.needs_input_grad) or grad_outs is not None
+        a.need_bwd = int(need_bwd)
+        a.eps, a.momentum = float(eps), float(momentum)
+        (a.w1, a.b1, a.g1, a.be1, a.w2, a.b2, a.g2, a.be2, a.w3, a.b3, a.g3, a.be3) = [t.data_ptr() for t in P]
+        for i, bufs in ((1, bufs1), (2, bufs2), (3, bufs3)):
+            if bufs is not None:
+                setattr(a, f"rm{i}", bufs[0].data_ptr()); setattr(a, f"rv{i}", bufs[1].data_ptr())
+                setattr(a, f"nbt{i}", _dp(bufs[2]))
+        key = (B, N, a.S, a.precision, a.fp32_side)
+        sizes = _SIZE_CACHE.get(key)
+        if sizes is None:
+            lib = _lib.load()
+            sizes = _SIZE_CACHE[key] = (lib.pngpd_trunk_train_save_bytes(ctypes.addressof(a)),
+                                        lib.pngpd_trunk_train_scratch_bytes(ctypes.addressof(a)))
+        # a forward without a backward keeps nothing: its "save" is scratch too
+        save = torch.empty(sizes[0], device=dev, dtype=torch.uint8) if need_bwd else None
+        ws = ops._workspace(dev, sizes[1] + (0 if need_bwd else sizes[0] + 256))
+        a.scratch, a.scratch_bytes = ws.data_ptr(), sizes[1]
+        if need_bwd:
+            a.save = save.data_ptr()
+        else:
+            a.save = ws.data_ptr() + ((sizes[1] + 255) & ~255)
+        a.save_bytes = sizes[0]
+        pooled = torch.empty(B, 1024, device=dev, dtype=torch.float32)
+        idx = torch.empty(B, 1024, device=dev, dtype=torch.int32)
+        zhat = torch.empty(B, 1024, device=dev, dtype=torch.float32)
+        a.pooled, a.idx, a.zhat = pooled.data_ptr(), idx.data_ptr(), zhat.data_ptr()
+        _ccall("pngpd_trunk_train_fwd", a, dev)
+        _bump(bufs1); _bump(bufs2); _bump(bufs3)
+        ctx.args, ctx.save_buf, ctx.grad_outs, ctx.sizes = a, save, grad_outs, sizes
+        ctx.has_t = T is not None
+        ctx.save_for_backward(x, T if T is not None else x.new_empty(0), pooled, idx, zhat, *P)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dp):
+        saved = ctx.saved_tensors          # raises if a parameter was modified in place since the forward
+        x = saved[0]
+        dev = x.device
+        a = ctx.args
+        dp = dp.contiguous()
+        a.dp = dp.data_ptr()
+        if ctx.grad_outs is not None:
+            outs = ctx.grad_outs
+            views = None
+        else:
+            buf = torch.empty(sum(n for _, n in _TRUNK_GRAD_LAYOUT), device=dev, dtype=torch.float32)
+            views = buf.split([n for _, n in _TRUNK_GRAD_LAYOUT])
+            outs = views
+        for (name, _), t in zip(_TRUNK_GRAD_LAYOUT, outs):
+            setattr(a, name, t.data_ptr())
+        dT = None
+        if ctx.has_t and ctx.needs_input_grad[1]:
+            dT = torch.empty(a.B, 3, 3, device=dev, dtype=torch.float32)
+        a.dT = _dp(dT)
+        ws = ops._workspace(dev, ctx.sizes[1])
+        a.scratch, a.scratch_bytes = ws.data_ptr(), ctx.sizes[1]
+        _ccall("pngpd_trunk_train_bwd", a, dev)
+        if views is None:
+            grads = (None,) * 12
+        else:
+            v = views
+            grads = (v[0].view(64, 3, 1), v[1], v[2], v[3], v[4].view(128, 64, 1), v[5], v[6], v[7],
+                     v[8].view(1024, 128, 1), v[9], v[10], v[11])
+        return (None, dT) + grads + (None,) * 7
+
+
+class FusedHeadFn(torch.autograd.Function):
+    """fc1/bn/relu -> fc2/bn/relu -> fc3 + tail (pointnet.py:35-43 / :191-194) through pngpd_head_train_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, inp, W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, epilogue, eps, momentum, bufs1, bufs2,
+                grad_outs):
+        inp = inp.contiguous()
+        dev = inp.device
+        P = [t.detach().contiguous() for t in (W1, b1, g1, be1, W2, b2, g2, be2, W3, b3)]
+        a = _lib.HeadTrainArgs()
+        a.inp, a.B, a.K0 = inp.data_ptr(), inp.shape[0], inp.shape[1]
+        a.H1, a.H2, a.k = P[0].shape[0], P[4].shape[0], P[8].shape[0]
+        a.epilogue, a.eps, a.momentum = int(epilogue), float(eps), float(momentum)
+        (a.W1, a.b1, a.g1, a.be1, a.W2, a.b2, a.g2, a.be2, a.W3, a.b3) = [t.data_ptr() for t in P]
+        for i, bufs in ((1, bufs1), (2, bufs2)):
+            if bufs is not None:
+                setattr(a, f"rm{i}", bufs[0].data_ptr()); setattr(a, f"rv{i}", bufs[1].data_ptr())
+                setattr(a, f"nbt{i}", _dp(bufs[2]))
+        key = ("head", a.B, a.K0, a.H1, a.H2, a.k)
+        sizes = _SIZE_CACHE.get(key)
+        if sizes is None:
+            lib = _lib.load()
+            sizes = _SIZE_CACHE[key] = (lib.pngpd_head_train_save_bytes(ctypes.addressof(a)),
+                                        lib.pngpd_head_train_scratch_bytes(ctypes.addressof(a)))
+        save = torch.empty(sizes[0], device=dev, dtype=torch.uint8)
+        a.save, a.save_bytes = save.data_ptr(), sizes[0]
+        out = torch.empty(a.B, a.k, device=dev, dtype=torch.float32)
+        a.out = out.data_ptr()
+        _ccall("pngpd_head_train_fwd", a, dev)
+        _bump(bufs1); _bump(bufs2)
+        ctx.args, ctx.save_buf, ctx.grad_outs, ctx.sizes = a, save, grad_outs, sizes
+        ctx.save_for_backward(inp, out, *P)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        saved = ctx.saved_tensors
+        inp, P = saved[0], saved[2:]
+        dev = inp.device
+        a = ctx.args
+        g = g.contiguous()
+        a.gout = g.data_ptr()
+        shapes = [tuple(t.shape) for t in P]
+        if ctx.grad_outs is not None:
+            outs, views = ctx.grad_outs, None
+        else:
+            sizes = [((t.numel() + 63) // 64) * 64 for t in P]        # 256-byte aligned segments
+            buf = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
+            views = [v[:t.numel()].view(sh) for v, t, sh in zip(buf.split(sizes), P, shapes)]
+            outs = views
+        for name, t in zip(("dW1", "db1", "dg1", "dbe1", "dW2", "db2", "dg2", "dbe2", "dW3", "db3"), outs):
+            setattr(a, name, t.data_ptr())
+        dinp = torch.empty_like(inp) if ctx.needs_input_grad[0] else None
+        a.dinp = _dp(dinp)
+        ws = ops._workspace(dev, ctx.sizes[1])
+        a.scratch, a.scratch_bytes = ws.data_ptr(), ctx.sizes[1]
+        _ccall("pngpd_head_train_bwd", a, dev)
+        grads = (None,) * 10 if views is None else tuple(views)
+        return (dinp,) + grads + (None,) * 6
+
+
 def _bufs(bn):
     return (bn.running_mean, bn.running_var, bn.num_batches_tracked) if bn.track_running_stats else None
+
+
+def _use_fused():
+    return _SEQUENCING == "fused" and DEBUG_STASH is None
+
+
+def _grad_outs(params):
+    outs = [_grad_out(p) for p in params]
+    return outs if all(o is not None for o in outs) else None
 
 
 def trunk_train(mod, x, trans, relu_last):
     """Train-mode trunk of a module holding conv1..3 / bn1..3."""
     mom = mod.bn1.momentum if mod.bn1.momentum is not None else 0.1
+    if _use_fused():
+        params = (mod.conv1.weight, mod.conv1.bias, mod.bn1.weight, mod.bn1.bias,
+                  mod.conv2.weight, mod.conv2.bias, mod.bn2.weight, mod.bn2.bias,
+                  mod.conv3.weight, mod.conv3.bias, mod.bn3.weight, mod.bn3.bias)
+        return FusedTrunkFn.apply(x, trans, *params, bool(relu_last), float(mod.bn1.eps), float(mom),
+                                  _bufs(mod.bn1), _bufs(mod.bn2), _bufs(mod.bn3), _grad_outs(params))
     return TrunkTrainFn.apply(x, trans,
                               mod.conv1.weight, mod.conv1.bias, mod.bn1.weight, mod.bn1.bias,
                               mod.conv2.weight, mod.conv2.bias, mod.bn2.weight, mod.bn2.bias,
@@ -310,6 +540,19 @@ def fc_epilogue_train(lin, inp, epilogue):
     return LinearEpiFn.apply(inp, lin.weight, lin.bias, epilogue)
 
 
+def head_train(fc1, bn1, fc2, bn2, fc3, inp, epilogue):
+    """relu(bn1(fc1(inp))) -> relu(bn2(fc2(.))) -> fc3 + tail, train mode (pointnet.py:35-43, :191-194)."""
+    if _use_fused():
+        mom = bn1.momentum if bn1.momentum is not None else 0.1
+        params = (fc1.weight, fc1.bias, bn1.weight, bn1.bias, fc2.weight, fc2.bias, bn2.weight, bn2.bias,
+                  fc3.weight, fc3.bias)
+        return FusedHeadFn.apply(inp, *params, int(epilogue), float(bn1.eps), float(mom), _bufs(bn1), _bufs(bn2),
+                                 _grad_outs(params))
+    g = fc_bn_relu_train(fc1, bn1, inp)
+    g = fc_bn_relu_train(fc2, bn2, g)
+    return fc_epilogue_train(fc3, g, epilogue)
+
+
 class GraphedTrainStep:
     """One training step (``main_1v.py:72-76``: zero_grad, forward, ``nll_loss``, backward, Adam step) of a fixed
     (batch, num_points) shape captured ONCE as a HIP graph and replayed.  A step is ≈190 kernel launches whose
@@ -321,6 +564,7 @@ class GraphedTrainStep:
         loss, logp = step(x, y)          # x (64,3,750) fp32 CUDA, y (64,) int64 CUDA; static output tensors
         step.optimizer                   # torch.optim.Adam(capturable=True, lr as a device tensor -> StepLR works)
 
+    ``optimizer``: a FlatAdam(capturable=True) (default) or a torch optimizer built with capturable=True.
     The three warm-up steps the capture needs run on zero data and are UNDONE (parameters, BatchNorm buffers and
     Adam state restored in place), so the first replay is the first real step.  Single process only: gradient
     all-reduce is not captured (use the eager loop + ``ddp.GradAverager`` under torchrun)."""
@@ -338,16 +582,20 @@ class GraphedTrainStep:
         k = model.fc3.out_features
         self.x = torch.zeros(batch, 3, num_points, device=dev)
         self.y = (torch.arange(batch, device=dev) % k).long()
+        from .optim import FlatAdam
         if optimizer is None:
-            optimizer = torch.optim.Adam(model.parameters(), lr=torch.tensor(float(lr), device=dev), capturable=True,
-                                         fused=True)
-        elif not all(g.get("capturable", False) for g in optimizer.param_groups):
+            optimizer = FlatAdam(model.parameters(), lr=torch.tensor(float(lr), device=dev), capturable=True)
+        flat = isinstance(optimizer, FlatAdam)
+        if flat and not optimizer.capturable:
+            raise RuntimeError("the FlatAdam must be constructed with capturable=True (device-resident step / lr)")
+        if not flat and not all(g.get("capturable", False) for g in optimizer.param_groups):
             raise RuntimeError("the optimizer must be constructed with capturable=True")
         self.optimizer = optimizer
         had_state = len(optimizer.state) > 0
         saved_model = {n: t.detach().clone() for n, t in model.state_dict().items()}
         saved_opt = [(st, {n: v.detach().clone() for n, v in st.items() if torch.is_tensor(v)})
                      for st in optimizer.state.values()] if had_state else None
+        saved_step = (optimizer._step, optimizer.step_dev.clone()) if flat else None
 
         def one_step():
             optimizer.zero_grad(set_to_none=True)
@@ -377,12 +625,16 @@ class GraphedTrainStep:
             if had_state:
                 for st, sv in saved_opt:
                     for n, v in sv.items():
-                        st[n].copy_(v)
+                        if st[n].device == v.device and st[n].shape == v.shape:
+                            st[n].copy_(v)
             else:
                 for st in optimizer.state.values():
                     for v in st.values():
                         if torch.is_tensor(v):
                             v.zero_()
+            if flat:
+                optimizer._step = saved_step[0]
+                optimizer.step_dev.copy_(saved_step[1])
         self.x.zero_()
         self._state = [t for t in list(model.parameters()) + list(model.buffers())]
 

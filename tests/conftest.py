@@ -25,3 +25,14 @@ def cuda_device():
     if not torch.cuda.is_available():
         pytest.fail("this test is marked gpu and needs a GPU; none is visible")
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def pass_sequencing():
+    """Kernel-level tests that record / intercept the individual pass launches (``train.DEBUG_STASH``, monkeypatched
+    ``ops.*``) run the step pass by pass from Python instead of through the fused per-direction entries — the two are
+    bit-identical (tests/test_gpu_fused.py)."""
+    from pointnetgpd_amd import train
+    train.set_sequencing("passes")
+    yield
+    train.set_sequencing("fused")

@@ -115,7 +115,7 @@ def test_bf16_train_step_error(kind, bf16_modes, cuda_device):
 
 
 @pytest.mark.parametrize("nt,tol", [(3, 1e-4), (1, 2e-2)])
-def test_bf_side_passes_match_fp32_passes(nt, tol, bf16_modes, cuda_device, monkeypatch):
+def test_bf_side_passes_match_fp32_passes(nt, tol, bf16_modes, cuda_device, monkeypatch, pass_sequencing):
     """Passes B / gather / D / E with their contractions on bf16 (nt = 1) / bf16x3 (nt = 3) operands — the NT variants
     of the fp32 kernels — against the fp32 passes on IDENTICAL inputs: the arguments of every side-pass launch of a
     real fp32 training step are recorded and replayed through the _bf entry points, output buffer by output buffer
@@ -192,7 +192,7 @@ def test_bf_side_passes_match_fp32_passes(nt, tol, bf16_modes, cuda_device, monk
 
 @pytest.mark.parametrize("nt", [3, 1])
 @pytest.mark.parametrize("B,N", [(6, 150), (4, 750), (3, 64)])
-def test_bf_pass_c_reads_z2_back(nt, B, N, bf16_modes, cuda_device, monkeypatch):
+def test_bf_pass_c_reads_z2_back(nt, B, N, bf16_modes, cuda_device, monkeypatch, pass_sequencing):
     """Pass C on bf16 operands with z2 read back from pass B's store (LOADZ) against the same kernel recomputing
     layers 1-2: same maxima, arg-maxima and sums.  N = 150: an odd number of 64-point tiles (the second half of the
     last 128-point tile does not exist in z2t); N = 64: a single half tile."""

@@ -191,7 +191,7 @@ def test_train_batch_of_one_raises(cuda_device):
         m(torch.zeros(1, 3, 64, device=cuda_device))
 
 
-def test_trunk_backward_intermediates(cuda_device):
+def test_trunk_backward_intermediates(cuda_device, pass_sequencing):
     """Model-level scenario, kernel-level check: every accumulated quantity of the feat-trunk backward
     (sums, second moments, gather, g2, closed-form dW, dT) vs the fp64 prototype fed with the SAME trans and
     the SAME upstream gradient the HIP run produced — no flip ambiguity, so the bounds are tight (5e-4 .. 5e-3)."""
@@ -280,7 +280,8 @@ def test_graphed_train_step_equals_eager(cuda_device):
     step = pt.GraphedTrainStep(m_g, batch=B, num_points=N, lr=0.005)
     for n, t in m_g.state_dict().items():                      # warm-up undone
         assert torch.equal(t, init[n]), n
-    opt_e = torch.optim.Adam(m_e.parameters(), lr=torch.tensor(0.005, device=cuda_device), capturable=True, fused=True)
+    from pointnetgpd_amd.optim import FlatAdam
+    opt_e = FlatAdam(m_e.parameters(), lr=torch.tensor(0.005, device=cuda_device), capturable=True)
     for i in range(3):
         x = synth_cloud(B, N, 6000 + i, "box").to(cuda_device)
         y = torch.randint(0, k, (B,), generator=torch.Generator().manual_seed(i)).to(cuda_device)

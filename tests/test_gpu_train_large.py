@@ -92,7 +92,7 @@ def test_train_step_bench_size(cuda_device):
     _run_case(1024, 1024, 2, cuda_device, None, "one")
 
 
-def test_trunk_intermediates_large(cuda_device):
+def test_trunk_intermediates_large(cuda_device, pass_sequencing):
     """Kernel-level check at S = 1 with many tiles per workgroup (B = 256, N = 1024): every accumulated quantity of
     the feat-trunk backward vs the fp64 pass-structured prototype fed the same trans and upstream gradient."""
     from pointnetgpd_amd import train
