@@ -43,7 +43,6 @@ def _worker(rank, world, port, out_dir, B_per, N, k):
     x_all = synth_cloud(world * B_per, N, 4242, "box")
     y_all = (torch.arange(world * B_per) * 5 % k).long()
     xs, ys = x_all[rank * B_per:(rank + 1) * B_per].to(dev), y_all[rank * B_per:(rank + 1) * B_per].to(dev)
-    avg.sync_buffers()
     sd0 = {n: t.detach().cpu().clone() for n, t in m.state_dict().items()}   # the synced replica
     logp, _ = m(xs)
     loss = F.nll_loss(logp, ys)
@@ -101,6 +100,72 @@ def test_two_ranks_hip_path_vs_oracle(tmp_path, cuda_device):
         assert err <= bound, (n, err, bound)
     # per-replica BatchNorm statistics: the two shards' local gradients are genuinely different
     assert _rel(res[0]["local"]["fc1.weight"], res[1]["local"]["fc1.weight"]) > 1e-3
+
+
+def _flat_worker(rank, world, port, out_dir, N, k):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    import torch.nn.functional as F
+    from pointnetgpd_amd import ddp
+    from pointnetgpd_amd.optim import FlatAdam
+    from tests.helpers import build_model, synth_cloud
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo")
+    m = build_model(N, k, 600 + rank, 5300 + rank).train().to(dev)      # different replicas on purpose
+    opt = FlatAdam(m.parameters(), lr=0.005)
+    avg = ddp.GradAverager(m, optimizer=opt)                             # -> rank 0's replica, flat buckets
+    assert avg._early is not None and avg._late is not None              # two buckets: [feat trunk + head], [STN]
+    n_loc = 7 if rank == 0 else 5                                        # ragged: my_collate dropped samples
+    x_all = synth_cloud(12, N, 4343, "box"); y_all = (torch.arange(12) * 5 % k).long()
+    lo = 0 if rank == 0 else 7
+    xs, ys = x_all[lo:lo + n_loc].to(dev), y_all[lo:lo + n_loc].to(dev)
+    # this rank's own summed gradient (no collective)
+    opt.zero_grad()
+    F.nll_loss(m(xs)[0], ys, reduction="sum").backward()
+    local = opt.flat_g.clone()
+    # the real step
+    opt.zero_grad()
+    loss_sum = F.nll_loss(m(xs)[0], ys, reduction="sum")
+    total = avg.backward(loss_sum, n_loc)
+    summed = opt.flat_g.clone()
+    opt.step(grad_div=total)
+    total = float(total)          # `total` aliases the averager's persistent count buffer: read it now
+    # a step this rank sits out (one sample left): zeros in, collectives joined
+    opt.zero_grad()
+    if rank == 0:
+        total2 = avg.backward(F.nll_loss(m(xs)[0], ys, reduction="sum"), n_loc)
+    else:
+        total2 = avg.backward(None, 1)
+    opt.step(grad_div=total2)
+    torch.cuda.synchronize()
+    avg.sync_buffers()
+    m.eval()
+    with torch.no_grad():
+        ev = m(x_all.to(dev))[0]
+    torch.save(dict(local=local.cpu(), summed=summed.cpu(), total=float(total), total2=float(total2),
+                    params=opt.flat_p.cpu().clone(), ev=ev.cpu(), rm=m.feat.bn3.running_mean.cpu().clone()),
+               os.path.join(out_dir, f"f{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_flat_gradient_buckets(tmp_path, cuda_device):
+    """The CLI's data-parallel step on the HIP path (FlatAdam + GradAverager.backward): the fused backward writes into
+    the flat buffer, two bucketed all-reduces (the [feat trunk + head] slice leaves from the tensor hook on the STN
+    output) carry the SUMMED per-sample gradients and the kept-sample count, the optimizer divides on the device.
+    Ragged per-rank batches, a rank that sits a step out, and eval with rank 0's running statistics."""
+    world, port, N, k = 2, _free_port(), 200, 3
+    mp.start_processes(_flat_worker, args=(world, port, str(tmp_path), N, k), nprocs=world, join=True,
+                       start_method="spawn")
+    r0, r1 = torch.load(tmp_path / "f0.pt"), torch.load(tmp_path / "f1.pt")
+    assert r0["total"] == 12.0 and r1["total"] == 12.0 and r0["total2"] == 7.0 and r1["total2"] == 7.0
+    assert torch.equal(r0["summed"], r1["summed"])
+    assert torch.allclose(r0["summed"], r0["local"] + r1["local"], atol=1e-6, rtol=1e-6)
+    assert torch.equal(r0["params"], r1["params"])                       # replicas stay identical through both steps
+    assert torch.equal(r0["rm"], r1["rm"]) and torch.equal(r0["ev"], r1["ev"])   # eval: rank 0's statistics everywhere
 
 
 def _score_worker(rank, world, port, out_dir):

@@ -120,6 +120,78 @@ def test_grad_averager_gloo_world2(tmp_path):
     assert abs(r1["rm"].mean().item() - r0["rm"].mean().item()) < 0.5
 
 
+def _ragged_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    import torch.nn.functional as F
+    from pointnetgpd_amd import ddp
+    from pointnetgpd_amd.model.pointnet import PointNetCls
+    ddp.init_from_env("gloo")
+    torch.manual_seed(7)
+    m = PointNetCls(64, 3, 2).train()
+    avg = ddp.GradAverager(m)
+    g = torch.Generator().manual_seed(11)
+    x_all = torch.randn(8, 3, 64, generator=g); y_all = torch.arange(8) % 2
+    out = {}
+    # step A: ragged per-rank batches (my_collate dropped samples): 5 on rank 0, 3 on rank 1
+    lo, hi = (0, 5) if rank == 0 else (5, 8)
+    m.zero_grad()
+    lp, _ = m(x_all[lo:hi])
+    assert avg.backward(F.nll_loss(lp, y_all[lo:hi], reduction="sum"), hi - lo) is None
+    out["ragged"] = {n: p.grad.clone() for n, p in m.named_parameters()}
+    # what this rank alone contributes (sum of its per-sample gradients)
+    m.zero_grad()
+    lp, _ = m(x_all[lo:hi])
+    F.nll_loss(lp, y_all[lo:hi], reduction="sum").backward()
+    out["local_sum"] = {n: p.grad.clone() for n, p in m.named_parameters()}
+    # step B: rank 1 is left with ONE sample (train-mode BatchNorm cannot run): it sits the step out, nobody hangs
+    m.zero_grad()
+    if rank == 0:
+        lp, _ = m(x_all[0:5])
+        avg.backward(F.nll_loss(lp, y_all[0:5], reduction="sum"), 5)
+    else:
+        avg.backward(None, 1)
+    out["sit_out"] = {n: p.grad.clone() for n, p in m.named_parameters()}
+    # step C: every sample of rank 1's batch was dropped (my_collate -> None)
+    m.zero_grad()
+    if rank == 0:
+        lp, _ = m(x_all[0:5])
+        avg.backward(F.nll_loss(lp, y_all[0:5], reduction="sum"), 5)
+    else:
+        avg.backward(None, 0)
+    out["empty"] = {n: p.grad.clone() for n, p in m.named_parameters()}
+    # running statistics drifted apart (per-replica BatchNorm): sync_buffers before eval makes rank 0's everyone's
+    avg.sync_buffers()
+    m.eval()
+    with torch.no_grad():
+        out["eval_logp"] = m(x_all)[0].clone()
+    out["rm"] = m.feat.bn3.running_mean.clone()
+    torch.save(out, os.path.join(out_dir, f"rag{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ragged_batches_weighted_mean_and_sit_out(tmp_path):
+    """per-rank kept-sample counts differ under my_collate.  The combined gradient is the per-sample mean
+    over the GLOBAL batch (what DataParallel's gathered nll_loss gives), a rank with < 2 samples contributes zeros and
+    still joins the collectives, and eval after sync_buffers() uses rank 0's running statistics on every rank."""
+    from pointnetgpd_amd import mains
+    assert mains.my_collate([None, None]) is None              # an all-dropped batch no longer raises in default_collate
+    world, port = 2, _free_port()
+    mp.start_processes(_ragged_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    r0 = torch.load(tmp_path / "rag0.pt"); r1 = torch.load(tmp_path / "rag1.pt")
+    for n in r0["ragged"]:
+        want = (r0["local_sum"][n] + r1["local_sum"][n]) / 8.0
+        assert torch.allclose(r0["ragged"][n], want, atol=1e-6), n
+        assert torch.equal(r0["ragged"][n], r1["ragged"][n]), n
+        for key in ("sit_out", "empty"):
+            assert torch.allclose(r0[key][n], r0["local_sum"][n] / 5.0, atol=1e-6), (key, n)
+            assert torch.equal(r0[key][n], r1[key][n]), (key, n)
+    assert torch.equal(r0["rm"], r1["rm"]) and torch.equal(r0["eval_logp"], r1["eval_logp"])
+
+
 def test_shard_grasps():
     from pointnetgpd_amd.scoring import shard_grasps
     spans = [shard_grasps(100000, r, 8) for r in range(8)]
