@@ -43,26 +43,39 @@ __device__ __forceinline__ void stage_points(const float *__restrict__ xb, int N
     }
 }
 
-// Layer 1 (3 -> 64) on the VALU.  thread = (point p = lane, 16-channel group = wave).
+// Layer 1 (3 -> 64) on the VALU.  thread = (channel c = lane, 16-point group = wave): the lane's six per-channel
+// constants stay in registers for the whole kernel (L1C, loaded once) and the tile's coordinates are LDS broadcast
+// reads.  (The previous mapping — point per lane, 16 wave-uniform channels per wave — re-fetched 96 constants through
+// the scalar cache for every tile: 8,100 of pass E's 33,500 cycles per wave and tile, tools/phase_times.py.)
 //   z = w1[c]·x + b1[c];  h1 = relu(z * sc[c] + sh[c])      (sc == nullptr: h1 = relu(z))
-// w1/b1 (and sc/sh) are indexed with wave-uniform c -> scalar loads.
-__device__ __forceinline__ void layer1_tile(const float *xs, const float *__restrict__ w1,
-                                            const float *__restrict__ b1, const float *__restrict__ sc,
-                                            const float *__restrict__ sh, float *h1, const Lane &L) {
-    const int p = L.lane;
-    const float x0 = xs[p], x1 = xs[TP + p], x2 = xs[2 * TP + p];
-    float *dst = h1 + p * H1S + L.wave * 16;
+// Same fmaf chain per element as before, so recomputed activations stay bit-identical across passes.
+struct L1C { float w0, w1, w2, b, sc, sh; bool affine; };
+
+__device__ __forceinline__ L1C load_l1c(const float *__restrict__ w1, const float *__restrict__ b1,
+                                        const float *__restrict__ sc, const float *__restrict__ sh, const Lane &L) {
+    L1C k;
+    const int c = L.lane;
+    k.w0 = w1[c * 3]; k.w1 = w1[c * 3 + 1]; k.w2 = w1[c * 3 + 2]; k.b = b1[c];
+    k.affine = sc != nullptr;
+    k.sc = k.affine ? sc[c] : 1.f;
+    k.sh = k.affine ? sh[c] : 0.f;
+    return k;
+}
+
+__device__ __forceinline__ void layer1_tile(const float *xs, const L1C &k, float *h1, const Lane &L) {
+    const int p0 = L.wave * 16;
+    float *dst = h1 + p0 * H1S + L.lane;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        f32x4 v;
+    for (int q = 0; q < 4; ++q) {   // 12 broadcast ds_read_b128: the wave's 16 points
+        const f32x4 x0 = *(const f32x4 *)(xs + p0 + 4 * q);
+        const f32x4 x1 = *(const f32x4 *)(xs + TP + p0 + 4 * q);
+        const f32x4 x2 = *(const f32x4 *)(xs + 2 * TP + p0 + 4 * q);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int c = L.wave * 16 + g * 4 + e;
-            float z = fmaf(w1[c * 3 + 2], x2, fmaf(w1[c * 3 + 1], x1, fmaf(w1[c * 3], x0, b1[c])));
-            if (sc) z = fmaf(z, sc[c], sh[c]);
-            v[e] = fmaxf(z, 0.f);
+            float z = fmaf(k.w2, x2[e], fmaf(k.w1, x1[e], fmaf(k.w0, x0[e], k.b)));
+            if (k.affine) z = fmaf(z, k.sc, k.sh);
+            dst[(4 * q + e) * H1S] = fmaxf(z, 0.f);
         }
-        *(f32x4 *)(dst + g * 4) = v;
     }
 }
 

@@ -16,6 +16,25 @@
 //                   h2 = relu(z2*s2c + t2c),  zhat2 = z2*is2 + nm2,   z2 = W2 h1   (no bias)
 #include "pngpd_tile.h"
 
+// Per-phase cycle accounting for kernel experiments (variant builds only: -DPNGPD_TIMING, tools/phase_times.py; never in
+// the product library).
+#ifdef PNGPD_TIMING
+__device__ unsigned long long pngpd_tm[16];
+#define TM_DECL unsigned long long tm_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tm_t = __builtin_amdgcn_s_memtime();
+#define TM(i) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tm_[i] += n_ - tm_t; tm_t = n_; }
+#define TM_END if ((threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&pngpd_tm[i_], tm_[i_]); atomicAdd(&pngpd_tm[15], 1ull); }
+extern "C" int pngpd_tm_read(unsigned long long *host16, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(host16, HIP_SYMBOL(pngpd_tm), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(pngpd_tm), z, sizeof(z)); }
+    return 0;
+}
+#else
+#define TM_DECL
+#define TM(i)
+#define TM_END
+#endif
+
 struct TrainChan {
     const float *w1, *b1, *s1c, *t1c;   // layer 1: (64,3) raw, bias, scale, shift
     const float *w2p, *s2c, *t2c;       // layer 2: raw MFMA_B packed (128,64), scale, shift
@@ -82,10 +101,11 @@ __global__ __launch_bounds__(256, 2) void trunk_bn2_stats_kernel(
     float sum = 0.f, sq = 0.f;
     f32x4 w2f[8];   // this wave's layer-2 weight fragments stay in registers for the whole kernel
     if (NT == 0) load_w2frag(w2f, P.w2p, L.wave, L);
+    const L1C l1c = load_l1c(P.w1, P.b1, P.s1c, P.t1c, L);
     for (int tile = t0; tile < t1; ++tile) {
         stage_points(xb, N, tile, has_t, tm, xs, nullptr, L.tid);
         __syncthreads();
-        layer1_tile(xs, P.w1, P.b1, P.s1c, P.t1c, h1, L);
+        layer1_tile(xs, l1c, h1, L);
         __syncthreads();
         f32x16 a0, a1;
         if constexpr (NT == 0) layer2_compute(h1, w2f, L, a0, a1);
@@ -319,6 +339,7 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_gather_kernel(
     const float sc = P.s2c[cb * 32 + L.j], sh = P.t2c[cb * 32 + L.j];
     f32x4 w2f[8];
     if (NT == 0) load_w2frag(w2f, P.w2p, L.wave, L);
+    const L1C l1c = load_l1c(P.w1, P.b1, P.s1c, P.t1c, L);
     // the arg-max points of cloud b+1 (a dependent idx -> x gather) are fetched while cloud b is processed
     float nx0 = 0.f, nx1 = 0.f, nx2 = 0.f, ncf = 0.f;
     auto fetch = [&](int b) {
@@ -348,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_gather_kernel(
             cf[L.tid] = cfv;
         }
         __syncthreads();   // also: every wave has finished cloud b-1's layer 2 (the last reader of h1)
-        layer1_tile(xs, P.w1, P.b1, P.s1c, P.t1c, h1, L);
+        layer1_tile(xs, l1c, h1, L);
         __syncthreads();
         f32x16 a0, a1;
         if constexpr (NT == 0) layer2_compute(h1, w2f, L, a0, a1);
@@ -415,8 +436,8 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
     static_assert(NT == 0 || LOADZ, "the bf16 variants read z2 back");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *h2 = smem;                     // [TP][H2S], rows past N zeroed
-    float *h1 = h2 + TP * H2S;            // [TP][H1S]
-    float *xs = h1 + TP * H1S;            // [3][TP]
+    float *h1 = h2 + TP * H2S;            // [TP][H1S]  (not allocated when z2 is read back)
+    float *xs = h1 + (LOADZ ? 0 : TP * H1S);   // [3][TP]
     float *cfl = xs + 3 * TP;             // [1024] coef row of this cloud
     int *idxl = (int *)(cfl + 1024);      // [1024] arg-extremum point of every channel of this cloud
     unsigned short *hits = (unsigned short *)(idxl + 1024);   // [2 lists][BWD_D_HITS]: (c << 5) | (point & 31)
@@ -444,6 +465,7 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) { gm0[r] = 0.f; gm1[r] = 0.f; gm2[r] = 0.f; }
     __syncthreads();   // cfl / idxl visible
+    TM_DECL
     for (int tile = t0; tile < t1; ++tile) {
         const int nbase = tile * TP;
         f32x4 zq[8];
@@ -470,11 +492,13 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
             }
             if (L.lane == 0) { hcnt[L.wave] = clo; hcnt[4 + L.wave] = chi; }
         }
+        TM(0)
         __syncthreads();
+        TM(1)
         f32x4 w2f[8];   // requested a phase ahead of layer 2 (not kept across the long MFMA phase: register budget)
         if (!LOADZ) {
             load_w2frag(w2f, P.w2p, cb, L);
-            layer1_tile(xs, P.w1, P.b1, P.s1c, P.t1c, h1, L);
+            layer1_tile(xs, load_l1c(P.w1, P.b1, P.s1c, P.t1c, L), h1, L);
         }
         int nlo = 0, nhi = 0;
         {   // ordered compaction at the prefix offsets of the four quarters
@@ -520,7 +544,9 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
             h2[row * H2S + c2] = (nbase + row < N) ? fmaxf(fmaf(z0[r], sc2, sh2), 0.f) : 0.f;
             h2[(32 + row) * H2S + c2] = (nbase + 32 + row < N) ? fmaxf(fmaf(z1[r], sc2, sh2), 0.f) : 0.f;
         }
+        TM(2)
         __syncthreads();   // h2 and the hit lists are complete
+        TM(3)
         f32x16 d0, d1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
@@ -592,6 +618,7 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
                 for (int t = 0; t < 4; ++t) { d0 = mfma32(a0[t], wv[t], d0); d1 = mfma32(a1[t], wv[t], d1); }
             }
         }
+        TM(4)
         // d -= sparse term: 8 hits (4 k-steps) per iteration, four W3 row pieces in flight
         {
             const float *w3c = D.w3 + c2;
@@ -615,6 +642,7 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
             sparse(hits, nlo, d0);
             sparse(hits + BWD_D_HITS, nhi, d1);
         }
+        TM(5)
         // Gram of the tile: D[i][j] += A[i][k = point] B[k = point][j], both operands read column-wise from h2.
         // 10 blocks over 4 waves: every wave takes (cb,cb) and (cb,cb+1); the two remaining blocks (0,2) and (1,3) are
         // split over the POINTS — wave cb < 2 contracts the tile's first 32 points of block (cb,cb+2), wave cb+2 the
@@ -635,6 +663,7 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
             };
             if (cb < 2) { gram(0, 1); gram(16, 0); } else { gram(0, 0); gram(16, 2); }
         }
+        TM(6)
         }   // NT == 0
         // epilogue: g2 = (cvec - d) masked by ReLU(bn2) and validity; running sums; lane-major hand-off.
         // (Measured: writing this VALU work interleaved with the Gram MFMAs above — two k-steps, one element pair —
@@ -665,9 +694,11 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
             }
             if constexpr (NT == 1) bf_tile_store((uint4 *)g2t + ((size_t)(b * T + tile) * 4) * 256 + L.tid, gb0, gb1);
         }
+        TM(7)
         // no end-of-tile barrier: the next tile's stage_points/census touch only xs/hcnt, whose readers all sit
         // before this tile's second barrier; h1, hits and h2 are rewritten after the next tile's first barrier.
     }
+    TM_END
     a1s += __shfl_xor(a1s, 32);
     a2s += __shfl_xor(a2s, 32);
     if (L.h == 0) {
@@ -733,6 +764,8 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
     for (int r = 0; r < 16; ++r) { pw0[r] = 0.f; pw1[r] = 0.f; }
     f32x4 w2f[8];   // this wave's layer-2 weight fragments stay in registers for the whole kernel
     if (!LOADZ) load_w2frag(w2f, P.w2p, cb, L);
+    const L1C l1c = load_l1c(P.w1, P.b1, P.s1c, P.t1c, L);
+    TM_DECL
     for (int tile = t0; tile < t1; ++tile) {
         const int nbase = tile * TP;
         float *xs = xbuf + ((tile - t0) & 1) * 6 * TP, *xo = xs + 3 * TP;
@@ -756,8 +789,11 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
             }
         }
         stage_points(xb, N, tile, has_t, tm, xs, xo, L.tid);
+        TM(0)
         __syncthreads();
-        layer1_tile(xs, P.w1, P.b1, P.s1c, P.t1c, h1, L);
+        TM(1)
+        layer1_tile(xs, l1c, h1, L);
+        TM(2)
         if (!LOADZ) __syncthreads();   // layer 2 reads h1; with LOADZ the dz tile below depends on registers only
         {
             f32x16 a0, a1, gv0, gv1;
@@ -793,7 +829,9 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
                 dz[(32 + row) * H2S + c2] = v1 ? dsc * (g1 - a1m - z1 * a2m) : 0.f;
             }
         }
+        TM(3)
         __syncthreads();
+        TM(4)
         {
             // dh1[point][c1] = sum_o dz[point][o] * W2[o][c1]   (K = 128), one 32x32 tile per wave
             f32x16 acc, unused;
@@ -801,6 +839,7 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             if constexpr (NT == 0) k128_stream<1>(dz, E.w2tp, cb1, pb1, L, acc, unused);
             else k128_bf<NT>(dz, E.w2tx, cb1, pb1, L, acc);
+            TM(5)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int pt = pb1 * 32 + mfma_row(r, L.lane);
@@ -814,6 +853,7 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
                 r2 = fmaf(g1v, xo[2 * TP + pt], r2);
             }
         }
+        TM(6)
         // dW2 += dz^T h1 : contraction over the tile's 64 points (rows past N carry dz == 0)
         if constexpr (NT > 0) {
             const float *dzc = dz + (8 * L.h) * H2S + cb * 32 + L.j, *h1c = h1 + (8 * L.h) * H1S + L.j;
@@ -857,9 +897,11 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
                 for (int u = 0; u < 4; ++u) { ca[u] = na[u]; c0[u] = n0[u]; c1v[u] = n1[u]; }
             }
         }
+        TM(7)
         // no end-of-tile barrier: xs/xo are double-buffered; h1 and dz are rewritten only after the next tile's
         // first barrier, which every wave reaches after finishing this tile.
     }
+    TM_END
     {
         float *oW = pW2 + (size_t)blockIdx.x * 128 * 64;
 #pragma unroll
@@ -1360,7 +1402,7 @@ int pngpd_trunk_bwd_d(const float *x, int B, int N, const float *trans,
     if (N > (1 << 30)) return PNGPD_ERR_UNSUPPORTED;
     TrainChan P = make_chan(w1, b1, s1c, t1c, w2p, s2c, t2c);
     BwdDParams D; D.is2 = is2; D.nm2 = nm2; D.Ap = Ap; D.Ax = nullptr; D.cvec = cvec; D.w3 = w3; D.idx = idx; D.coef = coef;
-    const size_t lds = BWD_D_LDS_FLOATS * sizeof(float);
+    const size_t lds = (BWD_D_LDS_FLOATS - (z2t ? TP * H1S : 0)) * sizeof(float);
     const dim3 grid((unsigned)B * S);
     return z2t ? launch_bwd_d<true, 0>(grid, lds, (hipStream_t)stream, x, N, trans, P, D, T, S, z2t, g2t, pa, ps2)
                : launch_bwd_d<false, 0>(grid, lds, (hipStream_t)stream, x, N, trans, P, D, T, S, nullptr, g2t, pa, ps2);
@@ -1381,7 +1423,7 @@ int pngpd_trunk_bwd_d_bf(const float *x, int B, int N, const float *s2c, const f
     TrainChan P = make_chan(nullptr, nullptr, nullptr, nullptr, nullptr, s2c, t2c);   // z2 is read back: layers 1-2 unused
     BwdDParams D; D.is2 = is2; D.nm2 = nm2; D.Ap = nullptr; D.Ax = (const u16 *)Ax; D.cvec = cvec; D.w3 = w3;
     D.idx = idx; D.coef = coef;
-    const size_t lds = BWD_D_LDS_FLOATS * sizeof(float);
+    const size_t lds = (BWD_D_LDS_FLOATS - TP * H1S) * sizeof(float);
     const dim3 grid((unsigned)B * S);
     return nterms == 1 ? launch_bwd_d<true, 1>(grid, lds, (hipStream_t)stream, x, N, nullptr, P, D, T, S, z2t, g2t, pa, ps2)
                        : launch_bwd_d<true, 3>(grid, lds, (hipStream_t)stream, x, N, nullptr, P, D, T, S, z2t, g2t, pa, ps2);

@@ -14,11 +14,12 @@ _train.set_train_precision(prec)
 dev = torch.device("cuda:0")
 B, N, k = 1024, 1024, 2
 m = bench.build_model(N, k, dev).train()
-opt = torch.optim.Adam(m.parameters(), lr=0.005, fused=True)
+from pointnetgpd_amd.optim import FlatAdam
+opt = FlatAdam(m.parameters(), lr=0.005)
 x = bench.synth_clouds(B, N, 1234, dev)
 y = (torch.arange(B, device=dev) % k).long()
 for _ in range(steps):
-    opt.zero_grad(set_to_none=True)
+    opt.zero_grad()
     lp, _ = m(x)
     F.nll_loss(lp, y).backward()
     opt.step()
