@@ -293,6 +293,19 @@ __device__ __forceinline__ void k128_bf(const float *tile, const u16 *__restrict
     }
 }
 
+// Experiment hook (variant builds: -DPNGPD_PRIO=n): a static priority for every other resident workgroup of a CU.
+#ifndef PNGPD_PRIO
+#define PNGPD_PRIO 0
+#endif
+#ifndef PNGPD_PRIO_SHIFT
+#define PNGPD_PRIO_SHIFT 8
+#endif
+__device__ __forceinline__ void wg_priority() {
+#if PNGPD_PRIO
+    if ((blockIdx.x >> PNGPD_PRIO_SHIFT) & 1) __builtin_amdgcn_s_setprio(PNGPD_PRIO);
+#endif
+}
+
 // Split of a cloud's T tiles over S workgroups.
 __device__ __forceinline__ void tile_range(int s, int S, int T, int &t0, int &t1) {
     t0 = (int)(((long)s * T) / S);

@@ -167,6 +167,7 @@ __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
     float *ss = (float *)(ri + 1024); // [1024] sum
     float *sq = ss + 1024;            // [1024] sum of squares
     const Lane L;
+    wg_priority();
     const int b = blockIdx.x / S, s = blockIdx.x - b * S;
     int t0, t1; tile_range(s, S, T, t0, t1);
     const float *xb = x + (size_t)b * 3 * N;
@@ -193,9 +194,12 @@ __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
 #pragma unroll
         for (int i = 0; i < 8; ++i) zq[i] = zt[(size_t)i * 256];
     }
+    TM_DECL
     for (int tile = t0; tile < t1; ++tile) {
+        TM(0)
         if (LOADZ) {
             if (tile > t0) __syncthreads();   // every wave is done reading the previous tile's h2
+            TM(1)
         } else if (L.tid < TP) {
             float x0 = px0, x1 = px1, x2 = px2;
             if (has_t) {
@@ -254,7 +258,9 @@ __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
                 hsum += (full || nbase + 32 + row < N) ? v1 : 0.f;
             }
         }
+        TM(2)
         __syncthreads();
+        TM(3)
         auto reduce_block = [&](int cb, const f32x16 &a0, const f32x16 &a1) {
             // max / argmax over this lane's 32 rows (ascending row order, strict >: first wins)
             float m = a0[0]; int am = mfma_row(0, L.lane);
@@ -290,14 +296,19 @@ __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
             f32x16 a0, a1;
             load_wfrag(wb, w3sp, cbB, L);
             swz_compute<I2S, 16>(h2, wa, L, a0, a1);
+            TM(4)
             reduce_block(cbA, a0, a1);
+            TM(5)
             load_wfrag(wa, w3sp, cbN, L);
             swz_compute<I2S, 16>(h2, wb, L, a0, a1);
+            TM(4)
             reduce_block(cbB, a0, a1);
+            TM(5)
         }
         // no end-of-tile barrier: the next tile's xs/h1 writes do not alias h2, and the barrier before its layer 2
         // orders the h2 rewrite after every wave's layer-3 reads (as in trunk_infer_kernel).
     }
+    TM_END
     hsum += __shfl_xor(hsum, 32);
     if (L.h == 0) {
         psh[(size_t)blockIdx.x * 128 + c2] = hsum;
@@ -443,6 +454,7 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
     unsigned short *hits = (unsigned short *)(idxl + 1024);   // [2 lists][BWD_D_HITS]: (c << 5) | (point & 31)
     int *hcnt = (int *)(hits + 2 * BWD_D_HITS);               // [2 lists][4 waves]
     const Lane L;
+    wg_priority();
     const int b = blockIdx.x / S, s = blockIdx.x - b * S;
     int t0, t1; tile_range(s, S, T, t0, t1);
     const float *xb = x + (size_t)b * 3 * N;
@@ -743,6 +755,7 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
     float *dz = h1 + TP * H1S;    // [TP][H2S]
     float *xbuf = dz + TP * H2S;  // 2 x ([3][TP] transformed, [3][TP] original): double-buffered per tile parity
     const Lane L;
+    wg_priority();
     const int b = blockIdx.x / S, s = blockIdx.x - b * S;
     int t0, t1; tile_range(s, S, T, t0, t1);
     const float *xb = x + (size_t)b * 3 * N;
