@@ -164,6 +164,26 @@ __device__ __forceinline__ int swz(int row, int col, int width) {
     return row * width + ((((col >> 2) ^ (row & 15)) << 2) | (col & 3));
 }
 
+// layer1_tile() for the swizzled h1 tile: lane = channel, so for a (wave-uniform) point p the 64 lanes write the 64
+// distinct floats of row p — conflict-free under the XOR swizzle as well.
+__device__ __forceinline__ void layer1_tile_swz(const float *xs, const L1C &k, float *h1, const Lane &L) {
+    const int p0 = L.wave * 16;
+    const int c = L.lane, c4 = c >> 2, ce = c & 3;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 x0 = *(const f32x4 *)(xs + p0 + 4 * q);
+        const f32x4 x1 = *(const f32x4 *)(xs + TP + p0 + 4 * q);
+        const f32x4 x2 = *(const f32x4 *)(xs + 2 * TP + p0 + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int p = p0 + 4 * q + e;
+            float z = fmaf(k.w2, x2[e], fmaf(k.w1, x1[e], fmaf(k.w0, x0[e], k.b)));
+            if (k.affine) z = fmaf(z, k.sc, k.sh);
+            h1[p * I1S + (((c4 ^ (p & 15)) << 2) | ce)] = fmaxf(z, 0.f);
+        }
+    }
+}
+
 // K-contraction of a swizzled [64][W] tile against register-resident MFMA_B fragments (NKB k-blocks).
 template <int W, int NKB>
 __device__ __forceinline__ void swz_compute(const float *tile, const f32x4 (&wf)[NKB], const Lane &L,

@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256, 2) void trunk_infer_kernel(
     // first block of the next tile, which also covers the tile prologue).
     f32x4 wa[16], wb[16];
     load_wfrag(wa, w3p, L.wave + 8 * cp0, L);
+    const L1C l1c = load_l1c(w1, b1, nullptr, nullptr, L);
     // the tile's points are fetched one tile ahead (threads 0..63 hold one point each in registers)
     float px0 = 0.f, px1 = 0.f, px2 = 0.f;
     if (L.tid < TP) {
@@ -73,20 +74,7 @@ __global__ __launch_bounds__(256, 2) void trunk_infer_kernel(
             }
         }
         __syncthreads();
-        {   // layer 1 (3 -> 64), VALU: thread = (point p = lane, 16-channel group = wave)
-            const int p = L.lane;
-            const float x0 = xs[p], x1 = xs[TP + p], x2 = xs[2 * TP + p];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int c = L.wave * 16 + g * 4 + e;   // wave-uniform -> scalar loads
-                    v[e] = fmaxf(fmaf(w1[c * 3 + 2], x2, fmaf(w1[c * 3 + 1], x1, fmaf(w1[c * 3], x0, b1[c]))), 0.f);
-                }
-                *(f32x4 *)(h1 + swz(p, L.wave * 16 + g * 4, I1S)) = v;
-            }
-        }
+        layer1_tile_swz(xs, l1c, h1, L);   // layer 1 (3 -> 64), VALU: lane = channel, its constants in registers
         __syncthreads();
         {   // layer 2 (64 -> 128), MFMA: wave owns channel block cb = wave, both point blocks
             f32x16 a0, a1;
@@ -154,15 +142,46 @@ __global__ void pool_reduce_kernel(const float *__restrict__ part, int S, float 
 // second launch to combine them).
 #define TRUNK_DEFAULT_TARGET_BLOCKS 1024
 
+// Work decomposition of a launch: S workgroups per cloud along the tiles x CS workgroups along the 32 channel blocks
+// (layers 1-2 are recomputed per channel slice: +3 % of a tile's work per extra slice).  512 workgroups are resident
+// (2 per CU); a launch whose grid is not a whole number of such rounds ends with CUs running one workgroup alone (one
+// wave per SIMD: nothing covers its epilogues) or idle.  Cost model in units of one channel-block pair on one tile:
+//   rounds(B S CS) * (ceil(T/S) * (4/CS) * (1 + 0.03 (CS-1)) + 0.6 for the prologue)
+// e.g. B = 64, N = 750 (T = 12): S = 12, CS = 1 is 768 workgroups = 1.5 rounds (measured 148 us, 58 % of peak);
+// S = 4, CS = 2 is exactly one round of 512 equal workgroups.
+static double infer_cost(int B, int T, int S, int CS) {
+    const long G = (long)B * S * CS;
+    const double w = (double)((T + S - 1) / S) * (4.0 / CS) * (1.0 + 0.03 * (CS - 1));
+    return (double)((G + 511) / 512) * (w + 0.6);
+}
+static int best_cs(int B, int T, int S) {
+    int cs = 1;
+    double best = infer_cost(B, T, S, 1);
+    for (int c = 2; c <= 4; c *= 2) {
+        const double v = infer_cost(B, T, S, c);
+        if (v < best - 1e-9) { best = v; cs = c; }
+    }
+    return cs;
+}
+static int auto_splits(int B, int T) {
+    int bestS = 1;
+    double best = infer_cost(B, T, 1, best_cs(B, T, 1));
+    for (int S = 2; S <= T; ++S) {
+        const double v = infer_cost(B, T, S, best_cs(B, T, S));
+        if (v < best - 1e-9) { best = v; bestS = S; }
+    }
+    return bestS;
+}
 static int resolve_splits(int B, int T, int splits) {
-    return (splits > 0) ? (splits > T ? T : splits) : pngpd_splits_for(B, T, TRUNK_DEFAULT_TARGET_BLOCKS);
+    return (splits > 0) ? (splits > T ? T : splits) : auto_splits(B, T);
 }
 
 extern "C" {
 
 int pngpd_trunk_infer_splits(int B, int N, int target_blocks) {
     if (B <= 0 || N <= 0) return 0;
-    return pngpd_splits_for(B, (N + TP - 1) / TP, target_blocks > 0 ? target_blocks : TRUNK_DEFAULT_TARGET_BLOCKS);
+    const int T = (N + TP - 1) / TP;
+    return target_blocks > 0 ? pngpd_splits_for(B, T, target_blocks) : auto_splits(B, T);
 }
 
 size_t pngpd_trunk_workspace_bytes(int B, int N, int splits) {
@@ -187,8 +206,7 @@ int pngpd_trunk_fwd_infer(const float *x, int B, int N, const float *trans,
     const size_t lds = TRUNK_LDS_FLOATS * sizeof(float);
     int st = pngpd_allow_lds((const void *)trunk_infer_kernel, lds);
     if (st != PNGPD_OK) return st;
-    int CS = 1;
-    if (B * S <= 128) CS = 4; else if (B * S <= 256) CS = 2;
+    const int CS = best_cs(B, T, S);
     hipLaunchKernelGGL(trunk_infer_kernel, dim3((unsigned)B * S * CS), dim3(256), lds, (hipStream_t)stream,
                        x, N, trans, w1, b1, w2p, b2, w3p, b3, relu_last, T, S, CS, dst);
     st = pngpd_launch_status();
