@@ -100,3 +100,26 @@ def oracle_train_step_on_device(sd, x, y, dtype, device):
     del sdd, loss, logp, trans, grads, stats
     torch.cuda.empty_cache()
     return out
+
+
+def oracle_forward_on_device(sd, x, device, dtype=torch.float64, chunk=128):
+    """The oracle's eval-mode forward (``oracle.pointnet_oracle.forward_torch`` — the reference's ATen op sequence)
+    over the WHOLE batch, executed through ATen on the GPU in ``dtype`` (fp64: 1x1 convolutions as matmuls, MIOpen has
+    no fp64 convolution).  Eval-mode samples are independent, so the batch is walked in chunks to bound the
+    (chunk,1024,N) activations.  Test-only checker."""
+    from oracle import pointnet_oracle as po
+    old = po.CONV_AS_MATMUL
+    po.CONV_AS_MATMUL = True
+    try:
+        sdd = {k: (v.to(device).to(dtype) if v.is_floating_point() else v.to(device)) for k, v in sd.items()}
+        lps, trs = [], []
+        with torch.no_grad():
+            for i in range(0, x.shape[0], chunk):
+                lp, tr = po.forward_torch(sdd, x[i:i + chunk].to(device).to(dtype))
+                lps.append(lp.cpu()); trs.append(tr.cpu())
+    finally:
+        po.CONV_AS_MATMUL = old
+    torch.cuda.synchronize()
+    del sdd
+    torch.cuda.empty_cache()
+    return torch.cat(lps), torch.cat(trs)

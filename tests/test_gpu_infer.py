@@ -113,8 +113,8 @@ def test_model_vs_oracle(B, N, k, cuda_device):
 
 
 def test_full_size_properties(cuda_device):
-    """BASELINE config 2 size (B=1024,N=1024): size-independent exact properties + an oracle
-    spot-check on a slice of the batch."""
+    """BASELINE config 2 size (B=1024,N=1024): size-independent exact properties + the fp64 oracle
+    over all 1024 clouds (run on the device)."""
     B, N = 1024, 1024
     m = build_model(N, 2, 50, 4360).eval()
     sd = state_dict_cpu(m)
@@ -137,12 +137,12 @@ def test_full_size_properties(cuda_device):
         # (4) determinism
         lp2, _ = mg(xg)
         assert torch.equal(lp, lp2)
-    # (5) oracle on a slice (eval mode: samples are independent)
-    idx = torch.arange(0, B, 128)
-    with torch.no_grad():
-        lp_ref, tr_ref = po.forward_torch(sd, x[idx])
-    np.testing.assert_allclose(lp[idx].cpu().numpy(), lp_ref.numpy(), atol=ATOL_LOGP, rtol=0)
-    np.testing.assert_allclose(tr[idx].cpu().numpy(), tr_ref.numpy(), atol=ATOL_LOGP, rtol=0)
+    # (5) the oracle over the WHOLE batch (fp64, run on the device): every one of the B clouds, not a slice
+    from tests.helpers import oracle_forward_on_device
+    lp_ref, tr_ref = oracle_forward_on_device(sd, x, cuda_device)
+    np.testing.assert_allclose(lp.cpu().numpy(), lp_ref.numpy(), atol=ATOL_LOGP, rtol=0)
+    np.testing.assert_allclose(tr.cpu().numpy(), tr_ref.numpy(), atol=ATOL_LOGP, rtol=0)
+    assert (lp.argmax(1).cpu() == lp_ref.argmax(1)).all()
 
 
 def test_duplicate_points_do_not_change_pool(cuda_device):

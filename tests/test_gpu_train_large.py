@@ -92,17 +92,25 @@ def test_train_step_bench_size(cuda_device):
     _run_case(1024, 1024, 2, cuda_device, None, "one")
 
 
-def test_trunk_intermediates_large(cuda_device, pass_sequencing):
+@pytest.mark.parametrize("which", ["feat", "stn"])
+def test_trunk_intermediates_large(which, cuda_device, pass_sequencing):
     """Kernel-level check at S = 1 with many tiles per workgroup (B = 256, N = 1024): every accumulated quantity of
-    the feat-trunk backward vs the fp64 pass-structured prototype fed the same trans and upstream gradient."""
+    a trunk's backward vs the fp64 pass-structured prototype fed the same trans and upstream gradient.
+    ``feat``: the PointNetfeat trunk (input transform, no ReLU before the max, pointnet.py:140-149); ``stn``: the
+    STN3d trunk (no transform, ReLU BEFORE the max — ``dp`` is masked by ``pooled > 0``, pointnet.py:29-33)."""
     from pointnetgpd_amd import train
     from tests.test_gpu_train import _trunk_params
     from tests.train_algo_prototype import trunk_fwd, trunk_bwd
     B, N, k = 256, 1024, 2
     m = build_model(N, k, 96, 4516).train()
+    if which == "stn":
+        # the max over 1024 points of a normalised channel is ~ +3 sigma, so with the recipe's beta ~ N(0, 0.1) the
+        # ReLU behind bn3 never clamps a pooled value; shift every other channel's beta so that the mask really bites
+        with torch.no_grad():
+            m.feat.stn.bn3.bias[::2] -= 3.0
     x = synth_cloud(B, N, 916, "box") * 4.0
     y = (torch.arange(B) * 7 % k).long()
-    P = _trunk_params(m.feat)
+    P = _trunk_params(m.feat if which == "feat" else m.feat.stn)
     mg = m.to(cuda_device)
     caps = []
     orig = train.TrunkTrainFn.backward
@@ -120,11 +128,15 @@ def test_trunk_intermediates_large(cuda_device, pass_sequencing):
         F.nll_loss(logp, y.to(cuda_device)).backward()
     finally:
         train.TrunkTrainFn.backward = orig
-    feat = caps[0]
+    feat = caps[0] if which == "feat" else caps[1]   # backward order: the feat trunk first, then the STN trunk
     T = trans.detach().double().cpu()
     dev = cuda_device
     Pd = {n: v.to(dev) for n, v in P.items()}
-    _, sv = trunk_fwd(x.double().to(dev), T.to(dev), Pd, relu_last=False)
+    _, sv = trunk_fwd(x.double().to(dev), T.to(dev) if which == "feat" else None, Pd, relu_last=which == "stn")
+    if which == "stn":
+        # the masking itself: entries of dp whose pooled output the ReLU clamped must not reach any gradient
+        dead = sv["y"] <= 0
+        assert 0.05 < dead.double().mean().item() < 0.95, "the case must exercise the ReLU-before-max mask"
     flips = (feat["idx"].long() != sv["idx"])
     assert flips.double().mean().item() < 1e-3
     # An arg-max that flips at an fp32 near-tie moves one upstream gradient entry to another point with (to round-off)
@@ -138,6 +150,6 @@ def test_trunk_intermediates_large(cuda_device, pass_sequencing):
         tol = 5e-3 if kx in ("a1", "a2", "c1", "c2", "Rb") else 1e-3       # cancelling batch sums: 5e-3
         r = _rel(feat[kx].cpu(), dbg[kx].cpu())
         assert r < tol, (kx, r)
-    for kx, ky in [("dW1", "W1"), ("dW2", "W2"), ("dW3", "W3"), ("dT", "T")]:
+    for kx, ky in [("dW1", "W1"), ("dW2", "W2"), ("dW3", "W3")] + ([("dT", "T")] if which == "feat" else []):
         r = _rel(feat[kx].cpu(), g[ky].cpu())
         assert r < 1e-3, (kx, r)
