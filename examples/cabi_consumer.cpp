@@ -5,7 +5,10 @@
 //
 // build:  hipcc --offload-arch=gfx950 -O2 -Iinclude examples/cabi_consumer.cpp -Lpointnetgpd_amd -lpngpd \
 //               -Wl,-rpath,'$ORIGIN/../pointnetgpd_amd' -o examples/cabi_consumer
-// run:    examples/cabi_consumer [B] [N]
+// run:    examples/cabi_consumer [B] [N] [train]
+// With a third argument it also runs ONE training step of a trunk through the fused per-direction entries
+// (pngpd_trunk_train_fwd / _bwd with caller-provided save / scratch buffers) followed by pngpd_adam_flat on the
+// layer-3 weight, and prints checksums of the pooled output, every gradient and the updated weight.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -104,5 +107,58 @@ int main(int argc, char **argv) {
         for (int j = 0; j < 9; ++j) std::printf(" %.9e", out[b * 9 + j]);
         std::printf("\n");
     }
+    if (argc <= 3) return 0;
+
+    // ---- one training step of the trunk (train-mode BatchNorm, closed-form backward) through the fused entries
+    pngpd_trunk_train_t a = {};
+    a.x = dx; a.trans = dT; a.B = B; a.N = N; a.S = pngpd_trunk_splits(B, N, 0);
+    a.relu_last = 0; a.precision = 0; a.fp32_side = 0; a.need_bwd = 1; a.eps = 1e-5f; a.momentum = 0.1f;
+    a.w1 = dW[0]; a.b1 = db[0]; a.g1 = dg[0]; a.be1 = dbe[0];
+    a.w2 = dW[1]; a.b2 = db[1]; a.g2 = dg[1]; a.be2 = dbe[1];
+    a.w3 = dW[2]; a.b3 = db[2]; a.g3 = dg[2]; a.be3 = dbe[2];
+    a.rm1 = dmu[0]; a.rv1 = dva[0]; a.rm2 = dmu[1]; a.rv2 = dva[1]; a.rm3 = dmu[2]; a.rv3 = dva[2];   // running stats
+    a.save_bytes = pngpd_trunk_train_save_bytes(&a);
+    a.scratch_bytes = pngpd_trunk_train_scratch_bytes(&a);
+    if (!a.save_bytes || !a.scratch_bytes || pngpd_struct_bytes(0) != sizeof(a)) { std::fprintf(stderr, "size query failed\n"); return 5; }
+    HIP_OK(hipMalloc(&a.save, a.save_bytes));
+    HIP_OK(hipMalloc(&a.scratch, a.scratch_bytes));
+    float *dzhat, *ddp, *dgrad, *ddT, *dm, *dv;
+    int *didx;
+    const size_t goff[13] = {0, 192, 256, 320, 384, 8576, 8704, 8832, 8960, 140032, 141056, 142080, 143104};
+    HIP_OK(hipMalloc((void **)&dzhat, (size_t)B * 1024 * sizeof(float)));
+    HIP_OK(hipMalloc((void **)&didx, (size_t)B * 1024 * sizeof(int)));
+    HIP_OK(hipMalloc((void **)&dgrad, goff[12] * sizeof(float)));
+    HIP_OK(hipMalloc((void **)&ddT, (size_t)B * 9 * sizeof(float)));
+    a.pooled = dpool; a.idx = didx; a.zhat = dzhat;
+    {   // a too-small scratch must be refused
+        pngpd_trunk_train_t bad = a; bad.scratch_bytes = 16;
+        if (pngpd_trunk_train_fwd(&bad, st) != PNGPD_ERR_WORKSPACE) { std::fprintf(stderr, "scratch check missing\n"); return 4; }
+    }
+    PN_OK(pngpd_trunk_train_fwd(&a, st));
+    auto dpv = fill(g, (size_t)B * 1024, 2.0f);           // upstream gradient dL/dpooled
+    if (upload(dpv, &ddp)) return 2;
+    a.dp = ddp; a.dT = ddT;
+    float **gp[12] = {&a.dW1, &a.db1, &a.dg1, &a.dbe1, &a.dW2, &a.db2, &a.dg2, &a.dbe2, &a.dW3, &a.db3, &a.dg3, &a.dbe3};
+    for (int i = 0; i < 12; ++i) *gp[i] = dgrad + goff[i];
+    PN_OK(pngpd_trunk_train_bwd(&a, st));
+    // Adam (torch defaults, lr 0.005, first step) on the layer-3 weight with its gradient slice
+    const size_t n3 = 1024 * 128;
+    HIP_OK(hipMalloc((void **)&dm, n3 * sizeof(float))); HIP_OK(hipMalloc((void **)&dv, n3 * sizeof(float)));
+    HIP_OK(hipMemsetAsync(dm, 0, n3 * sizeof(float), st)); HIP_OK(hipMemsetAsync(dv, 0, n3 * sizeof(float), st));
+    PN_OK(pngpd_adam_flat(dW[2], a.dW3, dm, dv, (long long)n3, 0.005f, nullptr, 0.9f, 0.999f, 1e-8f, 1.0f, nullptr, 1.0f,
+                          nullptr, st));
+    HIP_OK(hipStreamSynchronize(st));
+    auto csum = [&](const float *d, size_t n, const char *name) -> int {
+        std::vector<float> h(n);
+        HIP_OK(hipMemcpy(h.data(), d, n * sizeof(float), hipMemcpyDeviceToHost));
+        double s2 = 0, a2 = 0;
+        for (float v : h) { s2 += v; a2 += v > 0 ? v : -v; }
+        std::printf("train %s %.9e %.9e\n", name, s2, a2);
+        return 0;
+    };
+    const char *names[12] = {"dW1", "db1", "dg1", "dbe1", "dW2", "db2", "dg2", "dbe2", "dW3", "db3", "dg3", "dbe3"};
+    if (csum(dpool, (size_t)B * 1024, "pooled")) return 2;
+    for (int i = 0; i < 12; ++i) if (csum(dgrad + goff[i], goff[i + 1] - goff[i], names[i])) return 2;
+    if (csum(ddT, (size_t)B * 9, "dT") || csum(dW[2], n3, "W3_after_adam") || csum(dmu[2], 1024, "running_mean3")) return 2;
     return 0;
 }

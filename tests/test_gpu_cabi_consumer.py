@@ -79,3 +79,75 @@ def test_cabi_consumer_matches_binding(B, N, cuda_device):
     ref_fc = ref_pool @ Wfc.astype(np.float64).T + bfc + np.eye(3).reshape(1, 9)
     np.testing.assert_allclose(pool_np, ref_pool, rtol=0, atol=2e-5)
     np.testing.assert_allclose(fc, ref_fc, rtol=0, atol=2e-4)
+
+
+@pytest.mark.parametrize("B,N", [(5, 200), (16, 750)])
+def test_cabi_consumer_train_step_matches_binding(B, N, cuda_device):
+    """The torch-free consumer drives ONE training step of a trunk through the fused per-direction entries
+    (pngpd_trunk_train_fwd / _bwd, caller-provided save / scratch) and pngpd_adam_flat; the same calls through the
+    ctypes binding on the same inputs give the same numbers, and a too-small scratch buffer is refused."""
+    import ctypes
+    from pointnetgpd_amd import _lib, ops
+    subprocess.run(["make", "-C", os.path.join(ROOT, "pointnetgpd_amd", "csrc"), "example"], check=True,
+                   capture_output=True)
+    res = subprocess.run([EXE, str(B), str(N), "train"], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    got = {ln.split()[1]: (float(ln.split()[2]), float(ln.split()[3]))
+           for ln in res.stdout.splitlines() if ln.startswith("train ")}
+    assert len(got) == 16, got.keys()
+
+    g = Lcg(12345)
+    x = g.fill(B * 3 * N, 0.1).reshape(B, 3, N)
+    T = g.fill(B * 9, 0.2).reshape(B, 3, 3)
+    T[:, np.arange(3), np.arange(3)] += np.float32(1.0)
+    C = [3, 64, 128, 1024]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda_device)
+    L = []
+    for l in range(3):
+        L.append(dict(W=t(g.fill(C[l + 1] * C[l], 2.0 / C[l]).reshape(C[l + 1], C[l])), b=t(g.fill(C[l + 1], 0.1)),
+                      g=g.fill(C[l + 1], 1.0, 1.0), be=t(g.fill(C[l + 1], 0.2)), mu=t(g.fill(C[l + 1], 0.2)),
+                      var=t(g.fill(C[l + 1], 1.0, 1.0))))
+    L[2]["g"][::7] *= -1
+    for l in range(3):
+        L[l]["g"] = t(L[l]["g"])
+    g.fill(9 * 1024, 0.05); g.fill(9, 0.1)                    # the consumer's FC layer draws
+    dp = t(g.fill(B * 1024, 2.0).reshape(B, 1024))
+    xd, Td = t(x), t(T)
+    lib = _lib.load()
+    a = _lib.TrunkTrainArgs()
+    a.x, a.trans, a.B, a.N, a.S = xd.data_ptr(), Td.data_ptr(), B, N, ops.train_splits(B, N)
+    a.need_bwd, a.eps, a.momentum = 1, 1e-5, 0.1
+    for i, l in enumerate(L, 1):
+        setattr(a, f"w{i}", l["W"].data_ptr()); setattr(a, f"b{i}", l["b"].data_ptr())
+        setattr(a, f"g{i}", l["g"].data_ptr()); setattr(a, f"be{i}", l["be"].data_ptr())
+        setattr(a, f"rm{i}", l["mu"].data_ptr()); setattr(a, f"rv{i}", l["var"].data_ptr())
+    sb, wb = lib.pngpd_trunk_train_save_bytes(ctypes.addressof(a)), lib.pngpd_trunk_train_scratch_bytes(ctypes.addressof(a))
+    save = torch.empty(sb, dtype=torch.uint8, device=cuda_device)
+    ws = torch.empty(wb, dtype=torch.uint8, device=cuda_device)
+    a.save, a.save_bytes, a.scratch, a.scratch_bytes = save.data_ptr(), sb, ws.data_ptr(), wb
+    pooled = torch.empty(B, 1024, device=cuda_device); zhat = torch.empty_like(pooled)
+    idx = torch.empty(B, 1024, dtype=torch.int32, device=cuda_device)
+    a.pooled, a.idx, a.zhat = pooled.data_ptr(), idx.data_ptr(), zhat.data_ptr()
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.pngpd_trunk_train_fwd(ctypes.addressof(a), st), "fwd")
+    sizes = [192, 64, 64, 64, 8192, 128, 128, 128, 131072, 1024, 1024, 1024]
+    names = ["dW1", "db1", "dg1", "dbe1", "dW2", "db2", "dg2", "dbe2", "dW3", "db3", "dg3", "dbe3"]
+    grad = torch.empty(sum(sizes), device=cuda_device)
+    views = grad.split(sizes)
+    dT = torch.empty(B, 3, 3, device=cuda_device)
+    a.dp, a.dT = dp.data_ptr(), dT.data_ptr()
+    for n, v in zip(names, views):
+        setattr(a, n, v.data_ptr())
+    _lib.check(lib.pngpd_trunk_train_bwd(ctypes.addressof(a), st), "bwd")
+    m, v2 = torch.zeros(1024 * 128, device=cuda_device), torch.zeros(1024 * 128, device=cuda_device)
+    _lib.check(lib.pngpd_adam_flat(L[2]["W"].data_ptr(), views[8].data_ptr(), m.data_ptr(), v2.data_ptr(), 1024 * 128,
+                                   0.005, None, 0.9, 0.999, 1e-8, 1.0, None, 1.0, None, st), "adam")
+    torch.cuda.synchronize()
+    mine = dict(pooled=pooled, dT=dT, W3_after_adam=L[2]["W"], running_mean3=L[2]["mu"])
+    mine.update(dict(zip(names, views)))
+    for n, (s, ab) in got.items():
+        h = mine[n].double().cpu()
+        assert abs(h.sum().item() - s) <= 1e-9 * max(abs(s), ab * 1e-3, 1e-30) + 1e-12, (n, h.sum().item(), s)
+        assert abs(h.abs().sum().item() - ab) <= 1e-9 * max(ab, 1e-30) + 1e-12, (n, h.abs().sum().item(), ab)
+    assert got["db1"] == (0.0, 0.0) and got["db3"] == (0.0, 0.0)      # conv biases ahead of a train-mode BN
+    assert got["dW3"][1] > 0 and got["dT"][1] > 0
