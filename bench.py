@@ -271,6 +271,63 @@ def _self_spawn(args):
     return subprocess.call(cmd, env=env)
 
 
+def _trunk_only(batch, num_points, reps):
+    """Child mode of --pmc: nothing but ``reps`` launches of the dominant kernel (run under rocprofv3 --pmc)."""
+    import torch
+    from pointnetgpd_amd import ops
+    from pointnetgpd_amd.model import pointnet as pn
+    dev = torch.device("cuda", 0)
+    model = build_model(num_points, 2, dev)
+    x = synth_clouds(batch, num_points, 1234, dev)
+    wts = pn._trunk_infer_weights(model.feat.stn, dev)
+    with torch.no_grad():
+        for _ in range(reps):
+            ops.trunk_fwd_infer(x, None, *wts, relu_last=True)
+    torch.cuda.synchronize()
+
+
+def measure_traffic_pmc(batch, num_points, reps=6):
+    """HBM bytes per launch of trunk_infer_kernel from rocprofv3 PMC counters collected NOW, on this box: FETCH_SIZE and
+    WRITE_SIZE each in its own pass (they do not fit one pass; no trace domain besides --kernel-trace), the gfx950
+    correction of MI355X_MICROARCH.md applied (FETCH_SIZE tallies wide streaming reads at half their bytes).
+    Returns (bytes, description) or (None, reason)."""
+    import shutil
+    import sqlite3
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found on this box"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="pngpd_pmc_", dir="/tmp")
+        env = dict(os.environ, TMPDIR="/tmp")
+        for k_ in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k_, None)
+        cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+               "--trunk-only", str(reps), "--batch", str(batch), "--num-points", str(num_points)]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+        except Exception as e:      # noqa: BLE001
+            return None, f"rocprofv3 pass {counter} failed: {type(e).__name__}"
+        dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
+        if r.returncode != 0 or not dbs:
+            return None, f"rocprofv3 pass {counter} produced no database (rc {r.returncode})"
+        cur = sqlite3.connect(dbs[0]).cursor()
+        q = ("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? "
+             "group by kernel_name")
+        for name, n, v in cur.execute(q, (counter,)):
+            if "trunk_infer_kernel" in name and "x3" not in name:
+                vals[counter] = (n, v)
+        shutil.rmtree(d, ignore_errors=True)
+        if counter not in vals:
+            return None, f"{counter}: the kernel was not found in the counter table"
+    f_kb, w_kb = vals["FETCH_SIZE"][1], vals["WRITE_SIZE"][1]
+    return int(round((2 * f_kb + w_kb) * 1024)), (
+        f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over {vals['FETCH_SIZE'][0]} "
+        f"launches; 2 x FETCH_SIZE ({f_kb:.0f} KB raw; gfx950 tallies wide streaming reads at half their bytes) + "
+        f"WRITE_SIZE ({w_kb:.0f} KB)")
+
+
 class Timer:
     """Blocks of exactly ``steps`` steps, each bracketed by barrier + synchronize and by HIP events on the launch
     stream; repeated until ``min_seconds`` of timed work; max over ranks per block; median block reported."""
@@ -326,7 +383,14 @@ def main():
     ap.add_argument("--no-train", action="store_true", help="skip the training-step legs")
     ap.add_argument("--no-fast", action="store_true", help="skip the opt-in bf16x3 legs")
     ap.add_argument("--graph", action="store_true", help="also time the train step replayed from a HIP graph")
+    ap.add_argument("--pmc", action="store_true",
+                    help="measure roofline.traffic NOW with two rocprofv3 --pmc passes over the dominant kernel "
+                         "(N = 1 only; ~15 s) instead of citing the stored figure of profiles/pmc_trunk.json")
+    ap.add_argument("--trunk-only", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.trunk_only:
+        _trunk_only(args.batch, args.num_points, args.trunk_only)
+        return
 
     env_world = int(os.environ.get("WORLD_SIZE", "0") or 0)
     if args.gpus > 1 and env_world == 0:
@@ -533,14 +597,22 @@ def main():
     achieved = trunk_flops / (trunk_ms * 1e-3) / 1e12
 
     traffic, traffic_src = None, None
+    if args.pmc and world == 1:
+        traffic, traffic_src = measure_traffic_pmc(B, N)
+        if traffic is None:
+            traffic_src = "in-run PMC measurement failed (" + traffic_src + "); falling back to the stored figure"
     try:
+        if traffic is not None:
+            raise StopIteration
         with open(os.path.join(ROOT, "profiles", "pmc_trunk.json")) as f:
             pmc = json.load(f)
         if B == pmc.get("B") and N == pmc.get("N"):
             traffic = pmc["traffic_bytes_per_launch"]
-            traffic_src = (f"STORED rocprofv3 PMC figure (not measured in this run): profiles/pmc_trunk.json, "
-                           f"taken at commit {pmc.get('commit', '?')}; 2*FETCH_SIZE + WRITE_SIZE, separate passes")
-    except Exception:
+            traffic_src = ((traffic_src + "; " if traffic_src else "") +
+                           f"STORED rocprofv3 PMC figure (not measured in this run; pass --pmc to measure): "
+                           f"profiles/pmc_trunk.json, taken at commit {pmc.get('commit', '?')}; 2*FETCH_SIZE + "
+                           f"WRITE_SIZE, separate passes")
+    except (Exception, StopIteration):
         pass
     if rank == 0:
         value = world * B * args.steps / dt
