@@ -62,3 +62,18 @@ static inline int pngpd_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PNGPD_OK : (PNGPD_ERR_HIP + (int)e);
 }
+
+// Per-phase cycle accounting for kernel experiments (variant builds only: -DPNGPD_TIMING -fgpu-rdc is NOT needed: every
+// translation unit accumulates into its own copy read back by pngpd_tm_read / pngpd_tm_read_x3; tools/phase_times.py;
+// never in the product library).
+#ifdef PNGPD_TIMING
+#define TM_DECL unsigned long long tm_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tm_t = __builtin_amdgcn_s_memtime();
+#define TM(i) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tm_[i] += n_ - tm_t; tm_t = n_; }
+#define TM_END_TO(arr) if ((threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&arr[i_], tm_[i_]); atomicAdd(&arr[15], 1ull); }
+#define TM_END TM_END_TO(pngpd_tm)
+#else
+#define TM_DECL
+#define TM(i)
+#define TM_END
+#define TM_END_TO(arr)
+#endif

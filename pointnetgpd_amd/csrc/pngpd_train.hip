@@ -16,23 +16,14 @@
 //                   h2 = relu(z2*s2c + t2c),  zhat2 = z2*is2 + nm2,   z2 = W2 h1   (no bias)
 #include "pngpd_tile.h"
 
-// Per-phase cycle accounting for kernel experiments (variant builds only: -DPNGPD_TIMING, tools/phase_times.py; never in
-// the product library).
 #ifdef PNGPD_TIMING
 __device__ unsigned long long pngpd_tm[16];
-#define TM_DECL unsigned long long tm_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tm_t = __builtin_amdgcn_s_memtime();
-#define TM(i) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); tm_[i] += n_ - tm_t; tm_t = n_; }
-#define TM_END if ((threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&pngpd_tm[i_], tm_[i_]); atomicAdd(&pngpd_tm[15], 1ull); }
 extern "C" int pngpd_tm_read(unsigned long long *host16, int reset) {
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(host16, HIP_SYMBOL(pngpd_tm), sizeof(unsigned long long) * 16);
     if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(pngpd_tm), z, sizeof(z)); }
     return 0;
 }
-#else
-#define TM_DECL
-#define TM(i)
-#define TM_END
 #endif
 
 struct TrainChan {

@@ -12,6 +12,16 @@
 //   ds_read_b128), xs [3][128] f32, running max [1024] f32  ->  ~112 KB, one workgroup per CU.
 #include "pngpd_bf.h"
 
+#ifdef PNGPD_TIMING
+__device__ unsigned long long pngpd_tm_x3[16];
+extern "C" int pngpd_tm_read_x3(unsigned long long *host16, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(host16, HIP_SYMBOL(pngpd_tm_x3), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(pngpd_tm_x3), z, sizeof(z)); }
+    return 0;
+}
+#endif
+
 #define XP 128          // points per tile
 #define X1S 72          // h1 row stride (halfwords)
 #define X2S 136         // h2 row stride (halfwords)
@@ -90,7 +100,9 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
         px0 = ldx<XBF>(x, xo + n); px1 = ldx<XBF>(x, xo + N + n); px2 = ldx<XBF>(x, xo + 2 * (size_t)N + n);
     }
 
+    TM_DECL
     for (int tile = t0; tile < t1; ++tile) {
+        TM(0)
         if (tid < XP) {
             float x0 = px0, x1 = px1, x2 = px2;
             if (has_t) {
@@ -105,7 +117,9 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
                 px0 = ldx<XBF>(x, xo + n); px1 = ldx<XBF>(x, xo + N + n); px2 = ldx<XBF>(x, xo + 2 * (size_t)N + n);
             }
         }
+        TM(1)
         __syncthreads();
+        TM(2)
         {   // layer 1 (fp32 VALU): thread = (point p = tid & 127, 16-channel group g = tid >> 7 = wave >> 1)
             const int p = tid & 127, g = wave >> 1;
             const float x0 = xs[p], x1 = xs[XP + p], x2 = xs[2 * XP + p];
@@ -128,7 +142,9 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
                 if (NT == 3) dl[q] = vl;
             }
         }
+        TM(3)
         __syncthreads();
+        TM(4)
         {   // layer 2 (64 -> 128), bf16x3: wave owns channel block cb = wave & 3 and point blocks 2q, 2q+1
             const int cb = wave & 3, pb0 = (wave >> 2) * 2;
             f32x4 w2h[4], w2l[4];
@@ -158,7 +174,9 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
                 if (NT == 3) h2l[((pb0 + 1) * 32 + row) * X2S + cb * 32 + j] = lo;
             }
         }
+        TM(5)
         __syncthreads();
+        TM(6)
         // layer 3 (128 -> 1024), bf16x3: wave owns channel blocks wave + 8*ci, all four point blocks
         // One channel block x all four point blocks per step: 4 independent accumulator chains (an accumulator is
         // re-used every 4th MFMA) and the A fragments of k-step ks+1 in flight while k-step ks issues.
@@ -202,8 +220,10 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
         };
 #pragma unroll 1
         for (int ci = 0; ci < 4; ++ci) block4(wave + 8 * ci);
+        TM(7)
         // the barrier after the next tile's layer 1 orders the h2 rewrite after these reads
     }
+    TM_END_TO(pngpd_tm_x3)
     if (h == 0) {
         float *o = out + ((size_t)b * S + s) * 1024;
 #pragma unroll
