@@ -1,7 +1,11 @@
 """Drop-in (same names, arguments and return layouts) for the two hot functions of the reference's 36-hour
 preprocessing script ``PointNetGPD/ycb_cloud_generate.py`` (README.md:166): ``registerDepthMap`` (:60-121) and
 ``registeredDepthMapToPointCloud`` (:124-184) — pure-Python double loops over 480x640 pixels there, one kernel launch
-each here (``pointnetgpd_amd/csrc/pngpd_gpd.hip``).  numpy in, numpy out, bit-identical values."""
+each here (``pointnetgpd_amd/csrc/pngpd_gpd.hip``).  numpy in, numpy out, bit-identical values.
+
+One deliberate difference: a NaN depth is SKIPPED by ``registeredDepthMapToPointCloud`` here (the kernel keeps pixels
+with ``depth > 0``), whereas the reference's test ``depth <= 0`` is False for NaN and it would emit a NaN point.  The
+YCB depth maps hold zeros for missing returns, never NaN."""
 import numpy as np
 
 from . import gpd_ops

@@ -43,7 +43,11 @@ __global__ __launch_bounds__(256, 2) void trunk_infer_kernel(
     // A non-finite input coordinate must reach the output like it does through max_pool1d / torch.max (which
     // propagate NaN), but fmaxf drops NaNs and the ReLUs turn them into zeros: remember it and poison this
     // workgroup's pooled row at the end.
+    // (+-Inf coordinates poison the row as well: the reference can still produce finite outputs for them — relu(-inf)
+    // = 0 — but an infinite point is a corrupt cloud, and NaN is the conservative answer.)
     __shared__ int s_bad;
+    static_assert(TP <= 64, "s_bad: the clearing store (tid 0) and the setting stores (tid < TP) must sit in wave 0, "
+                            "where stores retire in program order; a larger TP needs a barrier in between");
     if (L.tid == 0) s_bad = 0;
     // layer-3 weight fragments are double-buffered in registers: while channel block ci is on the
     // MFMA pipe the 16 KiB of block ci+1 are in flight from L2 (the last block of a tile prefetches the

@@ -24,7 +24,12 @@ def _f64(t, dev):
 
 def project_grasps(points, normals, offsets, widths, chann=3, device=None):
     """points / normals (sum M_g,3) float64 (numpy or CUDA), offsets (G+1) int32, widths (G,) -> (G,60,60,chann)
-    float64 CUDA tensor, bit-identical to the reference's ``project_pc`` per grasp."""
+    float64 CUDA tensor, bit-identical to the reference's ``project_pc`` per grasp.
+
+    PRECONDITION (the reference's own, dataset.py:104-128): the points are IN-BOX crops (``collect_pc`` output), so
+    every voxel index ``floor(coord / resolution + 30)`` lies in [0, 60).  A point outside that range is DROPPED by the
+    kernel; the reference's numpy code would instead wrap a negative index to the other side of the image or raise
+    ``IndexError`` for an index >= 60.  Callers feeding arbitrary clouds must crop first."""
     if chann not in (3, 12):
         raise NotImplementedError("project_chann must be 3 or 12 (dataset.py:218-219)")
     dev = device or (points.device if isinstance(points, torch.Tensor) else torch.device("cuda", torch.cuda.current_device()))

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 python -m pytest tests -m gpu -q 2>&1 | tail -2 | tee gpurun_out/${TAG}_gpu_suite.txt
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_gpu_suite.txt
-python bench.py > gpurun_out/${TAG}_bench_final.json 2> /tmp/bench.err; echo "bench rc=$?"; cut -c1-300 gpurun_out/${TAG}_bench_final.json
+python bench.py --pmc > gpurun_out/${TAG}_bench_final.json 2> /tmp/bench.err; echo "bench rc=$?"; cut -c1-300 gpurun_out/${TAG}_bench_final.json
 timeout 300 python tools/bench_configs.py > gpurun_out/${TAG}_bench_configs.jsonl 2> /tmp/cfg.err; echo "cfg rc=$?"
 timeout 120 python tools/bench_latency.py 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_latency.json
 timeout 200 python tools/bench_gpg.py --P 3000 20000 50000 --cpu-draws 2 2>/dev/null | tail -3 > gpurun_out/${TAG}_bench_gpg.jsonl
@@ -19,4 +19,8 @@ bash tools/trace_train.sh ${TAG} > /tmp/tr.log 2>&1; grep "rc=" /tmp/tr.log
 bash tools/trace_train.sh ${TAG} bf16 > /tmp/tr.log 2>&1; grep "rc=" /tmp/tr.log
 bash tools/trace_train.sh ${TAG} bf16x3 > /tmp/tr.log 2>&1; grep "rc=" /tmp/tr.log
 bash tools/pmc_round.sh ${TAG} hbm > /tmp/pmc.log 2>&1; grep "rc=" /tmp/pmc.log
+bash tools/pmc_train.sh ${TAG} > /tmp/pmct.log 2>&1; grep "rc=" /tmp/pmct.log
+timeout 120 python tools/bench_eval.py 2>/dev/null > gpurun_out/${TAG}_bench_eval.txt
+timeout 120 python tools/bench_step.py 2>/dev/null > gpurun_out/${TAG}_bench_step.txt
+for f in trace_small_train trace_small_eval; do rm -rf /tmp/pst; ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/pst -o t -- python $GRAFT_REPO_ROOT/tools/$f.py > /tmp/$f.log 2>&1 ); DB=$(find /tmp/pst -name "*.db" | head -1); [ -n "$DB" ] && python tools/rocprof_summary.py --all gpurun_out/${TAG}_${f}.md "$f (B 64 N 750)=$DB" > /dev/null; done
 ls gpurun_out | grep ${TAG}

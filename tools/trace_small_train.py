@@ -9,8 +9,9 @@ B, N, k = int(os.environ.get("B", 64)), int(os.environ.get("N", 750)), 2
 torch.manual_seed(0)
 m = pn.PointNetCls(N, 3, k).to(dev).train()
 x = bench.synth_clouds(B, N, 1, dev); y = torch.randint(0, k, (B,), device=dev)
-opt = torch.optim.Adam(m.parameters(), lr=0.005, fused=True)
+from pointnetgpd_amd.optim import FlatAdam
+opt = FlatAdam(m.parameters(), lr=0.005)
 for i in range(12):
-    opt.zero_grad(set_to_none=True)
+    opt.zero_grad()
     lp, _ = m(x); F.nll_loss(lp, y).backward(); opt.step()
 torch.cuda.synchronize()
