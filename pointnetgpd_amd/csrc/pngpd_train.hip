@@ -1324,9 +1324,30 @@ static int launch_bwd_e(dim3 grid, size_t lds, hipStream_t sm, const float *x, i
 
 extern "C" {
 
+// Workgroups per cloud for the training passes when the caller names no target (target_blocks <= 0).  512 workgroups are
+// resident (2 per CU); every workgroup leaves ~80 KB of partial sums (Gram blocks, dW2 share) that a reduce launch
+// streams back, so at small batches "one tile per workgroup" both overshoots a resident round and triples the partial
+// traffic.  Cost of S, in tile times, fitted to tools/bench_train_splits.py (B 32..256, N 750 / 1024, and B = N = 1024):
+//   rounds(B S / 512) * (ceil(T/S) * (B S <= 256 ? 0.6 : 1) + 0.5)  +  0.5 * B S / 512
+// (0.6: a workgroup alone on its CU does not share the MFMA pipe; 0.5: prologue; last term: partial write + reduce).
+// Measured against the old rule (aim at 1024 workgroups): B=64 N=750 0.960 -> 0.853 ms per step, B=128 N=750 1.483 ->
+// 1.189 ms, B=256 N=1024 2.400 -> 2.319 ms, B=64 N=1024 1.018 -> 0.945 ms; B >= 512 unchanged (S = 1).
+static int train_auto_splits(int B, int T) {
+    int bestS = 1;
+    double best = 1e300;
+    for (int S = 1; S <= T; ++S) {
+        const long G = (long)B * S;
+        const double tiles = (double)((T + S - 1) / S) * (G <= 256 ? 0.6 : 1.0);
+        const double v = (double)((G + 511) / 512) * (tiles + 0.5) + 0.5 * (double)G / 512.0;
+        if (v < best - 1e-9) { best = v; bestS = S; }
+    }
+    return bestS;
+}
+
 int pngpd_trunk_splits(int B, int N, int target_blocks) {
     if (B <= 0 || N <= 0) return 0;
-    return pngpd_splits_for(B, (N + TP - 1) / TP, target_blocks > 0 ? target_blocks : 1024);
+    const int T = (N + TP - 1) / TP;
+    return target_blocks > 0 ? pngpd_splits_for(B, T, target_blocks) : train_auto_splits(B, T);
 }
 
 size_t pngpd_trunk_g2t_bytes(int B, int N) {

@@ -185,13 +185,13 @@ def _f32(t, name, shape=None):
     return _req(t, name, shape)
 
 
-TRAIN_TARGET_BLOCKS = 1024     # host-side default for the training passes (two resident rounds of 2 workgroups per CU)
+TRAIN_TARGET_BLOCKS = 0        # 0: the library's cost model (pngpd_trunk_splits); > 0: aim at that many workgroups
 
 
 def train_splits(B, N, target_blocks=None):
     """Workgroups per cloud for the training passes.  A pure function of its arguments: the caller passes the
     result to every pass AND sizes the partial buffers with it (the library keeps no tuning state)."""
-    return _lib.load().pngpd_trunk_splits(int(B), int(N), int(target_blocks or TRAIN_TARGET_BLOCKS))
+    return _lib.load().pngpd_trunk_splits(int(B), int(N), int(target_blocks or TRAIN_TARGET_BLOCKS or 0))
 
 
 def pack_mfma_b(W, scale=None):
