@@ -121,3 +121,53 @@ def test_argument_validation_of_every_family():
     assert lib.pngpd_fc_fwd(p, 4, 12, p, p, 3, 0, p, None) == INV                                  # K % 8 != 0
     assert lib.pngpd_fc_fwd(p, 4, 16, p, p, 40, 3, p, None) == INV                                 # log_softmax needs Nout <= 32
     assert lib.pngpd_strerror(UNSUP) == b"unsupported configuration"
+
+
+def _header_struct_fields(name):
+    """Field names of ``typedef struct <name> { ... } <name>_t;`` in declaration order."""
+    src = open(HEADER).read()
+    body = re.search(r"typedef struct %s \{(.*?)\} %s_t;" % (name, name), src, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        # "const float *w1, *b1, *g1, *be1" / "int B, N" / "void *save" / "size_t save_bytes" / "long long *nbt1"
+        first, *rest = decl.split(",")
+        fields.append(re.findall(r"[A-Za-z_][A-Za-z0-9_]*", first)[-1])
+        fields += [re.findall(r"[A-Za-z_][A-Za-z0-9_]*", r)[-1] for r in rest]
+    return fields
+
+
+@pytest.mark.parametrize("cname,which,cls", [("pngpd_trunk_train", 0, "TrunkTrainArgs"), ("pngpd_head_train", 1, "HeadTrainArgs")])
+def test_argument_structs_mirror_the_header(cname, which, cls):
+    """The ctypes.Structure mirrors of the two training-entry argument structs: same fields in the same order as the
+    header, and the same size as the compiled library's sizeof (no compute call)."""
+    import ctypes
+    from pointnetgpd_amd import _lib
+    st = getattr(_lib, cls)
+    assert [f[0] for f in st._fields_] == _header_struct_fields(cname)
+    assert _lib.load().pngpd_struct_bytes(which) == ctypes.sizeof(st)
+
+
+def test_training_entries_validate_arguments():
+    """No GPU here: the fused entries must reject NULL / inconsistent descriptors before touching the device."""
+    import ctypes
+    from pointnetgpd_amd import _lib
+    lib = _lib.load()
+    a = _lib.TrunkTrainArgs()
+    assert lib.pngpd_trunk_train_save_bytes(ctypes.addressof(a)) == 0          # B = N = 0
+    a.B, a.N, a.S = 4, 100, 1
+    assert lib.pngpd_trunk_train_save_bytes(ctypes.addressof(a)) > 0
+    assert lib.pngpd_trunk_train_scratch_bytes(ctypes.addressof(a)) > 0
+    assert lib.pngpd_trunk_train_fwd(ctypes.addressof(a), None) == 1           # PNGPD_ERR_INVALID_ARG: NULL pointers
+    a.S = 3                                                                     # more splits than tiles (T = 2)
+    assert lib.pngpd_trunk_train_save_bytes(ctypes.addressof(a)) == 0
+    h = _lib.HeadTrainArgs()
+    assert lib.pngpd_head_train_fwd(ctypes.addressof(h), None) == 1
+    assert lib.pngpd_adam_flat(None, None, None, None, 16, 0.005, None, 0.9, 0.999, 1e-8, 1.0, None, 1.0, None, None) == 1
+    for B, N in [(1, 500), (64, 750), (1024, 1024)]:
+        T = (N + 63) // 64
+        assert 1 <= lib.pngpd_trunk_splits(B, N, 0) <= T and 1 <= lib.pngpd_trunk_infer_splits(B, N, 0) <= T
+    assert lib.pngpd_trunk_splits(64, 750, 0) == 4 and lib.pngpd_trunk_infer_splits(64, 750, 0) == 4
