@@ -87,14 +87,17 @@ class GradAverager:
             output.register_hook(self._early_ready)
 
     def _early_ready(self, grad):
-        # d loss / d trans exists: the PointNetCls head and the PointNetfeat trunk have written their gradient slices
-        if self._early is not None and not self._skip:
+        # d loss / d trans exists: the PointNetCls head and the PointNetfeat trunk have written their gradient slices.
+        # Only inside backward(): a plain loss.backward() followed by average_gradients() must not see a bucket leave
+        # early (it would be reduced twice, and unevenly across ranks).
+        if self._active and self._early is not None and not self._skip:
             lo, n = self._early
             self._pending.append(dist.all_reduce(self.opt.flat_g[lo:lo + n], op=dist.ReduceOp.SUM, group=self.group,
                                                  async_op=True))
         return None
 
     _skip = False
+    _active = False
 
     def backward(self, loss_sum, n_local):
         """Back-propagate this rank's SUMMED loss (``n_local`` kept samples; ``loss_sum`` None or n_local < 2: the rank
@@ -113,7 +116,11 @@ class GradAverager:
                     self._pending.append(dist.all_reduce(self.opt.flat_g[lo:lo + n], op=dist.ReduceOp.SUM,
                                                          group=self.group, async_op=True))
             else:
-                loss_sum.backward()
+                self._active = True
+                try:
+                    loss_sum.backward()
+                finally:
+                    self._active = False
             self._count.zero_()
             self._count[0] = float(0 if sit_out else n_local)
             lo, n = self._late
