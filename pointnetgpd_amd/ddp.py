@@ -90,20 +90,23 @@ class GradAverager:
         # d loss / d trans exists: the PointNetCls head and the PointNetfeat trunk have written their gradient slices.
         # Only inside backward(): a plain loss.backward() followed by average_gradients() must not see a bucket leave
         # early (it would be reduced twice, and unevenly across ranks).
-        if self._active and self._early is not None and not self._skip:
+        if self._active and self._early is not None and not self._skip and not self._early_sent:
             lo, n = self._early
+            self._early_sent = True
             self._pending.append(dist.all_reduce(self.opt.flat_g[lo:lo + n], op=dist.ReduceOp.SUM, group=self.group,
                                                  async_op=True))
         return None
 
     _skip = False
     _active = False
+    _early_sent = False
 
     def backward(self, loss_sum, n_local):
         """Back-propagate this rank's SUMMED loss (``n_local`` kept samples; ``loss_sum`` None or n_local < 2: the rank
         sits this step out with zero gradients) and combine gradients across ranks.  Returns the global kept-sample
-        count as a 0-dim device tensor; the optimizer divides by it (``FlatAdam.step(grad_div=count)``), or call
-        ``finish()`` for plain ``p.grad`` means."""
+        count as a 0-dim device tensor for the optimizer to divide by (``FlatAdam.step(grad_div=count)``) when a flat
+        buffer is attached; without one the parameters' ``.grad`` already hold the global per-sample mean and None is
+        returned."""
         self._pending = []
         sit_out = loss_sum is None or n_local < 2
         if self.opt is not None:
@@ -116,11 +119,17 @@ class GradAverager:
                     self._pending.append(dist.all_reduce(self.opt.flat_g[lo:lo + n], op=dist.ReduceOp.SUM,
                                                          group=self.group, async_op=True))
             else:
-                self._active = True
+                self._active, self._early_sent = True, False
                 try:
                     loss_sum.backward()
                 finally:
                     self._active = False
+                if self._early is not None and not self._early_sent:
+                    # the hook did not fire (no gradient flowed into the STN output): every rank reaches this point
+                    # with the same graph, so the bucket is sent here on all of them
+                    lo, n = self._early
+                    self._pending.append(dist.all_reduce(self.opt.flat_g[lo:lo + n], op=dist.ReduceOp.SUM,
+                                                         group=self.group, async_op=True))
             self._count.zero_()
             self._count[0] = float(0 if sit_out else n_local)
             lo, n = self._late
