@@ -93,6 +93,20 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
 
     // layer-3 weight fragments (hi+lo of one 32-channel block = 64 VGPRs)
     f32x4 wah[8], wal[8];
+    // NT == 1 (plain bf16): the wave's FOUR channel blocks stay resident in 128 VGPRs for the whole kernel.  With the
+    // matrix cores 16x faster than in fp32 the weight stream itself was the bottleneck: every wave re-fetched 8 KB per
+    // block and tile from L2 (2 KB per point and workgroup; with all 256 CUs on the same 256 KB of weights: half of each
+    // XCD's L2 bandwidth), and tools/phase_times_x3.py showed 2,150 cycles per block waiting for the fragments to land —
+    // 35 % of the kernel.  (NT == 3 would need 256 VGPRs for hi + lo of four blocks and keeps streaming.)
+    f32x4 wres[NT == 1 ? 4 : 1][8];
+    if (NT == 1) {
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci) {
+            const f32x4 *p = (const f32x4 *)w3x + (size_t)((wave + 8 * ci) * 8) * 2 * 64 + lane;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) wres[ci][ks] = p[(ks * 2) * 64];
+        }
+    }
 
     float px0 = 0.f, px1 = 0.f, px2 = 0.f;
     if (tid < XP) {
@@ -180,8 +194,7 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
         // layer 3 (128 -> 1024), bf16x3: wave owns channel blocks wave + 8*ci, all four point blocks
         // One channel block x all four point blocks per step: 4 independent accumulator chains (an accumulator is
         // re-used every 4th MFMA) and the A fragments of k-step ks+1 in flight while k-step ks issues.
-        auto block4 = [&](int cb) {
-            load_wx<8, NT>(wah, wal, w3x, cb, lane);
+        auto block4 = [&](int cb, const f32x4 (&wah)[8], const f32x4 (&wal)[8]) {
             f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
             const int ro = j * X2S + h * 8;
             f32x4 ah[4], al[4];
@@ -218,8 +231,16 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
             m = fmaxf(m, __shfl_xor(m, 32));
             if (h == 0) rm[cb * 32 + j] = fmaxf(rm[cb * 32 + j], m);
         };
+        if (NT == 1) {
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci) block4(wave + 8 * ci, wres[ci], wres[ci]);
+        } else {
 #pragma unroll 1
-        for (int ci = 0; ci < 4; ++ci) block4(wave + 8 * ci);
+            for (int ci = 0; ci < 4; ++ci) {
+                load_wx<8, NT>(wah, wal, w3x, wave + 8 * ci, lane);
+                block4(wave + 8 * ci, wah, wal);
+            }
+        }
         TM(7)
         // the barrier after the next tile's layer 1 orders the h2 rewrite after these reads
     }
