@@ -9,6 +9,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define PNGPD_WAVE 64
 
@@ -20,6 +21,61 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 }
 
 __device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// ---- the per-lane epilogue of a pair of 32x32 accumulator blocks (training pass C) -----------------------------
+// On gfx950 the fp32 matrix instruction does NOT overlap VALU work on its SIMD, from either resident wave
+// (tools/probes/mfma_valu_overlap.hip: a v_mfma_f32_32x32x2_f32 costs 64 cycles, every plain VALU instruction ~4.7
+// more, every v_cmp ~8, and the times ADD) — so an epilogue is paid in matrix-pipe time, instruction by instruction.
+// lane_max_moments() gets the exact first maximum of the lane's 32 values (rows mfma_row(r, lane) of a0 and
+// 32 + mfma_row(r, lane) of a1, ascending) and their sum / sum of squares in ~120 VALU instructions and no compares,
+// where the compare-and-select chain took ~200 including 64 v_cmp:
+//   m    = v_max3 tree                                                (17)
+//   su,qu= packed adds / packed FMAs on register pairs                (34)
+//   row  = min over r of ((bits(m - v_r) & ~63) | code_r): m - v_r is +0 exactly for the maxima, so the smallest key
+//          is the smallest row code among them (packed subtract 16, v_and_or 32, v_min3_u32 tree 16).
+// Non-finite maxima (m - v = NaN) find no key below 64: the row is then arbitrary (callers clamp it); such a step has
+// already diverged.  Returns the row WITHOUT the lane half's +4 (mfma_row's 4 * (lane >> 5)).
+__device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+__device__ __forceinline__ unsigned min3u(unsigned a, unsigned b, unsigned c) { return min(min(a, b), c); }
+
+__device__ __forceinline__ void lane_max_moments(const f32x16 &a0, const f32x16 &a1, float &m, int &row,
+                                                 float &su, float &qu) {
+    float v[32];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { v[r] = a0[r]; v[16 + r] = a1[r]; }
+    float t[11];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) t[i] = max3f(v[3 * i], v[3 * i + 1], v[3 * i + 2]);
+    t[10] = __builtin_fmaxf(v[30], v[31]);
+    m = max3f(max3f(t[0], t[1], t[2]), max3f(t[3], t[4], t[5]),
+              max3f(max3f(t[6], t[7], t[8]), t[9], t[10]));
+    f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
+    const f32x2 m2 = {m, m};
+    unsigned k[32];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const f32x2 p = {v[2 * i], v[2 * i + 1]};
+        s2 += p;
+        q2 = __builtin_elementwise_fma(p, p, q2);
+        const f32x2 d = m2 - p;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int r = 2 * i + e;
+            const unsigned code = (unsigned)(((r & 15) & 3) + 8 * ((r & 15) >> 2) + 32 * (r >> 4));
+            k[r] = (__float_as_uint(d[e]) & 0xffffffc0u) | code;
+        }
+    }
+    unsigned u[11];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) u[i] = min3u(k[3 * i], k[3 * i + 1], k[3 * i + 2]);
+    u[10] = min(k[30], k[31]);
+    const unsigned kk = min3u(min3u(u[0], u[1], u[2]), min3u(u[3], u[4], u[5]),
+                              min3u(min3u(u[6], u[7], u[8]), u[9], u[10]));
+    row = (int)(kk & 63u);
+    su = s2[0] + s2[1];
+    qu = q2[0] + q2[1];
+}
+
 
 // Dynamic LDS above 48 KB needs a per-kernel opt-in.  Idempotent and checked on every call: no "already set"
 // flag to race on, and a failure is reported instead of surfacing later as a launch error.

@@ -62,21 +62,34 @@ __device__ __forceinline__ L1C load_l1c(const float *__restrict__ w1, const floa
     return k;
 }
 
-__device__ __forceinline__ void layer1_tile(const float *xs, const L1C &k, float *h1, const Lane &L) {
-    const int p0 = L.wave * 16;
-    float *dst = h1 + p0 * H1S + L.lane;
+// (Packed FMAs on point pairs: each element still goes through the same three-FMA chain, so the values are unchanged; the
+// affine / plain variants are two loops — a per-element select on k.affine costs a VALU instruction per activation.)
+template <bool AFF>
+__device__ __forceinline__ void layer1_rows(const float *xs, const L1C &k, float *dst, int p0) {
+    const f32x2 w0 = {k.w0, k.w0}, w1 = {k.w1, k.w1}, w2 = {k.w2, k.w2}, bb = {k.b, k.b};
+    const f32x2 sc = {k.sc, k.sc}, sh = {k.sh, k.sh};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {   // 12 broadcast ds_read_b128: the wave's 16 points
         const f32x4 x0 = *(const f32x4 *)(xs + p0 + 4 * q);
         const f32x4 x1 = *(const f32x4 *)(xs + TP + p0 + 4 * q);
         const f32x4 x2 = *(const f32x4 *)(xs + 2 * TP + p0 + 4 * q);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float z = fmaf(k.w2, x2[e], fmaf(k.w1, x1[e], fmaf(k.w0, x0[e], k.b)));
-            if (k.affine) z = fmaf(z, k.sc, k.sh);
-            dst[(4 * q + e) * H1S] = fmaxf(z, 0.f);
+        for (int e = 0; e < 4; e += 2) {
+            f32x2 z = __builtin_elementwise_fma(w2, f32x2{x2[e], x2[e + 1]},
+                      __builtin_elementwise_fma(w1, f32x2{x1[e], x1[e + 1]},
+                      __builtin_elementwise_fma(w0, f32x2{x0[e], x0[e + 1]}, bb)));
+            if (AFF) z = __builtin_elementwise_fma(z, sc, sh);
+            dst[(4 * q + e) * H1S] = fmaxf(z[0], 0.f);
+            dst[(4 * q + e + 1) * H1S] = fmaxf(z[1], 0.f);
         }
     }
+}
+
+__device__ __forceinline__ void layer1_tile(const float *xs, const L1C &k, float *h1, const Lane &L) {
+    const int p0 = L.wave * 16;
+    float *dst = h1 + p0 * H1S + L.lane;
+    if (k.affine) layer1_rows<true>(xs, k, dst, p0);
+    else layer1_rows<false>(xs, k, dst, p0);
 }
 
 // Layer 2 (64 -> 128) raw product for channel block cb (32 channels), both 32-point blocks:
@@ -199,7 +212,11 @@ __device__ __forceinline__ void swz_compute(const float *tile, const f32x4 (&wf)
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
         f32x4 n0 = a0, n1 = a1;
+#ifdef ABL_NOA
+        if (false) {
+#else
         if (kb + 1 < NKB) {
+#endif
             const int c4 = (((kb + 1) * 2 + L.h) ^ sx) << 2;
             n0 = *(const f32x4 *)(r0 + c4);
             n1 = *(const f32x4 *)(r1 + c4);
@@ -323,6 +340,22 @@ __device__ __forceinline__ void k128_bf(const float *tile, const u16 *__restrict
 __device__ __forceinline__ void wg_priority() {
 #if PNGPD_PRIO
     if ((blockIdx.x >> PNGPD_PRIO_SHIFT) & 1) __builtin_amdgcn_s_setprio(PNGPD_PRIO);
+#endif
+}
+
+// Phase priority: a wave raises its issue priority for a VALU phase (epilogue, tile build) so that those instructions
+// are not queued behind the co-resident wave's stream of matrix instructions (which wait for the pipe anyway).
+#ifndef PNGPD_VPRIO
+#define PNGPD_VPRIO 0
+#endif
+__device__ __forceinline__ void valu_phase_begin() {
+#if PNGPD_VPRIO
+    __builtin_amdgcn_s_setprio(PNGPD_VPRIO);
+#endif
+}
+__device__ __forceinline__ void valu_phase_end() {
+#if PNGPD_VPRIO
+    __builtin_amdgcn_s_setprio(0);
 #endif
 }
 

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void trunk_bn2_stats_kernel(
 #pragma unroll
         for (int i = 0; i < 9; ++i) tm[i] = trans[(size_t)b * 9 + i];
     }
-    float sum = 0.f, sq = 0.f;
+    double sum = 0.0, sq = 0.0;
     f32x4 w2f[8];   // this wave's layer-2 weight fragments stay in registers for the whole kernel
     if (NT == 0) load_w2frag(w2f, P.w2p, L.wave, L);
     const L1C l1c = load_l1c(P.w1, P.b1, P.s1c, P.t1c, L);
@@ -114,21 +114,35 @@ __global__ __launch_bounds__(256, 2) void trunk_bn2_stats_kernel(
             }
             }
         }
+        // the tile's 32 values per lane as packed fp32 partials; the running sums over the workgroup's tiles are fp64
+        // (a sequential fp32 accumulation over 512 values per lane was the largest round-off term of the batch
+        // statistics; the fp64 adds are two instructions per tile)
+        f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
+        if (nbase + TP <= N) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = mfma_row(r, L.lane);
-            const float v0 = (nbase + row < N) ? a0[r] : 0.f;
-            const float v1 = (nbase + 32 + row < N) ? a1[r] : 0.f;
-            sum += v0 + v1;
-            sq = fmaf(v0, v0, fmaf(v1, v1, sq));
+            for (int r = 0; r < 16; ++r) {
+                const f32x2 v = {a0[r], a1[r]};
+                s2 += v;
+                q2 = __builtin_elementwise_fma(v, v, q2);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mfma_row(r, L.lane);
+                const f32x2 v = {(nbase + row < N) ? a0[r] : 0.f, (nbase + 32 + row < N) ? a1[r] : 0.f};
+                s2 += v;
+                q2 = __builtin_elementwise_fma(v, v, q2);
+            }
         }
+        sum += (double)(s2[0] + s2[1]);
+        sq += (double)(q2[0] + q2[1]);
         __syncthreads();   // h1/xs are rewritten by the next tile
     }
     sum += __shfl_xor(sum, 32);
     sq += __shfl_xor(sq, 32);
     if (L.h == 0) {
         float *o = part + ((size_t)blockIdx.x * 128 + L.wave * 32 + L.j) * 2;
-        o[0] = sum; o[1] = sq;
+        o[0] = (float)sum; o[1] = (float)sq;
     }
 }
 
@@ -178,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
     }
     const int cb2 = L.wave, c2 = cb2 * 32 + L.j;
     const float sc2 = P.s2c[c2], sh2 = P.t2c[c2];
-    float hsum = 0.f;   // sum over this workgroup's valid points of h2[.][c2] (rows of this half-wave)
+    double hsum = 0.0;   // sum over this workgroup's valid points of h2[.][c2] (rows of this half-wave); fp64 across tiles
     f32x4 zq[8];
     if (LOADZ) {
         const f32x4 *zt = z2t + ((size_t)(b * T + t0) * 8) * 256 + L.tid;
@@ -189,7 +203,9 @@ __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
     for (int tile = t0; tile < t1; ++tile) {
         TM(0)
         if (LOADZ) {
+#ifndef ABL_NOBAR
             if (tile > t0) __syncthreads();   // every wave is done reading the previous tile's h2
+#endif
             TM(1)
         } else if (L.tid < TP) {
             float x0 = px0, x1 = px1, x2 = px2;
@@ -238,32 +254,55 @@ __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
                 load_w2frag(w2f, P.w2p, cb2, L);
                 swz_compute<I1S, 8>(h1, w2f, L, a0, a1);
             }
+            // column sums of h2 (the mean of h2 enters cvec of pass D and the closed-form dW3), finished HERE: left to
+            // itself the compiler sinks the masked accumulation below the tile's eight layer-3 blocks and keeps all 32
+            // activations in registers until then (32 VGPRs of a kernel at the 256 ceiling, ~200 VALU per tile).
+            f32x2 hs2 = {0.f, 0.f};
+            f32x2 hv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mfma_row(r, L.lane);
-                const float v0 = fmaxf(fmaf(a0[r], sc2, sh2), 0.f), v1 = fmaxf(fmaf(a1[r], sc2, sh2), 0.f);
-                h2[swz(row, c2, I2S)] = v0;
-                h2[swz(32 + row, c2, I2S)] = v1;
-                // column sums of h2 (the mean of h2 enters cvec of pass D and the closed-form dW3)
-                hsum += (full || nbase + row < N) ? v0 : 0.f;
-                hsum += (full || nbase + 32 + row < N) ? v1 : 0.f;
+                hv[r] = f32x2{fmaxf(fmaf(a0[r], sc2, sh2), 0.f), fmaxf(fmaf(a1[r], sc2, sh2), 0.f)};
+                h2[swz(row, c2, I2S)] = hv[r][0];
+                h2[swz(32 + row, c2, I2S)] = hv[r][1];
             }
-        }
-        TM(2)
-        __syncthreads();
-        TM(3)
-        auto reduce_block = [&](int cb, const f32x16 &a0, const f32x16 &a1) {
-            // max / argmax over this lane's 32 rows (ascending row order, strict >: first wins)
-            float m = a0[0]; int am = mfma_row(0, L.lane);
-#pragma unroll
-            for (int r = 1; r < 16; ++r) { if (a0[r] > m) { m = a0[r]; am = mfma_row(r, L.lane); } }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { if (a1[r] > m) { m = a1[r]; am = 32 + mfma_row(r, L.lane); } }
-            float su = 0.f, qu = 0.f;
             if (full) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { su += a0[r] + a1[r]; qu = fmaf(a0[r], a0[r], fmaf(a1[r], a1[r], qu)); }
+                for (int r = 0; r < 16; ++r) hs2 += hv[r];
             } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = mfma_row(r, L.lane);
+                    hs2[0] += (nbase + row < N) ? hv[r][0] : 0.f;
+                    hs2[1] += (nbase + 32 + row < N) ? hv[r][1] : 0.f;
+                }
+            }
+            hsum += (double)(hs2[0] + hs2[1]);
+            asm volatile("" : "+v"(hsum));
+        }
+        TM(2)
+#ifndef ABL_NOBAR
+        __syncthreads();
+#endif
+        TM(3)
+        auto reduce_block = [&](int cb, const f32x16 &a0, const f32x16 &a1) {
+            // first maximum over this lane's 32 rows (ascending row order) and the two moments
+            valu_phase_begin();
+            float m, su, qu; int am;
+#ifdef ABL_NOEPI
+            if (a0[0] + a1[15] == 123.f) rm[cb] = 1.f;
+            return;
+#endif
+            if (full) {
+                lane_max_moments(a0, a1, m, am, su, qu);
+                am += 4 * L.h;
+            } else {
+                m = a0[0]; am = mfma_row(0, L.lane);
+#pragma unroll
+                for (int r = 1; r < 16; ++r) { if (a0[r] > m) { m = a0[r]; am = mfma_row(r, L.lane); } }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { if (a1[r] > m) { m = a1[r]; am = 32 + mfma_row(r, L.lane); } }
+                su = 0.f; qu = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = mfma_row(r, L.lane);
@@ -272,6 +311,10 @@ __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
                     su += v0 + v1; qu = fmaf(v0, v0, fmaf(v1, v1, qu));
                 }
             }
+#ifdef ABL_NOMERGE
+            if (m + su + qu + (float)am == 123.f) rm[cb] = 1.f;
+            return;
+#endif
             const float om = __shfl_xor(m, 32); const int oa = __shfl_xor(am, 32);
             if (om > m || (om == m && oa < am)) { m = om; am = oa; }
             su += __shfl_xor(su, 32); qu += __shfl_xor(qu, 32);
@@ -280,18 +323,25 @@ __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
                 if (m > rm[c]) { rm[c] = m; int n = nbase + am; ri[c] = n < N ? n : N - 1; }
                 ss[c] += su; sq[c] += qu;
             }
+            valu_phase_end();
         };
 #pragma unroll 1
         for (int cp = 0; cp < 4; ++cp) {
             const int cbA = L.wave + 8 * cp, cbB = cbA + 4, cbN = L.wave + ((8 * cp + 8) & 31);
             f32x16 a0, a1;
+#ifndef ABL_NOW
             load_wfrag(wb, w3sp, cbB, L);
+#endif
             swz_compute<I2S, 16>(h2, wa, L, a0, a1);
             TM(4)
             reduce_block(cbA, a0, a1);
             TM(5)
+#ifndef ABL_NOW
             load_wfrag(wa, w3sp, cbN, L);
             swz_compute<I2S, 16>(h2, wb, L, a0, a1);
+#else
+            swz_compute<I2S, 16>(h2, wa, L, a0, a1);
+#endif
             TM(4)
             reduce_block(cbB, a0, a1);
             TM(5)
@@ -302,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
     TM_END
     hsum += __shfl_xor(hsum, 32);
     if (L.h == 0) {
-        psh[(size_t)blockIdx.x * 128 + c2] = hsum;
+        psh[(size_t)blockIdx.x * 128 + c2] = (float)hsum;
 #pragma unroll
         for (int ci = 0; ci < 8; ++ci) {
             const int c = (L.wave + 4 * ci) * 32 + L.j;
@@ -459,7 +509,7 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
         cfl[i] = D.coef[(size_t)b * 1024 + i];
         idxl[i] = D.idx[(size_t)b * 1024 + i];
     }
-    float a1s = 0.f, a2s = 0.f;
+    double a1s = 0.0, a2s = 0.0;   // running sums over the workgroup's tiles (tile partials are fp32)
     const int cb = L.wave;
     const int c2 = cb * 32 + L.j;
     const float sc2 = P.s2c[c2], sh2 = P.t2c[c2], is2 = D.is2[c2], nm2 = D.nm2[c2], cv = D.cvec[c2];
@@ -642,8 +692,10 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
                     for (int u = 0; u < 4; ++u) d = mfma32(av[u], bv[u], d);
                 }
             };
+#ifndef ABL_D_NOSPARSE
             sparse(hits, nlo, d0);
             sparse(hits + BWD_D_HITS, nhi, d1);
+#endif
         }
         TM(5)
         // Gram of the tile: D[i][j] += A[i][k = point] B[k = point][j], both operands read column-wise from h2.
@@ -664,7 +716,9 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
                     if (third == 2) gm2 = mfma32(rp[o2], av, gm2);
                 }
             };
+#ifndef ABL_D_NOGRAM
             if (cb < 2) { gram(0, 1); gram(16, 0); } else { gram(0, 0); gram(16, 2); }
+#endif
         }
         TM(6)
         }   // NT == 0
@@ -675,26 +729,47 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
         {
             f32x4 *gt = g2t + ((size_t)(b * T + tile) * 8) * 256 + L.tid;
             f32x16 gb0, gb1;   // NT == 1: the tile leaves as bf16 (the sums below take the unrounded values)
+            // per element: g = cv - d; mask = relu'(bn2(z)) (and validity in a ragged tile); a1 += g; a2 += g zhat2 —
+            // on register pairs (packed subtract / FMAs), tile partials in fp32, running sums over the tiles in fp64
+            const bool fullt = nbase + TP <= N;
+            const f32x2 cv2 = {cv, cv}, sc22 = {sc2, sc2}, sh22 = {sh2, sh2}, is22 = {is2, is2}, nm22 = {nm2, nm2};
+            f32x2 t1 = {0.f, 0.f}, t2 = {0.f, 0.f};
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
                 f32x4 o0, o1;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < 4; e += 2) {
                     const int r = rq * 4 + e;
                     const int row = mfma_row(r, L.lane);
-                    float g0 = cv - d0[r], g1 = cv - d1[r];
-                    g0 = (nbase + row < N && fmaf(z0[r], sc2, sh2) > 0.f) ? g0 : 0.f;
-                    g1 = (nbase + 32 + row < N && fmaf(z1[r], sc2, sh2) > 0.f) ? g1 : 0.f;
-                    a1s += g0 + g1;
-                    a2s = fmaf(g0, fmaf(z0[r], is2, nm2), fmaf(g1, fmaf(z1[r], is2, nm2), a2s));
-                    o0[e] = g0; o1[e] = g1;
-                    if (NT == 1) { gb0[r] = g0; gb1[r] = g1; }
+                    const f32x2 zz0 = {z0[r], z0[r + 1]}, zz1 = {z1[r], z1[r + 1]};
+                    f32x2 g0 = cv2 - f32x2{d0[r], d0[r + 1]}, g1 = cv2 - f32x2{d1[r], d1[r + 1]};
+                    const f32x2 ac0 = __builtin_elementwise_fma(zz0, sc22, sh22), ac1 = __builtin_elementwise_fma(zz1, sc22, sh22);
+                    if (fullt) {
+                        g0[0] = ac0[0] > 0.f ? g0[0] : 0.f; g0[1] = ac0[1] > 0.f ? g0[1] : 0.f;
+                        g1[0] = ac1[0] > 0.f ? g1[0] : 0.f; g1[1] = ac1[1] > 0.f ? g1[1] : 0.f;
+                    } else {
+                        g0[0] = (nbase + row < N && ac0[0] > 0.f) ? g0[0] : 0.f;
+                        g0[1] = (nbase + row + 1 < N && ac0[1] > 0.f) ? g0[1] : 0.f;
+                        g1[0] = (nbase + 32 + row < N && ac1[0] > 0.f) ? g1[0] : 0.f;
+                        g1[1] = (nbase + 33 + row < N && ac1[1] > 0.f) ? g1[1] : 0.f;
+                    }
+                    t1 += g0 + g1;
+                    t2 = __builtin_elementwise_fma(g0, __builtin_elementwise_fma(zz0, is22, nm22),
+                         __builtin_elementwise_fma(g1, __builtin_elementwise_fma(zz1, is22, nm22), t2));
+                    o0[e] = g0[0]; o0[e + 1] = g0[1]; o1[e] = g1[0]; o1[e + 1] = g1[1];
+                    if (NT == 1) { gb0[r] = g0[0]; gb0[r + 1] = g0[1]; gb1[r] = g1[0]; gb1[r + 1] = g1[1]; }
                 }
+#ifndef ABL_D_NOSTORE
                 if (NT != 1) {
                     gt[(size_t)rq * 256] = o0;
                     gt[(size_t)(4 + rq) * 256] = o1;
                 }
+#else
+                if (o0[0] + o1[3] == 123.f) gt[0] = o0;
+#endif
             }
+            a1s += (double)(t1[0] + t1[1]);
+            a2s += (double)(t2[0] + t2[1]);
             if constexpr (NT == 1) bf_tile_store((uint4 *)g2t + ((size_t)(b * T + tile) * 4) * 256 + L.tid, gb0, gb1);
         }
         TM(7)
@@ -706,7 +781,7 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
     a2s += __shfl_xor(a2s, 32);
     if (L.h == 0) {
         float *o = pa + ((size_t)blockIdx.x * 128 + c2) * 2;
-        o[0] = a1s; o[1] = a2s;
+        o[0] = (float)a1s; o[1] = (float)a2s;
     }
     {
         float *o = ps2 + ((size_t)blockIdx.x * 12 + cb * 3) * 1024 + L.lane;
@@ -762,21 +837,21 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
     const int pb1 = L.wave >> 1, cb1 = L.wave & 1, c1 = cb1 * 32 + L.j;
     const float w10 = P.w1[c1 * 3], w11 = P.w1[c1 * 3 + 1], w12 = P.w1[c1 * 3 + 2], bb1 = P.b1[c1];
     const float is1 = E.is1[c1], nm1 = E.nm1[c1];
-    float c1s = 0.f, c2s = 0.f, r0 = 0.f, r1 = 0.f, r2 = 0.f;
+    double c1d = 0.0, c2d = 0.0, r0d = 0.0, r1d = 0.0, r2d = 0.0;   // running sums over the workgroup's tiles
     f32x16 pw0, pw1;   // dW2 rows o = cb*32 + i, columns {0,1}*32 + j
 #pragma unroll
     for (int r = 0; r < 16; ++r) { pw0[r] = 0.f; pw1[r] = 0.f; }
     f32x4 w2f[8];   // this wave's layer-2 weight fragments stay in registers for the whole kernel
     if (!LOADZ) load_w2frag(w2f, P.w2p, cb, L);
     const L1C l1c = load_l1c(P.w1, P.b1, P.s1c, P.t1c, L);
-    TM_DECL
-    for (int tile = t0; tile < t1; ++tile) {
-        const int nbase = tile * TP;
-        float *xs = xbuf + ((tile - t0) & 1) * 6 * TP, *xo = xs + 3 * TP;
-        // (Requesting the NEXT tile's hand-off values right after the dz tile is written — they are dead from there on —
-        // was measured: 0.412 -> 0.528 ms; 64 more live registers across the MFMA phases cost more than the latency.)
-        f32x4 gq[8], zq[8];   // this lane's 32 g2 (and z2) values of the tile (g2 rows past N hold zeros)
-        uint4 gb[4], zb[4];   // NT == 1: the same values as bf16 tiles
+    f32x4 gq[8], zq[8];
+    uint4 gb[4], zb[4];   // NT == 1: the same values as bf16 tiles
+    // The hand-off values of a tile are dead once its dz tile is written, so the next tile's can be requested into the
+    // same registers a tile ahead.  WHERE matters: vmcnt retires in order, so any later load that is waited on (the
+    // W2^T fragment ring of the first contraction) would wait for these HBM reads as well — requested right after the dz
+    // tile they cost 0.412 -> 0.528 ms.  They are issued after the last fragment of the first contraction instead; the
+    // g1 epilogue, the dW2 contraction (LDS operands only) and the next tile's staging cover the round trip.
+    auto fetch_tile = [&](int tile) {
         if (NT == 1) {
             const uint4 *gt = (const uint4 *)g2t + ((size_t)(b * T + tile) * 4) * 256 + L.tid;
             const uint4 *zt = (const uint4 *)z2t + ((size_t)(b * T + tile) * 4) * 256 + L.tid;
@@ -792,7 +867,37 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
                 for (int i = 0; i < 8; ++i) zq[i] = zt[(size_t)i * 256];
             }
         }
-        stage_points(xb, N, tile, has_t, tm, xs, xo, L.tid);
+    };
+    fetch_tile(t0);
+    // the tile's points travel the same way: requested at the top of the previous tile, written to the other parity of
+    // xbuf just before that tile's hand-off prefetch (no vmem wait is left behind the HBM reads)
+    float px0 = 0.f, px1 = 0.f, px2 = 0.f;
+    auto load_points = [&](int tile) {
+        if (L.tid < TP) {
+            int n = tile * TP + L.tid; n = n < N ? n : N - 1;
+            px0 = xb[n]; px1 = xb[N + n]; px2 = xb[2 * N + n];
+        }
+    };
+    auto store_points = [&](int tile) {
+        if (L.tid < TP) {
+            float *xs_ = xbuf + ((tile - t0) & 1) * 6 * TP, *xo_ = xs_ + 3 * TP;
+            xo_[L.tid] = px0; xo_[TP + L.tid] = px1; xo_[2 * TP + L.tid] = px2;
+            float y0 = px0, y1 = px1, y2 = px2;
+            if (has_t) {
+                y0 = fmaf(px2, tm[6], fmaf(px1, tm[3], px0 * tm[0]));
+                y1 = fmaf(px2, tm[7], fmaf(px1, tm[4], px0 * tm[1]));
+                y2 = fmaf(px2, tm[8], fmaf(px1, tm[5], px0 * tm[2]));
+            }
+            xs_[L.tid] = y0; xs_[TP + L.tid] = y1; xs_[2 * TP + L.tid] = y2;
+        }
+    };
+    load_points(t0);
+    store_points(t0);
+    TM_DECL
+    for (int tile = t0; tile < t1; ++tile) {
+        const int nbase = tile * TP;
+        float *xs = xbuf + ((tile - t0) & 1) * 6 * TP, *xo = xs + 3 * TP;
+        if (tile + 1 < t1) load_points(tile + 1);
         TM(0)
         __syncthreads();
         TM(1)
@@ -823,14 +928,31 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
                     layer2_compute(h1, w2f, L, a0, a1);
                 }
             }
+            // dz2 = dsc (g2 - a1m - zhat2 a2m), zhat2 = z2 is2 + nm2 — per element exactly the operations pass D used
+            // for its sums of g2 zhat2 (folding the constants into one affine map of (g2, z2) is cheaper but gives a
+            // zhat2 that differs from pass D's in the last bit of its CONSTANTS: a systematic error that adds up
+            // coherently over the 10^6 points of dW2 = sum dz2 h1^T — 20x its round-off, measured).  On point pairs.
+            if (nbase + TP <= N) {
+                const f32x2 is22 = {is2, is2}, nm22 = {nm2, nm2}, a1m2 = {a1m, a1m}, na2m2 = {-a2m, -a2m}, dsc2 = {dsc, dsc};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = mfma_row(r, L.lane);
-                const bool v0 = nbase + row < N, v1 = nbase + 32 + row < N;
-                const float g0 = gv0[r], g1 = gv1[r];
-                const float z0 = fmaf(a0[r], is2, nm2), z1 = fmaf(a1[r], is2, nm2);
-                dz[row * H2S + c2] = v0 ? dsc * (g0 - a1m - z0 * a2m) : 0.f;
-                dz[(32 + row) * H2S + c2] = v1 ? dsc * (g1 - a1m - z1 * a2m) : 0.f;
+                for (int r = 0; r < 16; r += 2) {
+                    const int row = mfma_row(r, L.lane);
+                    const f32x2 zh0 = __builtin_elementwise_fma(f32x2{a0[r], a0[r + 1]}, is22, nm22);
+                    const f32x2 zh1 = __builtin_elementwise_fma(f32x2{a1[r], a1[r + 1]}, is22, nm22);
+                    const f32x2 d0 = dsc2 * __builtin_elementwise_fma(zh0, na2m2, f32x2{gv0[r], gv0[r + 1]} - a1m2);
+                    const f32x2 d1 = dsc2 * __builtin_elementwise_fma(zh1, na2m2, f32x2{gv1[r], gv1[r + 1]} - a1m2);
+                    dz[row * H2S + c2] = d0[0]; dz[(row + 1) * H2S + c2] = d0[1];
+                    dz[(32 + row) * H2S + c2] = d1[0]; dz[(33 + row) * H2S + c2] = d1[1];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = mfma_row(r, L.lane);
+                    const bool v0 = nbase + row < N, v1 = nbase + 32 + row < N;
+                    const float z0 = fmaf(a0[r], is2, nm2), z1 = fmaf(a1[r], is2, nm2);
+                    dz[row * H2S + c2] = v0 ? dsc * fmaf(z0, -a2m, gv0[r] - a1m) : 0.f;
+                    dz[(32 + row) * H2S + c2] = v1 ? dsc * fmaf(z1, -a2m, gv1[r] - a1m) : 0.f;
+                }
             }
         }
         TM(3)
@@ -843,19 +965,37 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             if constexpr (NT == 0) k128_stream<1>(dz, E.w2tp, cb1, pb1, L, acc, unused);
             else k128_bf<NT>(dz, E.w2tx, cb1, pb1, L, acc);
+            if (tile + 1 < t1) { store_points(tile + 1); fetch_tile(tile + 1); }
             TM(5)
+            // g1 = dh1 masked by ReLU(bn1) (rows past N: dz == 0 -> 0); c1 = sum g1, c2 = sum g1 zhat1, R = sum g1 x^T,
+            // all on point PAIRS (packed adds / FMAs; zhat1 through the same FMA chain as layer 1)
+            const f32x2 w102 = {w10, w10}, w112 = {w11, w11}, w122 = {w12, w12}, bb12 = {bb1, bb1};
+            const f32x2 is12 = {is1, is1}, nm12 = {nm1, nm1};
+            f32x2 cs2 = {0.f, 0.f}, cc2 = {0.f, 0.f}, rr0 = {0.f, 0.f}, rr1 = {0.f, 0.f}, rr2 = {0.f, 0.f};   // even / odd points
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int pt = pb1 * 32 + mfma_row(r, L.lane);
-                const float g1v = (h1[pt * H1S + c1] > 0.f) ? acc[r] : 0.f;   // rows past N: dz == 0 -> 0
-                const float xp0 = xs[pt], xp1 = xs[TP + pt], xp2 = xs[2 * TP + pt];
-                const float z1 = fmaf(w12, xp2, fmaf(w11, xp1, fmaf(w10, xp0, bb1)));
-                c1s += g1v;
-                c2s = fmaf(g1v, fmaf(z1, is1, nm1), c2s);
-                r0 = fmaf(g1v, xo[pt], r0);
-                r1 = fmaf(g1v, xo[TP + pt], r1);
-                r2 = fmaf(g1v, xo[2 * TP + pt], r2);
+            for (int rq = 0; rq < 4; ++rq) {
+                const int pt = pb1 * 32 + mfma_row(4 * rq, L.lane);   // 4 consecutive points
+                const f32x4 q0 = *(const f32x4 *)(xo + pt), q1 = *(const f32x4 *)(xo + TP + pt),
+                            q2 = *(const f32x4 *)(xo + 2 * TP + pt);
+                const f32x4 y0 = *(const f32x4 *)(xs + pt), y1 = *(const f32x4 *)(xs + TP + pt),
+                            y2 = *(const f32x4 *)(xs + 2 * TP + pt);
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    const int r = 4 * rq + e;
+                    const f32x2 g = {(h1[(pt + e) * H1S + c1] > 0.f) ? acc[r] : 0.f,
+                                     (h1[(pt + e + 1) * H1S + c1] > 0.f) ? acc[r + 1] : 0.f};
+                    const f32x2 z1 = __builtin_elementwise_fma(w122, f32x2{y2[e], y2[e + 1]},
+                                     __builtin_elementwise_fma(w112, f32x2{y1[e], y1[e + 1]},
+                                     __builtin_elementwise_fma(w102, f32x2{y0[e], y0[e + 1]}, bb12)));
+                    cs2 += g;
+                    cc2 = __builtin_elementwise_fma(g, __builtin_elementwise_fma(z1, is12, nm12), cc2);
+                    rr0 = __builtin_elementwise_fma(g, f32x2{q0[e], q0[e + 1]}, rr0);
+                    rr1 = __builtin_elementwise_fma(g, f32x2{q1[e], q1[e + 1]}, rr1);
+                    rr2 = __builtin_elementwise_fma(g, f32x2{q2[e], q2[e + 1]}, rr2);
+                }
             }
+            c1d += (double)(cs2[0] + cs2[1]); c2d += (double)(cc2[0] + cc2[1]);
+            r0d += (double)(rr0[0] + rr0[1]); r1d += (double)(rr1[0] + rr1[1]); r2d += (double)(rr2[0] + rr2[1]);
         }
         TM(6)
         // dW2 += dz^T h1 : contraction over the tile's 64 points (rows past N carry dz == 0)
@@ -915,8 +1055,9 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
             oW[o * 64 + 32 + L.j] = pw1[r];
         }
     }
-    c1s += __shfl_xor(c1s, 32); c2s += __shfl_xor(c2s, 32);
-    r0 += __shfl_xor(r0, 32); r1 += __shfl_xor(r1, 32); r2 += __shfl_xor(r2, 32);
+    c1d += __shfl_xor(c1d, 32); c2d += __shfl_xor(c2d, 32);
+    r0d += __shfl_xor(r0d, 32); r1d += __shfl_xor(r1d, 32); r2d += __shfl_xor(r2d, 32);
+    const float c1s = (float)c1d, c2s = (float)c2d, r0 = (float)r0d, r1 = (float)r1d, r2 = (float)r2d;
     // two waves (pb1 = 0,1) own the same channel block: combine through LDS
     __syncthreads();   // every wave is done with dz
     float *red = dz;

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(512, 2) void trunk_fwd_train_x3_kernel(
     u16 *h2l = h2h + XP * X2S;
     float *xs = (float *)(h2l + XP * X2S);
     float *rm = LOADZ ? xs : xs + 3 * XP;
-    float hsum = 0.f;   // sum of h2[.][(wave&3)*32 + j] over this wave's valid rows
+    double hsum = 0.0;   // sum of h2[.][(wave&3)*32 + j] over this wave's valid rows (fp64 across tiles)
     int *ri = (int *)(rm + 1024);
     float *ss = (float *)(ri + 1024);
     float *sq = ss + 1024;
@@ -400,6 +400,7 @@ __global__ __launch_bounds__(512, 2) void trunk_fwd_train_x3_kernel(
             }
             }   // !LOADZ
             const float sc = s2c[cb * 32 + j], sh = t2c[cb * 32 + j];
+            f32x2 hs2 = {0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mfma_row(r, lane);
@@ -411,9 +412,17 @@ __global__ __launch_bounds__(512, 2) void trunk_fwd_train_x3_kernel(
                 split2(v1, hi, lo);
                 h2h[((pb0 + 1) * 32 + row) * X2S + cb * 32 + j] = hi;
                 if (NT == 3) h2l[((pb0 + 1) * 32 + row) * X2S + cb * 32 + j] = lo;
-                hsum += (nbase + pb0 * 32 + row < N) ? v0 : 0.f;
-                hsum += (nbase + (pb0 + 1) * 32 + row < N) ? v1 : 0.f;
+                if (nbase + XP <= N) {
+                    hs2 += f32x2{v0, v1};
+                } else {
+                    hs2[0] += (nbase + pb0 * 32 + row < N) ? v0 : 0.f;
+                    hs2[1] += (nbase + (pb0 + 1) * 32 + row < N) ? v1 : 0.f;
+                }
             }
+            // finished here: left alone, the compiler sinks these sums below the tile's layer-3 blocks and keeps the 32
+            // activations in registers until then
+            hsum += (double)(hs2[0] + hs2[1]);
+            asm volatile("" : "+v"(hsum));
         }
         __syncthreads();
         const bool full = nbase + XP <= N;
@@ -457,16 +466,22 @@ __global__ __launch_bounds__(512, 2) void trunk_fwd_train_x3_kernel(
                     for (int q = 0; q < 4; ++q) { ah[q] = nh[q]; al[q] = nl[q]; }
                 }
             }
-            auto epi = [&](const f32x16 &ca, const f32x16 &cc, int qp) {
-                // ascending local-row order with strict >: the first maximum wins
+            if (full) {
+                // lane_max_moments (pngpd_tile.h): exact first maximum + both moments of 32 values without compares;
+                // the two halves of the 128-point tile are merged with "earlier rows win ties"
+                float m1, s1, q1; int r1;
+                lane_max_moments(c0, c1, m, am, su, qu);
+                lane_max_moments(c2, c3, m1, r1, s1, q1);
+                if (m1 > m) { m = m1; am = 64 + r1; }
+                am += 4 * h;
+                su += s1; qu += q1;
+            } else {
+                auto epi = [&](const f32x16 &ca, const f32x16 &cc, int qp) {
+                    // ascending local-row order with strict >: the first maximum wins
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { if (ca[r] > m) { m = ca[r]; am = (2 * qp) * 32 + mfma_row(r, lane); } }
+                    for (int r = 0; r < 16; ++r) { if (ca[r] > m) { m = ca[r]; am = (2 * qp) * 32 + mfma_row(r, lane); } }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { if (cc[r] > m) { m = cc[r]; am = (2 * qp + 1) * 32 + mfma_row(r, lane); } }
-                if (full) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { su += ca[r] + cc[r]; qu = fmaf(ca[r], ca[r], fmaf(cc[r], cc[r], qu)); }
-                } else {
+                    for (int r = 0; r < 16; ++r) { if (cc[r] > m) { m = cc[r]; am = (2 * qp + 1) * 32 + mfma_row(r, lane); } }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = mfma_row(r, lane);
@@ -474,10 +489,10 @@ __global__ __launch_bounds__(512, 2) void trunk_fwd_train_x3_kernel(
                         const float v1 = (nbase + (2 * qp + 1) * 32 + row < N) ? cc[r] : 0.f;
                         su += v0 + v1; qu = fmaf(v0, v0, fmaf(v1, v1, qu));
                     }
-                }
-            };
-            epi(c0, c1, 0);
-            epi(c2, c3, 1);
+                };
+                epi(c0, c1, 0);
+                epi(c2, c3, 1);
+            }
             const float om = __shfl_xor(m, 32); const int oa = __shfl_xor(am, 32);
             if (om > m || (om == m && oa < am)) { m = om; am = oa; }
             su += __shfl_xor(su, 32); qu += __shfl_xor(qu, 32);
@@ -490,7 +505,7 @@ __global__ __launch_bounds__(512, 2) void trunk_fwd_train_x3_kernel(
     }
     hsum += __shfl_xor(hsum, 32);
     if (h == 0) {
-        psh[((size_t)blockIdx.x * 2 + (wave >> 2)) * 128 + (wave & 3) * 32 + j] = hsum;
+        psh[((size_t)blockIdx.x * 2 + (wave >> 2)) * 128 + (wave & 3) * 32 + j] = (float)hsum;
 #pragma unroll
         for (int ci = 0; ci < 4; ++ci) {
             const int c = (wave + 8 * ci) * 32 + j;

@@ -152,4 +152,5 @@ def test_trunk_intermediates_large(which, cuda_device, pass_sequencing):
         assert r < tol, (kx, r)
     for kx, ky in [("dW1", "W1"), ("dW2", "W2"), ("dW3", "W3")] + ([("dT", "T")] if which == "feat" else []):
         r = _rel(feat[kx].cpu(), g[ky].cpu())
+        print(f"{which} {kx}: rel {r:.3e}")
         assert r < 1e-3, (kx, r)
