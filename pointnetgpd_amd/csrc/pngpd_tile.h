@@ -212,11 +212,7 @@ __device__ __forceinline__ void swz_compute(const float *tile, const f32x4 (&wf)
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
         f32x4 n0 = a0, n1 = a1;
-#ifdef ABL_NOA
-        if (false) {
-#else
         if (kb + 1 < NKB) {
-#endif
             const int c4 = (((kb + 1) * 2 + L.h) ^ sx) << 2;
             n0 = *(const f32x4 *)(r0 + c4);
             n1 = *(const f32x4 *)(r1 + c4);
@@ -340,22 +336,6 @@ __device__ __forceinline__ void k128_bf(const float *tile, const u16 *__restrict
 __device__ __forceinline__ void wg_priority() {
 #if PNGPD_PRIO
     if ((blockIdx.x >> PNGPD_PRIO_SHIFT) & 1) __builtin_amdgcn_s_setprio(PNGPD_PRIO);
-#endif
-}
-
-// Phase priority: a wave raises its issue priority for a VALU phase (epilogue, tile build) so that those instructions
-// are not queued behind the co-resident wave's stream of matrix instructions (which wait for the pipe anyway).
-#ifndef PNGPD_VPRIO
-#define PNGPD_VPRIO 0
-#endif
-__device__ __forceinline__ void valu_phase_begin() {
-#if PNGPD_VPRIO
-    __builtin_amdgcn_s_setprio(PNGPD_VPRIO);
-#endif
-}
-__device__ __forceinline__ void valu_phase_end() {
-#if PNGPD_VPRIO
-    __builtin_amdgcn_s_setprio(0);
 #endif
 }
 

@@ -203,9 +203,7 @@ __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
     for (int tile = t0; tile < t1; ++tile) {
         TM(0)
         if (LOADZ) {
-#ifndef ABL_NOBAR
             if (tile > t0) __syncthreads();   // every wave is done reading the previous tile's h2
-#endif
             TM(1)
         } else if (L.tid < TP) {
             float x0 = px0, x1 = px1, x2 = px2;
@@ -281,18 +279,11 @@ __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
             asm volatile("" : "+v"(hsum));
         }
         TM(2)
-#ifndef ABL_NOBAR
         __syncthreads();
-#endif
         TM(3)
         auto reduce_block = [&](int cb, const f32x16 &a0, const f32x16 &a1) {
             // first maximum over this lane's 32 rows (ascending row order) and the two moments
-            valu_phase_begin();
             float m, su, qu; int am;
-#ifdef ABL_NOEPI
-            if (a0[0] + a1[15] == 123.f) rm[cb] = 1.f;
-            return;
-#endif
             if (full) {
                 lane_max_moments(a0, a1, m, am, su, qu);
                 am += 4 * L.h;
@@ -311,10 +302,6 @@ __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
                     su += v0 + v1; qu = fmaf(v0, v0, fmaf(v1, v1, qu));
                 }
             }
-#ifdef ABL_NOMERGE
-            if (m + su + qu + (float)am == 123.f) rm[cb] = 1.f;
-            return;
-#endif
             const float om = __shfl_xor(m, 32); const int oa = __shfl_xor(am, 32);
             if (om > m || (om == m && oa < am)) { m = om; am = oa; }
             su += __shfl_xor(su, 32); qu += __shfl_xor(qu, 32);
@@ -323,25 +310,18 @@ __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
                 if (m > rm[c]) { rm[c] = m; int n = nbase + am; ri[c] = n < N ? n : N - 1; }
                 ss[c] += su; sq[c] += qu;
             }
-            valu_phase_end();
         };
 #pragma unroll 1
         for (int cp = 0; cp < 4; ++cp) {
             const int cbA = L.wave + 8 * cp, cbB = cbA + 4, cbN = L.wave + ((8 * cp + 8) & 31);
             f32x16 a0, a1;
-#ifndef ABL_NOW
             load_wfrag(wb, w3sp, cbB, L);
-#endif
             swz_compute<I2S, 16>(h2, wa, L, a0, a1);
             TM(4)
             reduce_block(cbA, a0, a1);
             TM(5)
-#ifndef ABL_NOW
             load_wfrag(wa, w3sp, cbN, L);
             swz_compute<I2S, 16>(h2, wb, L, a0, a1);
-#else
-            swz_compute<I2S, 16>(h2, wa, L, a0, a1);
-#endif
             TM(4)
             reduce_block(cbB, a0, a1);
             TM(5)
@@ -692,10 +672,8 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
                     for (int u = 0; u < 4; ++u) d = mfma32(av[u], bv[u], d);
                 }
             };
-#ifndef ABL_D_NOSPARSE
             sparse(hits, nlo, d0);
             sparse(hits + BWD_D_HITS, nhi, d1);
-#endif
         }
         TM(5)
         // Gram of the tile: D[i][j] += A[i][k = point] B[k = point][j], both operands read column-wise from h2.
@@ -716,9 +694,7 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
                     if (third == 2) gm2 = mfma32(rp[o2], av, gm2);
                 }
             };
-#ifndef ABL_D_NOGRAM
             if (cb < 2) { gram(0, 1); gram(16, 0); } else { gram(0, 0); gram(16, 2); }
-#endif
         }
         TM(6)
         }   // NT == 0
@@ -759,14 +735,10 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
                     o0[e] = g0[0]; o0[e + 1] = g0[1]; o1[e] = g1[0]; o1[e + 1] = g1[1];
                     if (NT == 1) { gb0[r] = g0[0]; gb0[r + 1] = g0[1]; gb1[r] = g1[0]; gb1[r + 1] = g1[1]; }
                 }
-#ifndef ABL_D_NOSTORE
                 if (NT != 1) {
                     gt[(size_t)rq * 256] = o0;
                     gt[(size_t)(4 + rq) * 256] = o1;
                 }
-#else
-                if (o0[0] + o1[3] == 123.f) gt[0] = o0;
-#endif
             }
             a1s += (double)(t1[0] + t1[1]);
             a2s += (double)(t2[0] + t2[1]);

@@ -304,27 +304,33 @@ __device__ __forceinline__ double s2_at(const double *__restrict__ S2c, int k, i
 
 // ---------------------------------------------------------------------------------------
 // dW3[c][j] = G[c][j] - s3 (m1 sh[j] + (m2/sig3) (W3 Sc)[c][j]),  Sc = S2 - sh sh^T / M
-// block = DW3_CPB channels c, 128 threads = j.  Thread j walks column j of S2 block by block (the storage orientation
+// block = DW3_CPB channels c.  A thread walks column j of S2 block-wise (the storage orientation
 // of a 32x32 block is decided once per block, not per element) and every element it fetches serves all DW3_CPB
 // channels of the block (one channel per block with a per-element s2_at() was 46 us for 17 M fp64 FMAs).
 // ---------------------------------------------------------------------------------------
 #define DW3_CPB 4
-__global__ __launch_bounds__(128) void dw3_finalize_kernel(
+// 512 threads = 4 row blocks a (k = 32 a + i) x 128 columns j: every thread walks ONE 32x32 block of S2 (32 dependent
+// loads instead of 128 — the kernel is a latency chain at two waves per CU otherwise: 31 us -> 10 us), the four partial
+// dot products of a column meet in LDS in fixed order.
+__global__ __launch_bounds__(512) void dw3_finalize_kernel(
     const double *__restrict__ G, const double *__restrict__ S2c, const double *__restrict__ sh, double M,
     const float *__restrict__ w3, const float *__restrict__ g3, const double *__restrict__ stats,
     const double *__restrict__ m12, double eps, float *__restrict__ dW3) {
     __shared__ double wrow[DW3_CPB][128];
     __shared__ double red[DW3_CPB][128];
-    const int c0 = blockIdx.x * DW3_CPB, j = threadIdx.x;
+    __shared__ double part[4][DW3_CPB][128];
+    const int c0 = blockIdx.x * DW3_CPB, j = threadIdx.x & 127, a = threadIdx.x >> 7;
     const double shj = sh[j];
+    if (a == 0) {
 #pragma unroll
-    for (int u = 0; u < DW3_CPB; ++u) {
-        wrow[u][j] = (double)w3[(size_t)(c0 + u) * 128 + j];
-        red[u][j] = wrow[u][j] * shj;
+        for (int u = 0; u < DW3_CPB; ++u) {
+            wrow[u][j] = (double)w3[(size_t)(c0 + u) * 128 + j];
+            red[u][j] = wrow[u][j] * shj;
+        }
     }
     __syncthreads();
     for (int s = 64; s > 0; s >>= 1) {
-        if (j < s) {
+        if (a == 0 && j < s) {
 #pragma unroll
             for (int u = 0; u < DW3_CPB; ++u) red[u][j] += red[u][j + s];
         }
@@ -334,7 +340,7 @@ __global__ __launch_bounds__(128) void dw3_finalize_kernel(
 #pragma unroll
     for (int u = 0; u < DW3_CPB; ++u) dot[u] = 0.0;
     const int bb = j >> 5, jj = j & 31;
-    for (int a = 0; a < 4; ++a) {          // rows k = 32 a + i of column j: block (a, bb) of S2
+    {          // rows k = 32 a + i of column j: block (a, bb) of S2
         const int d = (bb - a) & 3;
         const bool tr = d == 3 || (d == 2 && a >= 2);          // stored as the transposed block (bb, a)
         const int ra = tr ? bb : a, q = tr ? ((a - bb) & 3) : d;
@@ -352,12 +358,17 @@ __global__ __launch_bounds__(128) void dw3_finalize_kernel(
         }
     }
 #pragma unroll
-    for (int u = 0; u < DW3_CPB; ++u) {
-        const int c = c0 + u;
-        const double w3sc = dot[u] - red[u][0] * shj / M;
-        const double sig = sqrt(stats[1024 + c] + eps);
-        const double s3 = (double)g3[c] / sig;
-        dW3[(size_t)c * 128 + j] = (float)(G[(size_t)c * 128 + j] - s3 * (m12[c] * shj + (m12[1024 + c] / sig) * w3sc));
+    for (int u = 0; u < DW3_CPB; ++u) part[a][u][j] = dot[u];
+    __syncthreads();
+    if (a == 0) {
+#pragma unroll
+        for (int u = 0; u < DW3_CPB; ++u) {
+            const int c = c0 + u;
+            const double w3sc = ((part[0][u][j] + part[1][u][j]) + (part[2][u][j] + part[3][u][j])) - red[u][0] * shj / M;
+            const double sig = sqrt(stats[1024 + c] + eps);
+            const double s3 = (double)g3[c] / sig;
+            dW3[(size_t)c * 128 + j] = (float)(G[(size_t)c * 128 + j] - s3 * (m12[c] * shj + (m12[1024 + c] / sig) * w3sc));
+        }
     }
 }
 
@@ -776,7 +787,7 @@ int pngpd_dw3_finalize(const double *G, const double *S2c, const double *sh, int
                        void *stream) {
     if (!G || !S2c || !sh || !w3 || !g3 || !stats || !m12 || !dW3 || B <= 0 || N <= 0)
         return PNGPD_ERR_INVALID_ARG;
-    LAUNCH(dw3_finalize_kernel, dim3(1024 / DW3_CPB), dim3(128), G, S2c, sh, (double)B * N, w3, g3, stats, m12,
+    LAUNCH(dw3_finalize_kernel, dim3(1024 / DW3_CPB), dim3(512), G, S2c, sh, (double)B * N, w3, g3, stats, m12,
            (double)eps, dW3);
 }
 

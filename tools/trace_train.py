@@ -12,7 +12,7 @@ prec = sys.argv[2] if len(sys.argv) > 2 else "fp32"      # fp32 | bf16x3 | bf16
 from pointnetgpd_amd import train as _train
 _train.set_train_precision(prec)
 dev = torch.device("cuda:0")
-B, N, k = 1024, 1024, 2
+B, N, k = (int(os.environ.get(v, d)) for v, d in (("TRACE_B", 1024), ("TRACE_N", 1024), ("TRACE_K", 2)))
 m = bench.build_model(N, k, dev).train()
 from pointnetgpd_amd.optim import FlatAdam
 opt = FlatAdam(m.parameters(), lr=0.005)
@@ -24,4 +24,4 @@ for _ in range(steps):
     F.nll_loss(lp, y).backward()
     opt.step()
 torch.cuda.synchronize()
-print("steps", steps, prec)
+print("steps", steps, prec, "B", B, "N", N, "k", k)
