@@ -370,6 +370,35 @@ class Timer:
                 "min_wall": min(walls), "out": out}
 
 
+def measure_sustained_mfma(dev):
+    """TFLOP/s of a bare stream of matrix instructions (pngpd_probe_mfma_rate, HIP events on the launch stream)."""
+    import ctypes
+    import torch
+    from pointnetgpd_amd import _lib
+    out = {}
+    try:
+        lib = _lib.load()
+        sink = torch.empty(512 * 512, device=dev, dtype=torch.float32)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        for name, dt, iters in (("f32", 0, 20000), ("bf16", 1, 40000)):
+            flops = ctypes.c_longlong(0)
+            rates = []
+            for rep in range(5):        # the first two launches warm the clocks up; median of the other three
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                with _lib.device_guard(dev):
+                    _lib.check(lib.pngpd_probe_mfma_rate(dt, 1, iters, sink.data_ptr(), ctypes.addressof(flops), stream),
+                               "probe_mfma_rate")
+                e1.record()
+                torch.cuda.synchronize()
+                if rep >= 2:
+                    rates.append(flops.value / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+            out[name] = round(sorted(rates)[1], 1)
+    except Exception as e:     # a diagnostic: never fail the bench over it
+        out["error"] = repr(e)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -595,6 +624,7 @@ def main():
     trunk_ms = e0.elapsed_time(e1) / reps       # includes the 5 us partial-max combine when S > 1
     trunk_flops = B * N * FLOP_PER_POINT_TRUNK
     achieved = trunk_flops / (trunk_ms * 1e-3) / 1e12
+    sustained = measure_sustained_mfma(dev)     # {dtype: TFLOP/s} of a bare MFMA stream on THIS box, or {}
 
     traffic, traffic_src = None, None
     if args.pmc and world == 1:
@@ -635,7 +665,16 @@ def main():
             "hbm_algorithmic_gbs": round(value / world * alg_bytes / B / 1e9, 3),
             "roofline": {"bound": "mfma", "kernel": "trunk_infer_kernel", "achieved": round(achieved, 2),
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                         "peak_sustained_measured": sustained.get("f32"),
+                         "frac_of_sustained": (round(achieved / sustained["f32"], 4) if sustained.get("f32") else None),
+                         "peak_sustained_note": ("TFLOP/s of a kernel that issues nothing but independent "
+                                                 "v_mfma_f32_32x32x2_f32 on every SIMD (pngpd_probe_mfma_rate), timed "
+                                                 "in this run: the clock a CU array holds under that load is below the "
+                                                 "boost clock the nominal peak assumes"),
+                         "peak_sustained_bf16_measured": sustained.get("bf16"),
+                         **({"peak_sustained_error": sustained["error"]} if "error" in sustained else {}),
+                         "traffic": traffic,
                          "traffic_unit": "HBM bytes/launch", "traffic_source": traffic_src,
                          "avg_launch_ms": round(trunk_ms, 4), "flops_per_launch": trunk_flops,
                          "hbm_frac_algorithmic": round(value / world * alg_bytes / B / 1e9 / HBM_PEAK_GBS, 6)},
@@ -646,6 +685,9 @@ def main():
             res["infer_fast_bf16x3"] = fast_res["bf16x3"]
             res["infer_fast_bf16"] = fast_res["bf16"]
         if train_res is not None:
+            if sustained.get("f32") and "tflops_executed" in train_res:
+                train_res["tflops_executed_frac_of_sustained_fp32"] = round(
+                    train_res["tflops_executed"] / (world * sustained["f32"]), 4)
             res["train"] = train_res
             res["value_train"] = train_res["value"]
             res["value_train_is"] = "training-step leg (fwd + nll_loss + bwd + Adam, exact fp32), grasps/s, same batch"

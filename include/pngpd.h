@@ -352,6 +352,13 @@ typedef struct pngpd_head_train {
     void *scratch; size_t scratch_bytes;   /* backward only */
 } pngpd_head_train_t;
 
+/* Diagnostic, used by bench.py's roofline block: a stream of independent matrix instructions and nothing else on every
+ * CU (dtype 0: v_mfma_f32_32x32x2_f32, 1: v_mfma_f32_32x32x16_bf16; waves_per_simd 1 or 2; `iters` x 8 instructions per
+ * wave).  Time the launch on `stream`; *flops_out (may be NULL) receives the FLOPs it executes, so FLOPs / time is the
+ * matrix rate this device SUSTAINS — the ceiling the trunk kernels are priced against next to the nominal peak.
+ * sink: >= 512 x CU-count floats of scratch (never written).                                                          */
+int pngpd_probe_mfma_rate(int dtype, int waves_per_simd, int iters, float *sink, long long *flops_out, void *stream);
+
 size_t pngpd_struct_bytes(int which);   /* sizeof of pngpd_trunk_train_t (0) / pngpd_head_train_t (1): FFI self-check */
 size_t pngpd_head_train_save_bytes(const pngpd_head_train_t *a);        /* reads B, H1, H2 */
 size_t pngpd_head_train_scratch_bytes(const pngpd_head_train_t *a);     /* reads B, H1, H2, k */

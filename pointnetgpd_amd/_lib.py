@@ -114,6 +114,7 @@ SIGNATURES = {
                            [ctypes.c_float] + [c_void] * 4 + [c_void]),
     # ---- one entry per direction of the training graph + flat Adam
     "pngpd_struct_bytes": (ctypes.c_size_t, [ctypes.c_int]),
+    "pngpd_probe_mfma_rate": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void, c_void, c_void]),
     "pngpd_trunk_train_save_bytes": (ctypes.c_size_t, [c_void]),
     "pngpd_trunk_train_scratch_bytes": (ctypes.c_size_t, [c_void]),
     "pngpd_trunk_train_fwd": (ctypes.c_int, [c_void, c_void]),
