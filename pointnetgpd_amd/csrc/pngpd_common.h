@@ -22,6 +22,20 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 
 __device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+// The two 32-lane halves of a wave exchange a register: lo = the value held by lane (l & 31), hi = the value held by
+// lane 32 + (l & 31), in every lane — one v_permlane32_swap_b32 (a VALU instruction of gfx950) where __shfl_xor(x, 32)
+// is a ds_bpermute_b32, i.e. an LDS round trip queued behind the workgroup's A-fragment reads.
+__device__ __forceinline__ void half_pair(float x, float &lo, float &hi) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    lo = __uint_as_float(r[0]); hi = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void half_pair(int x, int &lo, int &hi) {
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
+    lo = (int)r[0]; hi = (int)r[1];
+}
+__device__ __forceinline__ float half_sum(float x) { float lo, hi; half_pair(x, lo, hi); return lo + hi; }
+
 // ---- the per-lane epilogue of a pair of 32x32 accumulator blocks (training pass C) -----------------------------
 // On gfx950 the fp32 matrix instruction does NOT overlap VALU work on its SIMD, from either resident wave
 // (tools/probes/mfma_valu_overlap.hip: a v_mfma_f32_32x32x2_f32 costs 64 cycles, every plain VALU instruction ~4.7

@@ -62,25 +62,21 @@ __device__ __forceinline__ L1C load_l1c(const float *__restrict__ w1, const floa
     return k;
 }
 
-// (Packed FMAs on point pairs: each element still goes through the same three-FMA chain, so the values are unchanged; the
-// affine / plain variants are two loops — a per-element select on k.affine costs a VALU instruction per activation.)
+// (The affine / plain variants are two loops: a per-element select on k.affine costs a VALU instruction per activation.
+// Packed FMAs on point pairs were measured and are SLOWER here — four dependent v_pk_fma_f32 per pair with a wait state
+// each against two interleaved scalar chains: gather pass 0.151 -> 0.183 ms.)
 template <bool AFF>
 __device__ __forceinline__ void layer1_rows(const float *xs, const L1C &k, float *dst, int p0) {
-    const f32x2 w0 = {k.w0, k.w0}, w1 = {k.w1, k.w1}, w2 = {k.w2, k.w2}, bb = {k.b, k.b};
-    const f32x2 sc = {k.sc, k.sc}, sh = {k.sh, k.sh};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {   // 12 broadcast ds_read_b128: the wave's 16 points
         const f32x4 x0 = *(const f32x4 *)(xs + p0 + 4 * q);
         const f32x4 x1 = *(const f32x4 *)(xs + TP + p0 + 4 * q);
         const f32x4 x2 = *(const f32x4 *)(xs + 2 * TP + p0 + 4 * q);
 #pragma unroll
-        for (int e = 0; e < 4; e += 2) {
-            f32x2 z = __builtin_elementwise_fma(w2, f32x2{x2[e], x2[e + 1]},
-                      __builtin_elementwise_fma(w1, f32x2{x1[e], x1[e + 1]},
-                      __builtin_elementwise_fma(w0, f32x2{x0[e], x0[e + 1]}, bb)));
-            if (AFF) z = __builtin_elementwise_fma(z, sc, sh);
-            dst[(4 * q + e) * H1S] = fmaxf(z[0], 0.f);
-            dst[(4 * q + e + 1) * H1S] = fmaxf(z[1], 0.f);
+        for (int e = 0; e < 4; ++e) {
+            float z = fmaf(k.w2, x2[e], fmaf(k.w1, x1[e], fmaf(k.w0, x0[e], k.b)));
+            if (AFF) z = fmaf(z, k.sc, k.sh);
+            dst[(4 * q + e) * H1S] = fmaxf(z, 0.f);
         }
     }
 }

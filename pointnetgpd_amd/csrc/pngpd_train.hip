@@ -282,6 +282,10 @@ __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
         __syncthreads();
         TM(3)
         auto reduce_block = [&](int cb, const f32x16 &a0, const f32x16 &a1) {
+            // the block's running state is requested first: its LDS latency (queued behind the workgroup's A-fragment
+            // reads) passes under the VALU work below instead of in four dependent round trips after it
+            const int c = cb * 32 + L.j;
+            const float rmc = rm[c], ssc = ss[c], sqc = sq[c];
             // first maximum over this lane's 32 rows (ascending row order) and the two moments
             float m, su, qu; int am;
             if (full) {
@@ -302,13 +306,17 @@ __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
                     su += v0 + v1; qu = fmaf(v0, v0, fmaf(v1, v1, qu));
                 }
             }
-            const float om = __shfl_xor(m, 32); const int oa = __shfl_xor(am, 32);
-            if (om > m || (om == m && oa < am)) { m = om; am = oa; }
-            su += __shfl_xor(su, 32); qu += __shfl_xor(qu, 32);
+            // the two row halves meet through v_permlane32_swap (no LDS round trip); ties go to the earlier row
+            {
+                float mlo, mhi; int alo, ahi;
+                half_pair(m, mlo, mhi); half_pair(am, alo, ahi);
+                const bool hi_wins = mhi > mlo || (mhi == mlo && ahi < alo);
+                m = hi_wins ? mhi : mlo; am = hi_wins ? ahi : alo;
+                su = half_sum(su); qu = half_sum(qu);
+            }
             if (L.h == 0) {
-                const int c = cb * 32 + L.j;
-                if (m > rm[c]) { rm[c] = m; int n = nbase + am; ri[c] = n < N ? n : N - 1; }
-                ss[c] += su; sq[c] += qu;
+                if (m > rmc) { rm[c] = m; int n = nbase + am; ri[c] = n < N ? n : N - 1; }
+                ss[c] = ssc + su; sq[c] = sqc + qu;
             }
         };
 #pragma unroll 1
@@ -349,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void trunk_fwd_train_kernel(
 // workgroup = (64-channel chunk cc, cloud range rng).
 // ---------------------------------------------------------------------------------------
 template <int NT>
-__global__ __launch_bounds__(256, 2) void trunk_bwd_gather_kernel(
+__global__ __launch_bounds__(256, 4) void trunk_bwd_gather_kernel(   // 4 workgroups per CU: <= 128 VGPRs (129 costs 25 %)
     const float *__restrict__ x, int B, int N, const float *__restrict__ trans, TrainChan P,
     const int *__restrict__ idx, const float *__restrict__ coef, int clouds_per_range,
     float *__restrict__ Gp) {

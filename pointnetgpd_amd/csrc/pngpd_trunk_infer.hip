@@ -15,6 +15,23 @@
 
 #define TRUNK_LDS_FLOATS (TP * I1S + TP * I2S + 3 * TP + 1024)
 
+// Max of a lane's 32 accumulator values (v_max3 tree) joined with the other row half of the tile.
+__device__ __forceinline__ float block_max(const f32x16 &a0, const f32x16 &a1) {
+    float t[6];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) t[i] = max3f(a0[3 * i], a0[3 * i + 1], a0[3 * i + 2]);
+    t[5] = a0[15];
+    float u[6];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) u[i] = max3f(a1[3 * i], a1[3 * i + 1], a1[3 * i + 2]);
+    u[5] = a1[15];
+    const float m = max3f(max3f(t[0], t[1], t[2]), max3f(t[3], t[4], t[5]),
+                          max3f(max3f(u[0], u[1], u[2]), max3f(u[3], u[4], u[5]), -INFINITY));
+    float lo, hi;
+    half_pair(m, lo, hi);
+    return fmaxf(lo, hi);
+}
+
 __global__ __launch_bounds__(256, 2) void trunk_infer_kernel(
     const float *__restrict__ x, int N, const float *__restrict__ trans,
     const float *__restrict__ w1, const float *__restrict__ b1,
@@ -101,20 +118,17 @@ __global__ __launch_bounds__(256, 2) void trunk_infer_kernel(
         for (int cp = cp0; cp < cp1; ++cp) {
             const int cbA = L.wave + 8 * cp, cbB = cbA + 4, cbN = L.wave + 8 * (cp + 1 < cp1 ? cp + 1 : cp0);
             f32x16 a0, a1;
+            // the block's running max is requested before its 128 MFMAs and merged after them; the two row halves of
+            // the tile meet through v_permlane32_swap — no LDS round trip is left between two blocks' matrix streams
+            const float rA = rm[cbA * 32 + L.j], rB = rm[cbB * 32 + L.j];
             load_wfrag(wb, w3p, cbB, L);
             swz_compute<I2S, 16>(h2, wa, L, a0, a1);
-            float m = fmaxf(a0[0], a1[0]);
-#pragma unroll
-            for (int r = 1; r < 16; ++r) m = fmaxf(m, fmaxf(a0[r], a1[r]));
-            m = fmaxf(m, __shfl_xor(m, 32));   // the other half-wave holds the tile's other rows
-            if (L.h == 0) rm[cbA * 32 + L.j] = fmaxf(rm[cbA * 32 + L.j], m);
+            float m = block_max(a0, a1);
+            if (L.h == 0) rm[cbA * 32 + L.j] = fmaxf(rA, m);
             load_wfrag(wa, w3p, cbN, L);
             swz_compute<I2S, 16>(h2, wb, L, a0, a1);
-            m = fmaxf(a0[0], a1[0]);
-#pragma unroll
-            for (int r = 1; r < 16; ++r) m = fmaxf(m, fmaxf(a0[r], a1[r]));
-            m = fmaxf(m, __shfl_xor(m, 32));
-            if (L.h == 0) rm[cbB * 32 + L.j] = fmaxf(rm[cbB * 32 + L.j], m);
+            m = block_max(a0, a1);
+            if (L.h == 0) rm[cbB * 32 + L.j] = fmaxf(rB, m);
         }
         // no barrier here: the next tile's xs/h1 writes do not alias h2, and the barrier before its
         // layer 2 orders the h2 rewrite after every wave's layer-3 reads.

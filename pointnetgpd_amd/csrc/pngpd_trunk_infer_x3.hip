@@ -195,6 +195,7 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
         // One channel block x all four point blocks per step: 4 independent accumulator chains (an accumulator is
         // re-used every 4th MFMA) and the A fragments of k-step ks+1 in flight while k-step ks issues.
         auto block4 = [&](int cb, const f32x4 (&wah)[8], const f32x4 (&wal)[8]) {
+            const float rmc = rm[cb * 32 + j];   // requested before the block's MFMAs, merged after them
             f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
             const int ro = j * X2S + h * 8;
             f32x4 ah[4], al[4];
@@ -227,9 +228,10 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
             }
             float m = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) m = fmaxf(m, fmaxf(fmaxf(c0[r], c1[r]), fmaxf(c2[r], c3[r])));
-            m = fmaxf(m, __shfl_xor(m, 32));
-            if (h == 0) rm[cb * 32 + j] = fmaxf(rm[cb * 32 + j], m);
+            for (int r = 0; r < 16; ++r) m = max3f(m, max3f(c0[r], c1[r], c2[r]), c3[r]);
+            float mlo, mhi;
+            half_pair(m, mlo, mhi);   // v_permlane32_swap: the LDS is this kernel's scarcest resource, no ds_bpermute
+            if (h == 0) rm[cb * 32 + j] = fmaxf(rmc, fmaxf(mlo, mhi));
         };
         if (NT == 1) {
 #pragma unroll
@@ -493,9 +495,13 @@ __global__ __launch_bounds__(512, 2) void trunk_fwd_train_x3_kernel(
                 epi(c0, c1, 0);
                 epi(c2, c3, 1);
             }
-            const float om = __shfl_xor(m, 32); const int oa = __shfl_xor(am, 32);
-            if (om > m || (om == m && oa < am)) { m = om; am = oa; }
-            su += __shfl_xor(su, 32); qu += __shfl_xor(qu, 32);
+            {
+                float mlo, mhi; int alo, ahi;
+                half_pair(m, mlo, mhi); half_pair(am, alo, ahi);
+                const bool hi_wins = mhi > mlo || (mhi == mlo && ahi < alo);
+                m = hi_wins ? mhi : mlo; am = hi_wins ? ahi : alo;
+                su = half_sum(su); qu = half_sum(qu);
+            }
             if (h == 0) {
                 const int c = cb * 32 + j;
                 if (m > rm[c]) { rm[c] = m; const int n = nbase + am; ri[c] = n < N ? n : N - 1; }

@@ -23,4 +23,8 @@ bash tools/pmc_train.sh ${TAG} > /tmp/pmct.log 2>&1; grep "rc=" /tmp/pmct.log
 timeout 120 python tools/bench_eval.py 2>/dev/null > gpurun_out/${TAG}_bench_eval.txt
 timeout 120 python tools/bench_step.py 2>/dev/null > gpurun_out/${TAG}_bench_step.txt
 for f in trace_small_train trace_small_eval; do rm -rf /tmp/pst; ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/pst -o t -- python $GRAFT_REPO_ROOT/tools/$f.py > /tmp/$f.log 2>&1 ); DB=$(find /tmp/pst -name "*.db" | head -1); [ -n "$DB" ] && python tools/rocprof_summary.py --all gpurun_out/${TAG}_${f}.md "$f (B 64 N 750)=$DB" > /dev/null; done
+# matrix / vector issue probe (tools/probes/mfma_valu_overlap.hip, built on the dev box into build_probe/)
+( for v in 0 1 4 8 9; do [ -x build_probe/mvo$v ] && timeout 60 ./build_probe/mvo$v; done ) > gpurun_out/${TAG}_probe_mfma_valu.txt 2>&1
+# per-phase wave-cycle accounting of passes C / D / E (a -DPNGPD_TIMING build of the library in build_probe/)
+[ -f build_probe/lib_tm.so ] && PNGPD_LIB=$GRAFT_REPO_ROOT/build_probe/lib_tm.so timeout 200 python tools/phase_times.py 2>/dev/null | grep -v "^B " > gpurun_out/${TAG}_phase_times.txt
 ls gpurun_out | grep ${TAG}

@@ -9,9 +9,10 @@ from pointnetgpd_amd import _lib, ops
 lib = _lib.load()
 buf = (ctypes.c_ulonglong * 16)()
 g = runpy.run_path(os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench_pass.py"))
-names = {"fwd_train": ["(loop)", "barrier 1", "h2 tile build", "barrier 2", "8 x 128 mfma (issue)", "8 x epilogue (rest: LDS running max, sums)", "epi: argmax chain", "epi: sums", "epi: 4 bpermute + merge"],
+names = {"fwd_train": ["(loop)", "barrier 1", "h2 tile build", "barrier 2", "8 x 128 mfma (issue)", "8 x epilogue"],
          "bwd_d": ["loads+census", "barrier1", "compact+h2 write", "barrier2", "A.h2 (128 mfma)", "sparse", "gram (80 mfma)", "epilogue+store"],
-         "bwd_e": ["loads+stage x", "barrier A", "layer1", "dz tile", "barrier B", "W2^T dz (64 mfma)", "g1 epilogue", "dW2 (64 mfma)"]}
+         "bwd_e": ["next tile's point loads issued", "barrier A", "layer1", "dz tile (first use of the prefetched hand-off)", "barrier B",
+                   "W2^T dz (64 mfma) + prefetch issue", "g1 epilogue", "dW2 (64 mfma)"]}
 x, T, w1, b1, s1c, t1c, w2p, s2c, t2c, is2, nm2, Ap, cvec, w3, idx, coef, S, z2t, g2t = [g[k] for k in
     "x T w1 b1 s1c t1c w2p s2c t2c is2 nm2 Ap cvec w3 idx coef S z2t g2t".split()]
 is1, nm1, ev, w2tp = g["is1"], g["nm1"], g["ev"], g["w2tp"]
