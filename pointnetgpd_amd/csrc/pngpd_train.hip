@@ -460,8 +460,8 @@ struct BwdDParams {
     const int *idx;             // (B,1024)
     const float *coef;          // (B,1024)
 };
-#define BWD_D_HITS 1032   // per list: up to 1024 hits + read-ahead padding of the 8-hit sparse step
-#define BWD_D_LDS_FLOATS (TP * H2S + TP * H1S + 3 * TP + 1024 + 1024 + BWD_D_HITS + 16)
+#define BWD_D_HITS 1048   // per list: up to 1024 hit records + 24 zero records (16-hit steps, two steps of read-ahead)
+#define BWD_D_LDS_FLOATS (TP * H2S + TP * H1S + 3 * TP + 1024 + 1024 + 4 * BWD_D_HITS + 16)
 
 // LOADZ: the raw layer-2 output z2 was stored by pass B (z2t, lane-major tiles) and is read back here instead of
 // recomputing layers 1-2: 64 of the 324 MFMAs per wave and tile, the layer-1 VALU work, the h1 tile and one of the
@@ -480,7 +480,10 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
     float *xs = h1 + (LOADZ ? 0 : TP * H1S);   // [3][TP]
     float *cfl = xs + 3 * TP;             // [1024] coef row of this cloud
     int *idxl = (int *)(cfl + 1024);      // [1024] arg-extremum point of every channel of this cloud
-    unsigned short *hits = (unsigned short *)(idxl + 1024);   // [2 lists][BWD_D_HITS]: (c << 5) | (point & 31)
+    // [2 lists][BWD_D_HITS] hit records {-coef[c] as bits, (c << 5) | (point & 31)}: everything the sparse steps need in
+    // ONE LDS read per hit (the old u16 list cost a second, dependent read of the coefficient row per hit, and every
+    // LDS round trip of this phase queues behind the other waves' A-fragment reads)
+    uint2 *hits = (uint2 *)(idxl + 1024);
     int *hcnt = (int *)(hits + 2 * BWD_D_HITS);               // [2 lists][4 waves]
     const Lane L;
     wg_priority();
@@ -556,10 +559,14 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
                 const int n = idxl[c] - nbase;
                 const bool lo = n >= 0 && n < 32, hi = n >= 32 && n < TP;
                 const unsigned long long mlo = __ballot(lo), mhi = __ballot(hi);
-                if (lo) hits[olo + __popcll(mlo & ltmask)] = (unsigned short)((c << 5) | n);
-                if (hi) hits[BWD_D_HITS + ohi + __popcll(mhi & ltmask)] = (unsigned short)((c << 5) | (n - 32));
+                const unsigned ncf = __float_as_uint(-cfl[c]);
+                if (lo) hits[olo + __popcll(mlo & ltmask)] = uint2{ncf, (unsigned)((c << 5) | n)};
+                if (hi) hits[BWD_D_HITS + ohi + __popcll(mhi & ltmask)] = uint2{ncf, (unsigned)((c << 5) | (n - 32))};
                 olo += __popcll(mlo); ohi += __popcll(mhi);
             }
+            // zero records behind both lists: the sparse steps read whole steps and two steps ahead, unguarded
+            if (L.tid < 24) hits[nlo + L.tid] = uint2{0u, 0u};
+            else if (L.tid >= 32 && L.tid < 56) hits[BWD_D_HITS + nhi + L.tid - 32] = uint2{0u, 0u};
         }
         nlo = __builtin_amdgcn_readfirstlane(nlo);
         nhi = __builtin_amdgcn_readfirstlane(nhi);
@@ -597,18 +604,15 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
             k128_bf<NT>(h2, D.Ax, cb, 1, L, d1);
             {   // sparse term: 16 hits per k-step; lane (j, h) supplies hits e0 + 8h .. 8h+7
                 const float *w3c = D.w3 + c2;
-                auto sparse = [&](const unsigned short *hl, int n, f32x16 &d) {
+                auto sparse = [&](const uint2 *hl, int n, f32x16 &d) {
 #pragma unroll 1
                     for (int e0 = 0; e0 < n; e0 += 16) {
                         float av[8], bv[8];
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
-                            const int e = e0 + 8 * L.h + u;
-                            const int v = (e < BWD_D_HITS) ? hl[e] : 0;
-                            const int c = (e < n) ? (v >> 5) : 0;
-                            const float cf = (e < n) ? cfl[c] : 0.f;
-                            bv[u] = w3c[(size_t)c * 128];
-                            av[u] = ((v & 31) == L.j) ? -cf : 0.f;
+                            const uint2 rec = hl[e0 + 8 * L.h + u];   // zero records behind the list: coef 0, row 0
+                            bv[u] = w3c[(size_t)(rec.y >> 5) * 128];
+                            av[u] = ((int)(rec.y & 31) == L.j) ? __uint_as_float(rec.x) : 0.f;
                         }
                         f32x4 ah, al, bh, bl;
                         bf_pack8<NT>(av, ah, al);
@@ -660,24 +664,37 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
             }
         }
         TM(4)
-        // d -= sparse term: 8 hits (4 k-steps) per iteration, four W3 row pieces in flight
+        // d -= sparse term: 8 hits (4 k-steps) per step.  The step is a chain LDS record -> W3 row piece (L2) -> MFMA,
+        // and a tile has ~16 of them: left serial, the phase was 18,500 of a wave's 51,800 cycles per tile for 2,000
+        // cycles of matrix work (tools/phase_times.py).  Software-pipelined two deep: the records of step i+2 and the
+        // row pieces of step i+1 are in flight while step i is on the pipe.
         {
-            const float *w3c = D.w3 + c2;
-            auto sparse = [&](const unsigned short *hl, int n, f32x16 &d) {
+            const char *w3c = (const char *)(D.w3 + c2);
+            auto sparse = [&](const uint2 *hl, int n, f32x16 &d) {
+                if (n <= 0) return;
+                const uint2 *hp = hl + L.h;
+                uint2 r0[4], r1[4];
+                float b0[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) r0[u] = hp[2 * u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) r1[u] = hp[8 + 2 * u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) b0[u] = *(const float *)(w3c + (size_t)(r0[u].y >> 5) * 512);
 #pragma unroll 1
                 for (int e0 = 0; e0 < n; e0 += 8) {
-                    float av[4], bv[4];
+                    uint2 r2[4];
+                    float b1[4], av[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int e = e0 + 2 * u + L.h;
-                        const int v = hl[e];
-                        const int c = (e < n) ? (v >> 5) : 0;
-                        const float cf = (e < n) ? cfl[c] : 0.f;
-                        bv[u] = w3c[(size_t)c * 128];
-                        av[u] = ((v & 31) == L.j) ? -cf : 0.f;
-                    }
+                    for (int u = 0; u < 4; ++u) r2[u] = hp[e0 + 16 + 2 * u];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) d = mfma32(av[u], bv[u], d);
+                    for (int u = 0; u < 4; ++u) b1[u] = *(const float *)(w3c + (size_t)(r1[u].y >> 5) * 512);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) av[u] = ((int)(r0[u].y & 31) == L.j) ? __uint_as_float(r0[u].x) : 0.f;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) d = mfma32(av[u], b0[u], d);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { r0[u] = r1[u]; r1[u] = r2[u]; b0[u] = b1[u]; }
                 }
             };
             sparse(hits, nlo, d0);
