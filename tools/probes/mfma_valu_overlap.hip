@@ -115,7 +115,10 @@ void run(const char *name, int threads) {
 }
 
 int main() {
-    printf("VOP %d\n", VOP);
+    const char *names[] = {"v_fma_f32", "v_cndmask_b32", "v_max_f32", "v_add_u32", "v_cmp_gt_f32 (vcc)", "v_mov_b32", "v_max3_f32",
+                           "s_nop 3", "ds_read_b32", "v_pk_fma_f32", "v_min3_u32", "v_bfi_b32", "v_pk_add_f32",
+                           "v_cmp_gt_f32 (sgpr)", "v_or_b32"};
+    printf("== the interleaved instruction (\"op\") is %s; columns: wall time of the launch | cycles per matrix instruction slot\n", names[VOP]);
     run<0, 0, 0>("fp32 mfma only, 1 wave/SIMD", 256);
     run<0, 8, 0>("fp32 mfma + 8 op same wave, 1 wave/SIMD", 256);
     run<0, 16, 0>("fp32 mfma + 16 op same wave, 1 wave/SIMD", 256);
