@@ -253,18 +253,18 @@ __device__ __forceinline__ void layer2_compute(const float *h1, const f32x4 (&wf
     }
 }
 
-// K = 128 product accumulated INTO acc0/acc1 (not zeroed here), weights streamed from L2 through a 4-deep register
-// ring (fragment kb+4 is requested when fragment kb is consumed: ~2,000 MFMA cycles of cover) and the A fragments
-// double-buffered.  Both point blocks (NPB = 2) or only block pb (NPB = 1, acc1 unused).
-template <int NPB>
+// K = 128 product accumulated INTO acc0/acc1 (not zeroed here), weights streamed from L2 through a RING-deep register
+// ring (fragment kb+RING is requested when fragment kb is consumed: RING x 256 (NPB = 1) or x 512 (NPB = 2) MFMA cycles
+// of cover — an L2 round trip under load is 1,000-2,000 cycles) and the A fragments double-buffered.  Both point blocks (NPB = 2) or only block pb (NPB = 1, acc1 unused).
+template <int NPB, int RING = 4>
 __device__ __forceinline__ void k128_stream(const float *tile, const float *__restrict__ wp128, int cb, int pb,
                                             const Lane &L, f32x16 &acc0, f32x16 &acc1) {
     const f32x4 *wp = (const f32x4 *)wp128 + (size_t)(cb * 16) * 64 + L.lane;
     const float *a0p = tile + (pb * 32 + L.j) * H2S + L.h * 4;
     const float *a1p = tile + (32 + L.j) * H2S + L.h * 4;
-    f32x4 wq[4];
+    f32x4 wq[RING];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) wq[i] = wp[i * 64];
+    for (int i = 0; i < RING; ++i) wq[i] = wp[i * 64];
     f32x4 a0 = *(const f32x4 *)a0p, a1 = a0;
     if (NPB == 2) a1 = *(const f32x4 *)a1p;
 #pragma unroll
@@ -274,8 +274,8 @@ __device__ __forceinline__ void k128_stream(const float *tile, const float *__re
             n0 = *(const f32x4 *)(a0p + (kb + 1) * 8);
             if (NPB == 2) n1 = *(const f32x4 *)(a1p + (kb + 1) * 8);
         }
-        const f32x4 wv = wq[kb & 3];
-        if (kb + 4 < 16) wq[kb & 3] = wp[(kb + 4) * 64];
+        const f32x4 wv = wq[kb % RING];
+        if (kb + RING < 16) wq[kb % RING] = wp[(kb + RING) * 64];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             acc0 = mfma32(a0[t], wv[t], acc0);
