@@ -171,3 +171,11 @@ def test_training_entries_validate_arguments():
         T = (N + 63) // 64
         assert 1 <= lib.pngpd_trunk_splits(B, N, 0) <= T and 1 <= lib.pngpd_trunk_infer_splits(B, N, 0) <= T
     assert lib.pngpd_trunk_splits(64, 750, 0) == 4 and lib.pngpd_trunk_infer_splits(64, 750, 0) == 4
+
+
+def test_probe_entry_validates_arguments():
+    """pngpd_probe_mfma_rate rejects bad descriptors before touching the device (no GPU here)."""
+    from pointnetgpd_amd import _lib
+    lib = _lib.load()
+    for args in [(2, 1, 10, 1, None, None), (0, 3, 10, 1, None, None), (0, 1, 0, 1, None, None), (1, 2, 10, None, None, None)]:
+        assert lib.pngpd_probe_mfma_rate(*args) == 1

@@ -151,3 +151,30 @@ def test_cabi_consumer_train_step_matches_binding(B, N, cuda_device):
         assert abs(h.abs().sum().item() - ab) <= 1e-9 * max(ab, 1e-30) + 1e-12, (n, h.abs().sum().item(), ab)
     assert got["db1"] == (0.0, 0.0) and got["db3"] == (0.0, 0.0)      # conv biases ahead of a train-mode BN
     assert got["dW3"][1] > 0 and got["dT"][1] > 0
+
+
+@pytest.mark.gpu
+def test_probe_mfma_rate_runs_and_counts_flops(cuda_device):
+    """The matrix-rate probe of bench.py's roofline block: launches, reports the FLOPs it executes, and lands in a sane
+    range (a bare fp32 MFMA stream cannot beat the nominal peak and should not be far below it)."""
+    import ctypes
+    import torch
+    from pointnetgpd_amd import _lib
+    lib = _lib.load()
+    cus = torch.cuda.get_device_properties(cuda_device).multi_processor_count
+    sink = torch.empty(512 * 512, device=cuda_device)
+    stream = torch.cuda.current_stream(cuda_device).cuda_stream
+    for dtype, per in ((0, 2 * 32 * 32 * 2), (1, 2 * 32 * 32 * 16)):
+        for wps in (1, 2):
+            flops = ctypes.c_longlong(0)
+            iters = 2000
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for rep in range(2):
+                e0.record()
+                _lib.check(lib.pngpd_probe_mfma_rate(dtype, wps, iters, sink.data_ptr(), ctypes.addressof(flops), stream), "probe")
+                e1.record()
+                torch.cuda.synchronize()
+            assert flops.value == cus * 4 * wps * iters * 8 * per
+            tf = flops.value / (e0.elapsed_time(e1) * 1e-3) / 1e12
+            peak = 157.3 if dtype == 0 else 2500.0
+            assert 0.5 * peak < tf < 1.02 * peak, (dtype, wps, tf)
