@@ -7,6 +7,22 @@
 
 #include "../../include/pngpd.h"
 
+// AddressSanitizer builds (`make asan`): the kernels that run 1024-thread workgroups in the product build get 256-thread
+// workgroups — an instrumented 1024-thread kernel is held to 128 VGPRs and spills ~1,700 registers per lane
+// (profiles/r03_asan.txt); same algorithm, fewer row lanes (the summation order differs from the product build's).
+#if defined(__SANITIZE_ADDRESS__)
+#define PNGPD_ASAN 1
+#elif defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define PNGPD_ASAN 1
+#endif
+#endif
+#ifndef PNGPD_ASAN
+#define PNGPD_ASAN 0
+#endif
+#define PNGPD_RED_RL (PNGPD_ASAN ? 8 : 32)     // row lanes of the 32-column reduction kernels
+#define PNGPD_BN3_RL (PNGPD_ASAN ? 16 : 64)    // row lanes of bn3_bwd_prep_kernel (16 channels per workgroup)
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));

@@ -1082,7 +1082,7 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
 // instead of three, and 2x the workgroups of a 32-channel block).
 // ---------------------------------------------------------------------------------------
 #define BN1D_CW 16
-#define BN1D_RL 64
+#define BN1D_RL (PNGPD_ASAN ? 16 : 64)   // row lanes; the sanitizer build runs 256-thread workgroups (pngpd_common.h)
 #define BN1D_NV 16
 
 __device__ __forceinline__ float bn1d_colsum(float (*red)[BN1D_CW + 1], int cx, int ry, float v) {
@@ -1096,7 +1096,7 @@ __device__ __forceinline__ float bn1d_colsum(float (*red)[BN1D_CW + 1], int cx, 
 }
 
 template <bool REG>
-__global__ __launch_bounds__(1024) void bn1d_fwd_train_kernel(
+__global__ __launch_bounds__(BN1D_CW * BN1D_RL) void bn1d_fwd_train_kernel(
     const float *__restrict__ z, int B, int C, const float *__restrict__ gamma,
     const float *__restrict__ beta, float eps, int relu, float *__restrict__ y,
     float *__restrict__ mean_out, float *__restrict__ var_out,
@@ -1162,7 +1162,7 @@ __global__ __launch_bounds__(1024) void bn1d_fwd_train_kernel(
 
 // dy: gradient wrt the (post-ReLU if relu) output y.  dz, dgamma, dbeta out.
 template <bool REG>
-__global__ __launch_bounds__(1024) void bn1d_bwd_kernel(
+__global__ __launch_bounds__(BN1D_CW * BN1D_RL) void bn1d_bwd_kernel(
     const float *__restrict__ dy, const float *__restrict__ z, const float *__restrict__ y, int B, int C,
     const float *__restrict__ gamma, const float *__restrict__ mean, const float *__restrict__ var,
     float eps, int relu, float *__restrict__ dz, float *__restrict__ dgamma, float *__restrict__ dbeta) {
@@ -1652,10 +1652,10 @@ int pngpd_bn1d_fwd_train(const float *z, int B, int C, const float *gamma, const
     if (!z || !gamma || !beta || !y || !mean || !var || B <= 0 || C <= 0 || (rm && !rv)) return PNGPD_ERR_INVALID_ARG;
     const dim3 grid((C + BN1D_CW - 1) / BN1D_CW);
     if (B <= BN1D_RL * BN1D_NV)
-        hipLaunchKernelGGL(bn1d_fwd_train_kernel<true>, grid, dim3(1024), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(bn1d_fwd_train_kernel<true>, grid, dim3(BN1D_CW * BN1D_RL), 0, (hipStream_t)stream,
                            z, B, C, gamma, beta, eps, relu, y, mean, var, momentum, rm, rv, nbt);
     else
-        hipLaunchKernelGGL(bn1d_fwd_train_kernel<false>, grid, dim3(1024), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(bn1d_fwd_train_kernel<false>, grid, dim3(BN1D_CW * BN1D_RL), 0, (hipStream_t)stream,
                            z, B, C, gamma, beta, eps, relu, y, mean, var, momentum, rm, rv, nbt);
     return pngpd_launch_status();
 }
@@ -1667,10 +1667,10 @@ int pngpd_bn1d_bwd(const float *dy, const float *z, const float *y, int B, int C
         return PNGPD_ERR_INVALID_ARG;
     const dim3 grid((C + BN1D_CW - 1) / BN1D_CW);
     if (B <= BN1D_RL * BN1D_NV)
-        hipLaunchKernelGGL(bn1d_bwd_kernel<true>, grid, dim3(1024), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(bn1d_bwd_kernel<true>, grid, dim3(BN1D_CW * BN1D_RL), 0, (hipStream_t)stream,
                            dy, z, y, B, C, gamma, mean, var, eps, relu, dz, dgamma, dbeta);
     else
-        hipLaunchKernelGGL(bn1d_bwd_kernel<false>, grid, dim3(1024), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(bn1d_bwd_kernel<false>, grid, dim3(BN1D_CW * BN1D_RL), 0, (hipStream_t)stream,
                            dy, z, y, B, C, gamma, mean, var, eps, relu, dz, dgamma, dbeta);
     return pngpd_launch_status();
 }

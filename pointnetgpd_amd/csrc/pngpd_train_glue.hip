@@ -198,18 +198,18 @@ __global__ __launch_bounds__(NT) void pool_finalize_kernel(
 //   d = dp (masked by pooled>0 if relu_last);  dbe3 = sum_b d;  dg3 = sum_b d*zhat
 //   coef[b][c] = d * g3/sig3 ;  m12 f64 = m1[1024] (= dbe3/M), m2[1024] (= dg3/M)
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void bn3_bwd_prep_kernel(
+__global__ __launch_bounds__(16 * PNGPD_BN3_RL) void bn3_bwd_prep_kernel(
     const float *__restrict__ dp, const float *__restrict__ pooled, const float *__restrict__ zhat, int B,
     double M, const float *__restrict__ g3, const double *__restrict__ stats, double eps, int relu_last,
     float *__restrict__ coef, float *__restrict__ dg3, float *__restrict__ dbe3, double *__restrict__ m12) {
     // block = 16 channels x 64 row lanes (64 workgroups); the row loop is unrolled so that 8 rows' loads are in flight
-    __shared__ double r1[64][17], r2[64][17];
+    __shared__ double r1[PNGPD_BN3_RL][17], r2[PNGPD_BN3_RL][17];
     const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cx;
     const double s3 = (double)g3[c] / sqrt(stats[1024 + c] + eps);
     double a1 = 0.0, a2 = 0.0;
 #pragma unroll 8
-    for (int b = ry; b < B; b += 64) {
+    for (int b = ry; b < B; b += PNGPD_BN3_RL) {
         const size_t i = (size_t)b * 1024 + c;
         float d = dp[i];
         if (relu_last && !(pooled[i] > 0.f)) d = 0.f;
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(1024) void bn3_bwd_prep_kernel(
     if (ry == 0) {
         double t1 = 0.0, t2 = 0.0;
 #pragma unroll 8
-        for (int i = 0; i < 64; ++i) { t1 += r1[i][cx]; t2 += r2[i][cx]; }
+        for (int i = 0; i < PNGPD_BN3_RL; ++i) { t1 += r1[i][cx]; t2 += r2[i][cx]; }
         dbe3[c] = (float)t1;
         dg3[c] = (float)t2;
         m12[c] = t1 / M;
@@ -232,22 +232,22 @@ __global__ __launch_bounds__(1024) void bn3_bwd_prep_kernel(
 
 // out[o][j] = sum_r in[o][r][j]   (fp32 partials -> fp64), deterministic order.
 // block = 32 columns x 32 row-lanes (rows strided by 32, then a fixed-order LDS tree over the lanes).
-__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float *__restrict__ in, int R, int n,
+__global__ __launch_bounds__(32 * PNGPD_RED_RL) void reduce_partials_kernel(const float *__restrict__ in, int R, int n,
                                                               double *__restrict__ out) {
-    __shared__ double red[32][33];
+    __shared__ double red[PNGPD_RED_RL][33];
     const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
     const int j = blockIdx.x * 32 + cx;
     double s = 0.0;
     if (j < n) {
         const float *p = in + (size_t)blockIdx.y * R * n + j;
-        for (int r = ry; r < R; r += 32) s += (double)p[(size_t)r * n];
+        for (int r = ry; r < R; r += PNGPD_RED_RL) s += (double)p[(size_t)r * n];
     }
     red[ry][cx] = s;
     __syncthreads();
     if (ry == 0 && j < n) {
         double t = 0.0;
 #pragma unroll
-        for (int i = 0; i < 32; ++i) t += red[i][cx];
+        for (int i = 0; i < PNGPD_RED_RL; ++i) t += red[i][cx];
         out[(size_t)blockIdx.y * n + j] = t;
     }
 }
@@ -257,8 +257,8 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float *__re
 struct ReduceSeg { const float *in; double *out; int outer, R, n, blocks_per_outer; };
 struct ReduceSegs { ReduceSeg seg[4]; int first[5]; };
 
-__global__ __launch_bounds__(1024) void reduce_partials_multi_kernel(ReduceSegs A) {
-    __shared__ double red[32][33];
+__global__ __launch_bounds__(32 * PNGPD_RED_RL) void reduce_partials_multi_kernel(ReduceSegs A) {
+    __shared__ double red[PNGPD_RED_RL][33];
     int g = 0;
 #pragma unroll
     for (int i = 1; i < 4; ++i) g += ((int)blockIdx.x >= A.first[i]) ? 1 : 0;
@@ -270,14 +270,14 @@ __global__ __launch_bounds__(1024) void reduce_partials_multi_kernel(ReduceSegs 
     double s = 0.0;
     if (j < sg.n) {
         const float *p = sg.in + (size_t)o * sg.R * sg.n + j;
-        for (int r = ry; r < sg.R; r += 32) s += (double)p[(size_t)r * sg.n];
+        for (int r = ry; r < sg.R; r += PNGPD_RED_RL) s += (double)p[(size_t)r * sg.n];
     }
     red[ry][cx] = s;
     __syncthreads();
     if (ry == 0 && j < sg.n) {
         double t = 0.0;
 #pragma unroll
-        for (int i = 0; i < 32; ++i) t += red[i][cx];
+        for (int i = 0; i < PNGPD_RED_RL; ++i) t += red[i][cx];
         sg.out[(size_t)o * sg.n + j] = t;
     }
 }
@@ -312,16 +312,17 @@ __device__ __forceinline__ double s2_at(const double *__restrict__ S2c, int k, i
 // 512 threads = 4 row blocks a (k = 32 a + i) x 128 columns j: every thread walks ONE 32x32 block of S2 (32 dependent
 // loads instead of 128 — the kernel is a latency chain at two waves per CU otherwise: 31 us -> 10 us), the four partial
 // dot products of a column meet in LDS in fixed order.
-__global__ __launch_bounds__(512) void dw3_finalize_kernel(
+#define DW3_KQ (PNGPD_ASAN ? 1 : 4)   // k-quarters walked concurrently (sanitizer build: 128-thread workgroups)
+__global__ __launch_bounds__(128 * DW3_KQ) void dw3_finalize_kernel(
     const double *__restrict__ G, const double *__restrict__ S2c, const double *__restrict__ sh, double M,
     const float *__restrict__ w3, const float *__restrict__ g3, const double *__restrict__ stats,
     const double *__restrict__ m12, double eps, float *__restrict__ dW3) {
     __shared__ double wrow[DW3_CPB][128];
     __shared__ double red[DW3_CPB][128];
     __shared__ double part[4][DW3_CPB][128];
-    const int c0 = blockIdx.x * DW3_CPB, j = threadIdx.x & 127, a = threadIdx.x >> 7;
+    const int c0 = blockIdx.x * DW3_CPB, j = threadIdx.x & 127, aq = threadIdx.x >> 7;
     const double shj = sh[j];
-    if (a == 0) {
+    if (aq == 0) {
 #pragma unroll
         for (int u = 0; u < DW3_CPB; ++u) {
             wrow[u][j] = (double)w3[(size_t)(c0 + u) * 128 + j];
@@ -330,17 +331,17 @@ __global__ __launch_bounds__(512) void dw3_finalize_kernel(
     }
     __syncthreads();
     for (int s = 64; s > 0; s >>= 1) {
-        if (a == 0 && j < s) {
+        if (aq == 0 && j < s) {
 #pragma unroll
             for (int u = 0; u < DW3_CPB; ++u) red[u][j] += red[u][j + s];
         }
         __syncthreads();
     }
-    double dot[DW3_CPB];
-#pragma unroll
-    for (int u = 0; u < DW3_CPB; ++u) dot[u] = 0.0;
     const int bb = j >> 5, jj = j & 31;
-    {          // rows k = 32 a + i of column j: block (a, bb) of S2
+    for (int a = aq; a < 4; a += DW3_KQ) {          // rows k = 32 a + i of column j: block (a, bb) of S2
+        double dot[DW3_CPB];
+#pragma unroll
+        for (int u = 0; u < DW3_CPB; ++u) dot[u] = 0.0;
         const int d = (bb - a) & 3;
         const bool tr = d == 3 || (d == 2 && a >= 2);          // stored as the transposed block (bb, a)
         const int ra = tr ? bb : a, q = tr ? ((a - bb) & 3) : d;
@@ -356,11 +357,11 @@ __global__ __launch_bounds__(512) void dw3_finalize_kernel(
 #pragma unroll
             for (int u = 0; u < DW3_CPB; ++u) dot[u] = fma(wrow[u][a * 32 + i], v, dot[u]);
         }
-    }
 #pragma unroll
-    for (int u = 0; u < DW3_CPB; ++u) part[a][u][j] = dot[u];
+        for (int u = 0; u < DW3_CPB; ++u) part[a][u][j] = dot[u];
+    }
     __syncthreads();
-    if (a == 0) {
+    if (aq == 0) {
 #pragma unroll
         for (int u = 0; u < DW3_CPB; ++u) {
             const int c = c0 + u;
@@ -524,8 +525,8 @@ __global__ __launch_bounds__(64) void dtrans_finalize_kernel(
 //   RF_ZERO          no input: f0[64] = f1[128] = f2[1024] = 0 (the exactly-zero gradients of conv biases ahead of a
 //                    train-mode BatchNorm)
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void reduce_fin_kernel(RFArgs A) {
-    __shared__ double red[32][33];
+__global__ __launch_bounds__(32 * PNGPD_RED_RL) void reduce_fin_kernel(RFArgs A) {
+    __shared__ double red[PNGPD_RED_RL][33];
     __shared__ double tot[32];
     int g = 0;
 #pragma unroll
@@ -549,7 +550,7 @@ __global__ __launch_bounds__(1024) void reduce_fin_kernel(RFArgs A) {
         double s = 0.0;
         if (j < sg.n) {
             const float *p = sg.in + (size_t)o * sg.R * stride + (size_t)pl * sg.n + j;
-            for (int r = ry; r < sg.R; r += 32) s += (double)p[(size_t)r * stride];
+            for (int r = ry; r < sg.R; r += PNGPD_RED_RL) s += (double)p[(size_t)r * stride];
         }
         if (pl) __syncthreads();
         red[ry][cx] = s;
@@ -557,7 +558,7 @@ __global__ __launch_bounds__(1024) void reduce_fin_kernel(RFArgs A) {
         if (ry == 0) {
             double a = 0.0;
 #pragma unroll
-            for (int i = 0; i < 32; ++i) a += red[i][cx];
+            for (int i = 0; i < PNGPD_RED_RL; ++i) a += red[i][cx];
             t[pl] = a;
         }
     }
@@ -594,7 +595,7 @@ int pngpd_reduce_fin_launch(RFArgs &A, int nseg, void *stream) {
     }
     A.first[4] = total;
     if (total == 0) return PNGPD_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(reduce_fin_kernel, dim3(total), dim3(1024), 0, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(reduce_fin_kernel, dim3(total), dim3(32 * PNGPD_RED_RL), 0, (hipStream_t)stream, A);
     return pngpd_launch_status();
 }
 
@@ -742,13 +743,13 @@ int pngpd_bn3_bwd_prep(const float *dp, const float *pooled, const float *zhat, 
                        double *m12, void *stream) {
     if (!dp || !pooled || !zhat || !g3 || !stats || !coef || !dg3 || !dbe3 || !m12 || B <= 0 || N <= 0)
         return PNGPD_ERR_INVALID_ARG;
-    LAUNCH(bn3_bwd_prep_kernel, dim3(64), dim3(1024), dp, pooled, zhat, B, (double)B * N, g3, stats,
+    LAUNCH(bn3_bwd_prep_kernel, dim3(64), dim3(16 * PNGPD_BN3_RL), dp, pooled, zhat, B, (double)B * N, g3, stats,
            (double)eps, relu_last, coef, dg3, dbe3, m12);
 }
 
 int pngpd_reduce_partials(const float *in, int outer, int R, int n, double *out, void *stream) {
     if (!in || !out || outer <= 0 || R <= 0 || n <= 0) return PNGPD_ERR_INVALID_ARG;
-    LAUNCH(reduce_partials_kernel, dim3((n + 31) / 32, outer), dim3(1024), in, R, n, out);
+    LAUNCH(reduce_partials_kernel, dim3((n + 31) / 32, outer), dim3(32 * PNGPD_RED_RL), in, R, n, out);
 }
 
 int pngpd_reduce_partials4(const float *in0, int outer0, int R0, int n0, double *out0,
@@ -772,7 +773,7 @@ int pngpd_reduce_partials4(const float *in0, int outer0, int R0, int n0, double 
     }
     A.first[4] = total;
     if (total == 0) return PNGPD_ERR_INVALID_ARG;
-    LAUNCH(reduce_partials_multi_kernel, dim3(total), dim3(1024), A);
+    LAUNCH(reduce_partials_multi_kernel, dim3(total), dim3(32 * PNGPD_RED_RL), A);
 }
 
 int pngpd_a_cvec_finalize(const double *sh, int B, int N, const float *w3, const float *g3, const double *stats,
@@ -787,7 +788,7 @@ int pngpd_dw3_finalize(const double *G, const double *S2c, const double *sh, int
                        void *stream) {
     if (!G || !S2c || !sh || !w3 || !g3 || !stats || !m12 || !dW3 || B <= 0 || N <= 0)
         return PNGPD_ERR_INVALID_ARG;
-    LAUNCH(dw3_finalize_kernel, dim3(1024 / DW3_CPB), dim3(512), G, S2c, sh, (double)B * N, w3, g3, stats, m12,
+    LAUNCH(dw3_finalize_kernel, dim3(1024 / DW3_CPB), dim3(128 * DW3_KQ), G, S2c, sh, (double)B * N, w3, g3, stats, m12,
            (double)eps, dW3);
 }
 
