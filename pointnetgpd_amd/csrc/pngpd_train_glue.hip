@@ -240,6 +240,7 @@ __global__ __launch_bounds__(32 * PNGPD_RED_RL) void reduce_partials_kernel(cons
     double s = 0.0;
     if (j < n) {
         const float *p = in + (size_t)blockIdx.y * R * n + j;
+        #pragma unroll 8   // eight rows' loads in flight per thread: the kernel is a latency chain otherwise (2-3 TB/s)
         for (int r = ry; r < R; r += PNGPD_RED_RL) s += (double)p[(size_t)r * n];
     }
     red[ry][cx] = s;
@@ -270,6 +271,7 @@ __global__ __launch_bounds__(32 * PNGPD_RED_RL) void reduce_partials_multi_kerne
     double s = 0.0;
     if (j < sg.n) {
         const float *p = sg.in + (size_t)o * sg.R * sg.n + j;
+        #pragma unroll 8   // eight rows' loads in flight per thread: the kernel is a latency chain otherwise (2-3 TB/s)
         for (int r = ry; r < sg.R; r += PNGPD_RED_RL) s += (double)p[(size_t)r * sg.n];
     }
     red[ry][cx] = s;
@@ -550,6 +552,7 @@ __global__ __launch_bounds__(32 * PNGPD_RED_RL) void reduce_fin_kernel(RFArgs A)
         double s = 0.0;
         if (j < sg.n) {
             const float *p = sg.in + (size_t)o * sg.R * stride + (size_t)pl * sg.n + j;
+            #pragma unroll 8   // eight rows' loads in flight per thread: the kernel is a latency chain otherwise (2-3 TB/s)
             for (int r = ry; r < sg.R; r += PNGPD_RED_RL) s += (double)p[(size_t)r * stride];
         }
         if (pl) __syncthreads();
