@@ -63,8 +63,8 @@ __device__ __forceinline__ L1C load_l1c(const float *__restrict__ w1, const floa
 }
 
 // (The affine / plain variants are two loops: a per-element select on k.affine costs a VALU instruction per activation.
-// Packed FMAs on point pairs were measured and are SLOWER here — four dependent v_pk_fma_f32 per pair with a wait state
-// each against two interleaved scalar chains: gather pass 0.151 -> 0.183 ms.)
+// Packed FMAs on point pairs were measured and are not faster here — four dependent v_pk_fma_f32 per pair with a wait
+// state each against two interleaved scalar chains: pass B +3 %.)
 template <bool AFF>
 __device__ __forceinline__ void layer1_rows(const float *xs, const L1C &k, float *dst, int p0) {
 #pragma unroll
