@@ -199,9 +199,8 @@ class _RefPathPickler(pickle._Pickler):
             self.memoize(obj)
             return
         return super().save_global(obj, name)
-
-    dispatch = dict(pickle._Pickler.dispatch)
-    dispatch[type] = save_global
+    # no ``dispatch`` override: pickle._Pickler.save_type (which special-cases NoneType / NotImplementedType /
+    # ellipsis) already ends in ``self.save_global`` for every other class, i.e. in the method above
 
 
 class _RefPathPickleModule:
@@ -210,18 +209,21 @@ class _RefPathPickleModule:
     Pickler = _RefPathPickler
 
 
-def save_model(model, path):
+def save_model(model, path, world=1):
     """Whole-module pickle like the reference's ``torch.save(model, path)`` (main_1v.py:177-178), written so that BOTH
     implementations can load it: the classes are pickled under the reference's module path ``model.pointnet`` (which
     ``install_reference_aliases`` maps to this package on load, and which IS the reference's own module in its
     scripts — kinect2grasp.py / main_test.py); the per-instance cache of folded inference weights is never pickled.
-    A failure is reported, not raised: only rank 0 saves, and an exception here would strand the other ranks at the
-    next barrier."""
+    Single process: a failure raises, as the reference's ``torch.save`` does.  ``world > 1``: only rank 0 saves and an
+    exception here would strand the other ranks in their next collective, so the failure is reported and returned
+    (False) — ``run()`` broadcasts the flag and every rank aborts together."""
     try:
         torch.save(model, path, pickle_module=_RefPathPickleModule)   # _HipModule.__getstate__ drops the fold cache
         return True
     except Exception as e:      # noqa: BLE001
-        print(f"WARNING: could not save {path}: {type(e).__name__}: {e}")
+        if world <= 1:
+            raise
+        print(f"ERROR: could not save {path}: {type(e).__name__}: {e}")
         return False
 
 
@@ -387,6 +389,7 @@ def run(variant, argv=None):
             if rank == 0:
                 print("Train done, acc={}".format(acc_train))
             acc, loss = test()
+            saved = True
             if rank == 0:
                 print("Test done, acc={}, loss={}".format(acc, loss))
                 logger.add_scalar("train_acc", acc_train, epoch)
@@ -394,8 +397,15 @@ def run(variant, argv=None):
                 logger.add_scalar("test_loss", loss, epoch)
                 if epoch % args.save_interval == 0:
                     path = os.path.join(args.model_path, args.tag + "_{}.model".format(epoch))
-                    save_model(model, path)
-                    print("Save model @ {}".format(path))
+                    saved = save_model(model, path, world)
+                    if saved:
+                        print("Save model @ {}".format(path))
+            if world > 1 and epoch % args.save_interval == 0:
+                # a failed checkpoint ends the run on EVERY rank (rank 0 alone raising would hang the others)
+                flag = torch.tensor([1.0 if saved else 0.0], device=device)
+                torch.distributed.broadcast(flag, src=0)
+                if flag.item() == 0.0:
+                    raise RuntimeError("checkpoint could not be written on rank 0 (see its log); aborting all ranks")
             result = dict(train_acc=acc_train, test_acc=acc, test_loss=loss, epoch=epoch)
     else:
         print("testing...")

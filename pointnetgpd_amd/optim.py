@@ -16,9 +16,46 @@ The update is torch's single-tensor Adam in fp32 (torch/optim/adam.py ``_single_
 ``state`` entries (``step``, ``exp_avg``, ``exp_avg_sq``) are views of the flat moments, so ``state_dict()`` has the
 layout of ``torch.optim.Adam``'s and checkpoints move between the two.
 """
+import weakref
+
 import torch
+from torch.utils.weak import WeakIdKeyDictionary
 
 from . import _lib
+
+# parameter -> (gradient view, weakref to the owning FlatAdam, index in its parameter list).  Kept HERE and not as an
+# attribute of the Parameter: instance attributes of a Parameter are pickled with it (a whole-module checkpoint would
+# carry a second 6.4 MB buffer and come back with an orphaned view), and a registry entry dies with its optimizer.
+_GRAD_VIEWS = WeakIdKeyDictionary()
+
+
+def grad_view(param):
+    """The flat-buffer gradient view the fused backward may write for ``param`` in place, or None: only while the
+    owning FlatAdam is alive AND ``param.grad`` still IS that view (a ``zero_grad(set_to_none=True)`` of the module, a
+    foreign optimizer, or a checkpoint round trip all break the identity and fall back to autograd's accumulation)."""
+    e = _GRAD_VIEWS.get(param)
+    if e is None:
+        return None
+    view, owner, _ = e
+    if owner() is None or param.grad is not view:
+        return None
+    return view
+
+
+def mark_written(params):
+    """Called by the fused backward after it has written the gradient slices of ``params`` in place."""
+    for p in params:
+        e = _GRAD_VIEWS.get(p)
+        if e is None:
+            continue
+        opt = e[1]()
+        if opt is None:
+            continue
+        if opt._written[e[2]]:
+            raise RuntimeError("FlatAdam: a gradient slice was written twice before step() — the fused backward "
+                               "OVERWRITES gradients (no accumulation over micro-batches or repeated module calls); "
+                               "use train.set_sequencing('passes') or torch.optim.Adam for accumulation")
+        opt._written[e[2]] = 1
 
 
 class FlatAdam(torch.optim.Optimizer):
@@ -44,6 +81,8 @@ class FlatAdam(torch.optim.Optimizer):
         # device-resident step count / learning rate for captured graphs (StepLR rewrites group["lr"] in place)
         self.step_dev = torch.zeros((), device=dev, dtype=torch.float32) if capturable else None
         self._step = 0
+        self._views = []
+        self._written = bytearray(len(ps))    # per parameter: slice written in place by the fused backward this step
         with torch.no_grad():
             for p, o in zip(ps, self.offsets):
                 n = p.numel()
@@ -51,7 +90,8 @@ class FlatAdam(torch.optim.Optimizer):
                 p.data = self.flat_p[o:o + n].view(p.shape)
                 gv = self.flat_g[o:o + n].view(p.shape)
                 p.grad = gv
-                p._pngpd_grad = gv
+                _GRAD_VIEWS[p] = (gv, weakref.ref(self), len(self._views))
+                self._views.append(gv)
                 self.state[p] = {"step": torch.tensor(0.0),
                                  "exp_avg": self.flat_m[o:o + n].view(p.shape),
                                  "exp_avg_sq": self.flat_v[o:o + n].view(p.shape)}
@@ -67,13 +107,37 @@ class FlatAdam(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none=True):
         """The fused backward OVERWRITES every gradient slice, so nothing is cleared (and the views are never
-        dropped); with pass-by-pass / ATen sequencing autograd accumulates into the views, which then need zeros."""
+        dropped); with pass-by-pass / ATen sequencing autograd accumulates into the views, which then need zeros.
+        Slices the fused backward did NOT write in a step (a sub-module that took no part in it) are zeroed by
+        ``step()`` itself, and a slice written twice raises (``mark_written``): no stale or half-accumulated gradient
+        reaches the update."""
         from . import train
+        for p, gv in zip(self._params, self._views):
+            if p.grad is not gv:
+                p.grad = gv
+        self._written[:] = bytes(len(self._written))
         if train._use_fused():
             return
-        for p in self._params:
-            p.grad = p._pngpd_grad
         self.flat_g.zero_()
+
+    def _settle_gradients(self):
+        """Before the update: every parameter's gradient must be IN its slice.  A gradient autograd left elsewhere
+        (``.grad`` re-pointed or dropped by foreign code) is copied in / zeroed; in fused sequencing a slice nobody
+        wrote this step is zeroed (torch.optim.Adam would skip a ``None`` gradient; with zero gradient Adam's moments
+        still decay — the same update torch makes for a zero ``.grad``)."""
+        from . import train
+        fused = train._use_fused()
+        for i, (p, gv) in enumerate(zip(self._params, self._views)):
+            g = p.grad
+            if g is not gv:
+                if g is None:
+                    gv.zero_()
+                else:
+                    gv.copy_(g)
+                p.grad = gv
+            elif fused and not self._written[i] and any(self._written):
+                gv.zero_()
+        self._written[:] = bytes(len(self._written))
 
     # ---- update ----------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -90,6 +154,7 @@ class FlatAdam(torch.optim.Optimizer):
         stream = torch.cuda.current_stream(self.device).cuda_stream
         lr_dev = lr.data_ptr() if torch.is_tensor(lr) and lr.is_cuda else None
         lr_host = 0.0 if lr_dev else float(lr)
+        self._settle_gradients()
         self._step += 1
         with _lib.device_guard(self.device):
             if self.step_dev is not None:
@@ -107,8 +172,11 @@ class FlatAdam(torch.optim.Optimizer):
 
     # ---- checkpoints (torch.optim.Adam layout) ------------------------------------------------------------------
     def state_dict(self):
+        # a captured graph (train.GraphedTrainStep) advances only the device-resident counter: it is the truth then
+        step = float(self.step_dev.item()) if self.step_dev is not None else float(self._step)
+        self._step = int(step)
         for p in self._params:
-            self.state[p]["step"] = torch.tensor(float(self._step))
+            self.state[p]["step"] = torch.tensor(step)
         return super().state_dict()
 
     def load_state_dict(self, state_dict):
@@ -126,5 +194,10 @@ class FlatAdam(torch.optim.Optimizer):
             self.step_dev.fill_(float(self._step))
         for g, sg in zip(self.param_groups, state_dict["param_groups"]):
             for k, v in sg.items():
-                if k != "params":
+                if k == "params":
+                    continue
+                if k == "lr" and torch.is_tensor(g.get("lr")):
+                    # a capturable optimizer's lr is a device tensor a captured graph reads: fill it, never replace it
+                    g["lr"].fill_(float(v))
+                else:
                     g[k] = v

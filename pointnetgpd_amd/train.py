@@ -347,8 +347,10 @@ def _dp(t):
 
 
 def _grad_out(param):
-    """The persistent gradient view a flat optimizer (optim.FlatAdam) registered on ``param``, or None."""
-    return getattr(param, "_pngpd_grad", None)
+    """The persistent gradient view a LIVE flat optimizer (optim.FlatAdam) holds for ``param`` — only while
+    ``param.grad`` still is that view — or None (the backward then returns gradients through autograd)."""
+    from .optim import grad_view
+    return grad_view(param)
 
 
 class FusedTrunkFn(torch.autograd.Function):
@@ -432,6 +434,8 @@ class FusedTrunkFn(torch.autograd.Function):
         a.scratch, a.scratch_bytes = ws.data_ptr(), ctx.sizes[1]
         _ccall("pngpd_trunk_train_bwd", a, dev)
         if views is None:
+            _mark_written(ctx.grad_outs)
+        if views is None:
             grads = (None,) * 12
         else:
             v = views
@@ -497,6 +501,8 @@ class FusedHeadFn(torch.autograd.Function):
         ws = ops._workspace(dev, ctx.sizes[1])
         a.scratch, a.scratch_bytes = ws.data_ptr(), ctx.sizes[1]
         _ccall("pngpd_head_train_bwd", a, dev)
+        if views is None:
+            _mark_written(ctx.grad_outs)
         grads = (None,) * 10 if views is None else tuple(views)
         return (dinp,) + grads + (None,) * 6
 
@@ -509,9 +515,28 @@ def _use_fused():
     return _SEQUENCING == "fused" and DEBUG_STASH is None
 
 
+class _GradOuts(list):
+    """The in-place gradient targets of one fused piece: the flat optimizer's views, plus the parameters they belong to
+    (``optim.mark_written`` records the write so that FlatAdam.step() can tell stale slices from fresh ones)."""
+    params = ()
+
+
 def _grad_outs(params):
     outs = [_grad_out(p) for p in params]
-    return outs if all(o is not None for o in outs) else None
+    have = sum(o is not None for o in outs)
+    if have == 0:
+        return None
+    if have != len(outs):
+        raise RuntimeError("optim.FlatAdam must own all parameters of a trunk / FC stack or none of them "
+                           "(the fused backward writes the whole piece's gradients in place)")
+    g = _GradOuts(outs)
+    g.params = tuple(params)
+    return g
+
+
+def _mark_written(grad_outs):
+    from .optim import mark_written
+    mark_written(grad_outs.params)
 
 
 def trunk_train(mod, x, trans, relu_last):

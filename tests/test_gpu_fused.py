@@ -86,6 +86,7 @@ def test_flat_adam_matches_torch_adam(cuda_device):
 def test_flat_adam_training_step_overwrites_flat_gradients(cuda_device):
     """With FlatAdam attached the fused backward writes every gradient into its slice of ONE buffer (bit-identical to
     the autograd-returned gradients), zero_grad is a no-op, and an eval forward after step() sees the new weights."""
+    from pointnetgpd_amd import optim
     from pointnetgpd_amd.optim import FlatAdam
     B, N, k = 16, 750, 2
     m = build_model(N, k, 42, 3500).to(cuda_device)
@@ -106,7 +107,7 @@ def test_flat_adam_training_step_overwrites_flat_gradients(cuda_device):
         F.nll_loss(logp, y).backward()
         if it == 0:
             for n, p in m.named_parameters():
-                assert p.grad.data_ptr() == p._pngpd_grad.data_ptr(), n
+                assert p.grad is optim.grad_view(p), n
                 assert torch.equal(p.grad, ref[3][n]), n
         opt.step()
         lt, _ = mt(x)
@@ -123,6 +124,113 @@ def test_flat_adam_training_step_overwrites_flat_gradients(cuda_device):
     with torch.no_grad():
         after = m(x)[0]
     assert (after - before).abs().max().item() > 1e-4      # the fold cache saw the in-place update
+
+
+def test_flat_adam_checkpoint_round_trip_then_foreign_optimizer(cuda_device, tmp_path):
+    """the flat gradient views live in the optimizer, not on the Parameters.  A whole-module
+    checkpoint of a FlatAdam-trained model is one 6.4 MB storage (no pickled gradient buffer, plain
+    ``_rebuild_parameter``), and the loaded model — or the same model after its FlatAdam was replaced by
+    torch.optim.Adam — trains: the fused backward returns gradients through autograd, ``p.grad`` is set, parameters move."""
+    import gc
+    import os
+    from pointnetgpd_amd import mains, optim, install_reference_aliases
+    from pointnetgpd_amd.optim import FlatAdam
+    B, N, k = 8, 128, 2
+    m = build_model(N, k, 43, 3501).to(cuda_device).train()
+    x = synth_cloud(B, N, 703, "box").to(cuda_device)
+    y = (torch.arange(B) % k).long().to(cuda_device)
+    opt = FlatAdam(m.parameters(), lr=0.005)
+    opt.zero_grad(); F.nll_loss(m(x)[0], y).backward(); opt.step()
+    assert not any("_pngpd" in a for p in m.parameters() for a in vars(p))
+    path = str(tmp_path / "flat.model")
+    mains.save_model(m, path)
+    assert os.path.getsize(path) < 7.5e6, os.path.getsize(path)          # parameters + buffers, not twice that
+    install_reference_aliases()
+    back = torch.load(path, map_location=cuda_device, weights_only=False).train()
+    for p in back.parameters():
+        assert optim.grad_view(p) is None and p.grad is None
+    tor = torch.optim.Adam(back.parameters(), lr=0.005)
+    w0 = {n: p.detach().clone() for n, p in back.named_parameters()}
+    tor.zero_grad(); F.nll_loss(back(x)[0], y).backward()
+    assert all(p.grad is not None for p in back.parameters())
+    tor.step()
+    assert any((p.detach() - w0[n]).abs().max().item() > 1e-4 for n, p in back.named_parameters())
+    # the ORIGINAL model with its FlatAdam dropped and a torch optimizer in its place
+    ref_g = {n: p.grad.detach().clone() for n, p in back.named_parameters()}
+    del opt
+    gc.collect()
+    for p in m.parameters():
+        assert optim.grad_view(p) is None                 # the registry entry died with the optimizer
+    tor2 = torch.optim.Adam(m.parameters(), lr=0.005)
+    tor2.zero_grad(set_to_none=True)
+    w1 = m.fc3.weight.detach().clone()
+    F.nll_loss(m(x)[0], y).backward()
+    assert all(p.grad is not None for p in m.parameters())
+    tor2.step()
+    assert (m.fc3.weight.detach() - w1).abs().max().item() > 1e-5
+    assert set(ref_g) == {n for n, _ in m.named_parameters()}
+
+
+def test_flat_adam_partial_backward_and_double_write(cuda_device):
+    """the fused backward overwrites gradient slices.  (i) A slice written twice before step()
+    raises instead of silently keeping the last contribution; (ii) parameters that took no part in a backward get a
+    ZERO gradient in step(), not the previous step's; (iii) ``p.grad`` dropped by foreign code (``set_to_none``) falls
+    back to autograd and step() picks the gradient up."""
+    from pointnetgpd_amd import optim
+    from pointnetgpd_amd.optim import FlatAdam
+    B, N, k = 8, 128, 2
+    m = build_model(N, k, 44, 3502).to(cuda_device).train()
+    x = synth_cloud(B, N, 704, "box").to(cuda_device)
+    y = (torch.arange(B) % k).long().to(cuda_device)
+    opt = FlatAdam(m.parameters(), lr=0.005)
+    opt.zero_grad(); F.nll_loss(m(x)[0], y).backward()
+    with pytest.raises(RuntimeError, match="written twice"):
+        F.nll_loss(m(x)[0], y).backward()
+    opt.zero_grad()
+    # (ii) only the feature extractor takes part: the head's slices hold the previous gradients and must be zeroed
+    F.nll_loss(m(x)[0], y).backward(); opt.step()
+    head_before = m.fc3.weight.detach().clone()
+    assert m.fc3.weight.grad.abs().max().item() > 0
+    opt2_state = opt.state[m.fc3.weight]["exp_avg"].clone()
+    opt.zero_grad()
+    feat, _ = m.feat(x)
+    feat.square().mean().backward()
+    opt.step()
+    assert m.fc3.weight.grad.abs().max().item() == 0.0
+    # zero gradient: the first moment only decays
+    assert torch.allclose(opt.state[m.fc3.weight]["exp_avg"], 0.9 * opt2_state, rtol=1e-6, atol=0)
+    assert m.fc3.weight.shape == head_before.shape
+    # (iii) gradients dropped by the module's own zero_grad: autograd path, then adopted by step()
+    m.zero_grad(set_to_none=True)
+    assert all(optim.grad_view(p) is None for p in m.parameters())
+    w0 = m.feat.conv3.weight.detach().clone()
+    F.nll_loss(m(x)[0], y).backward()
+    g = m.feat.conv3.weight.grad.detach().clone()
+    opt.step()
+    assert m.feat.conv3.weight.grad is optim.grad_view(m.feat.conv3.weight)
+    assert torch.equal(m.feat.conv3.weight.grad, g)
+    assert (m.feat.conv3.weight.detach() - w0).abs().max().item() > 1e-5
+
+
+def test_flat_adam_state_dict_after_graph_replays(cuda_device):
+    """a captured graph advances only the device-resident step counter — state_dict() reports it; and
+    load_state_dict() FILLS the device lr tensor a captured graph reads instead of replacing it."""
+    from pointnetgpd_amd.optim import FlatAdam
+    from pointnetgpd_amd.train import GraphedTrainStep
+    B, N, k = 8, 128, 2
+    m = build_model(N, k, 45, 3503).to(cuda_device).train()
+    x = synth_cloud(B, N, 705, "box").to(cuda_device)
+    y = (torch.arange(B) % k).long().to(cuda_device)
+    step = GraphedTrainStep(m, B, N, lr=0.005)
+    for _ in range(4):
+        step(x, y)
+    sd = step.optimizer.state_dict()
+    assert {float(v["step"]) for v in sd["state"].values()} == {4.0}
+    lr_t = step.optimizer.param_groups[0]["lr"]
+    sd["param_groups"][0]["lr"] = 0.00125
+    step.optimizer.load_state_dict(sd)
+    assert step.optimizer.param_groups[0]["lr"] is lr_t and abs(lr_t.item() - 0.00125) < 1e-9
+    assert step.optimizer._step == 4 and step.optimizer.step_dev.item() == 4.0
 
 
 def test_struct_sizes_match_header(cuda_device):

@@ -304,3 +304,25 @@ def test_saved_checkpoint_loads_in_the_unmodified_reference(tmp_path):
     assert isinstance(back, PointNetCls)
     with torch.no_grad():
         assert torch.equal(back.eval()(x)[0], lp)
+
+
+def test_save_model_failure_raises_single_process_and_none_type_attribute_pickles(tmp_path):
+    """ADVICE r3 (low x2): a failed checkpoint raises when there is one process (the reference's ``torch.save`` would;
+    silently losing every checkpoint of a run is worse than stopping), is reported + returned under world > 1 (run()
+    broadcasts the flag); and the pickler needs no ``dispatch`` override — a module attribute holding ``type(None)``
+    pickles through pickle's own ``save_type``."""
+    from pointnetgpd_amd import mains
+    from pointnetgpd_amd.model.pointnet import PointNetCls
+    m = PointNetCls(64, 3, 2)
+    bad = str(tmp_path / "no_such_dir" / "x.model")
+    with pytest.raises(Exception):
+        mains.save_model(m, bad)
+    assert mains.save_model(m, bad, world=2) is False
+    m.some_type = type(None)
+    m.other = (type(NotImplemented), type(...))
+    ok = str(tmp_path / "ok.model")
+    assert mains.save_model(m, ok) is True
+    from pointnetgpd_amd import install_reference_aliases
+    install_reference_aliases()
+    back = torch.load(ok, weights_only=False)
+    assert back.some_type is type(None) and back.other == (type(NotImplemented), type(...))
