@@ -167,46 +167,96 @@ def _conv1x1_torch(F, x, w, b):
     return F.conv1d(x, w, b)
 
 
-def _trunk_torch(F, x, sd, prefix, training, relu_last):
+def _trunk_torch(F, x, sd, prefix, training, relu_last, choice=None):
+    """``choice`` (see ``forward_torch``): None = the reference's ops; else ``(idx (B,1024) int64, keep (B,1024)
+    bool or None)`` — the max over N is evaluated AT the given points (a gather) and, for the STN trunk, the ReLU
+    ahead of the max keeps exactly the pooled entries ``keep`` marks."""
     x = F.relu(_bn_torch(F, _conv1x1_torch(F, x, sd[prefix + "conv1.weight"], sd[prefix + "conv1.bias"]),
                          sd, prefix + "bn1", training))
     x = F.relu(_bn_torch(F, _conv1x1_torch(F, x, sd[prefix + "conv2.weight"], sd[prefix + "conv2.bias"]),
                          sd, prefix + "bn2", training))
     x = _bn_torch(F, _conv1x1_torch(F, x, sd[prefix + "conv3.weight"], sd[prefix + "conv3.bias"]),
                   sd, prefix + "bn3", training)
+    if choice is not None:
+        import torch
+        idx, keep = choice
+        g = torch.gather(x, 2, idx.view(idx.shape[0], 1024, 1)).view(-1, 1024)
+        if relu_last:
+            g = g * keep.to(g.dtype)
+        return g
     if relu_last:
         x = F.relu(x)
     n = x.shape[2]
     return F.max_pool1d(x, n).view(-1, 1024)
 
 
-def forward_torch(sd, x, training=False):
+def _relu_choice(F, y, keep):
+    """ReLU, or — with a recorded activation pattern ``keep`` — the linear map that pattern selects."""
+    return F.relu(y) if keep is None else y * keep.to(y.dtype)
+
+
+def forward_torch(sd, x, training=False, choices=None):
     """PointNetCls.forward on the reference's ATen op sequence (pointnet.py:27-45,
     137-154, 189-194).  ``sd`` maps reference names -> tensors (running stats are
-    updated IN PLACE when training, exactly like nn.BatchNorm1d)."""
+    updated IN PLACE when training, exactly like nn.BatchNorm1d).
+
+    ``choices`` (tests only; default None = the reference's own ops): the DISCRETE decisions of another run of the
+    same step — ``{"stn_idx", "stn_keep", "feat_idx", "fc_keep": [4 masks: STN fc1, STN fc2, head fc1, head fc2]}``.
+    With them imposed the network is a smooth function of its inputs (max -> gather at the recorded arg-max points,
+    the five ReLUs that act on single values per sample -> their recorded patterns), so two correct implementations
+    agree to rounding error and a gradient comparison needs no allowance for arg-max / ReLU flips at fp32 near-ties.
+    The per-point ReLUs of trunk layers 1-2 stay the reference's: one flipped (point, channel) entry in 10^8 moves
+    nothing measurable."""
     import torch
     import torch.nn.functional as F
     b = x.shape[0]
-    g = _trunk_torch(F, x, sd, "feat.stn.", training, True)
-    g = F.relu(_bn_torch(F, F.linear(g, sd["feat.stn.fc1.weight"], sd["feat.stn.fc1.bias"]),
-                         sd, "feat.stn.bn4", training))
-    g = F.relu(_bn_torch(F, F.linear(g, sd["feat.stn.fc2.weight"], sd["feat.stn.fc2.bias"]),
-                         sd, "feat.stn.bn5", training))
+    c = choices or {}
+    fk = c.get("fc_keep", [None] * 4)
+    g = _trunk_torch(F, x, sd, "feat.stn.", training, True,
+                     (c["stn_idx"], c["stn_keep"]) if choices else None)
+    g = _relu_choice(F, _bn_torch(F, F.linear(g, sd["feat.stn.fc1.weight"], sd["feat.stn.fc1.bias"]),
+                                  sd, "feat.stn.bn4", training), fk[0])
+    g = _relu_choice(F, _bn_torch(F, F.linear(g, sd["feat.stn.fc2.weight"], sd["feat.stn.fc2.bias"]),
+                                  sd, "feat.stn.bn5", training), fk[1])
     g = F.linear(g, sd["feat.stn.fc3.weight"], sd["feat.stn.fc3.bias"])
     iden = torch.eye(3, dtype=x.dtype, device=x.device).view(1, 9).repeat(b, 1)
     trans = (g + iden).view(-1, 3, 3)
     xt = torch.bmm(x.transpose(2, 1), trans).transpose(2, 1)
-    f = _trunk_torch(F, xt, sd, "feat.", training, False)
-    f = F.relu(_bn_torch(F, F.linear(f, sd["fc1.weight"], sd["fc1.bias"]), sd, "bn1", training))
-    f = F.relu(_bn_torch(F, F.linear(f, sd["fc2.weight"], sd["fc2.bias"]), sd, "bn2", training))
+    f = _trunk_torch(F, xt, sd, "feat.", training, False, (c["feat_idx"], None) if choices else None)
+    f = _relu_choice(F, _bn_torch(F, F.linear(f, sd["fc1.weight"], sd["fc1.bias"]), sd, "bn1", training), fk[2])
+    f = _relu_choice(F, _bn_torch(F, F.linear(f, sd["fc2.weight"], sd["fc2.bias"]), sd, "bn2", training), fk[3])
     logits = F.linear(f, sd["fc3.weight"], sd["fc3.bias"])
     return F.log_softmax(logits, dim=-1), trans
 
 
-def train_step_torch(sd, x, target, dtype=None):
+def head_stack_torch(inp, P, tail, training=True, keep=None):
+    """One FC stack of the reference: ``fc1 -> BatchNorm1d -> ReLU -> fc2 -> BatchNorm1d -> ReLU -> fc3`` followed by
+    ``+ eye(3)`` (STN3d, pointnet.py:35-43; ``tail="iden"``) or ``log_softmax`` (PointNetCls, pointnet.py:191-194;
+    ``tail="log_softmax"``) or nothing.  ``P`` maps ``W1 b1 g1 be1 rm1 rv1 W2 b2 g2 be2 rm2 rv2 W3 b3`` to tensors
+    (running statistics updated in place when training, like nn.BatchNorm1d).  The gradient oracle of the FC-stack
+    training kernels is autograd through this function in fp64.  Returns (out, [y1, y2]) — the two hidden activations
+    are returned so a test can assert that no pre-activation sits near its ReLU threshold."""
+    import torch
+    import torch.nn.functional as F
+    keep = keep or [None, None]
+    z1 = F.linear(inp, P["W1"], P["b1"])
+    a1 = F.batch_norm(z1, P["rm1"], P["rv1"], P["g1"], P["be1"], training, BN_MOMENTUM, BN_EPS)
+    y1 = _relu_choice(F, a1, keep[0])
+    z2 = F.linear(y1, P["W2"], P["b2"])
+    a2 = F.batch_norm(z2, P["rm2"], P["rv2"], P["g2"], P["be2"], training, BN_MOMENTUM, BN_EPS)
+    y2 = _relu_choice(F, a2, keep[1])
+    out = F.linear(y2, P["W3"], P["b3"])
+    if tail == "iden":
+        out = out + torch.eye(3, dtype=out.dtype, device=out.device).view(1, 9)
+    elif tail == "log_softmax":
+        out = F.log_softmax(out, dim=-1)
+    return out, [a1, a2]
+
+
+def train_step_torch(sd, x, target, dtype=None, choices=None):
     """One forward + nll_loss + backward (main_1v.py:72-75) through
     ``forward_torch``.  Returns (loss, logp, trans, grads{name: tensor},
-    new_running_stats{name: tensor}).  ``sd`` is not modified."""
+    new_running_stats{name: tensor}).  ``sd`` is not modified.  ``choices``: see ``forward_torch``."""
     import torch
     import torch.nn.functional as F
     work = {}
@@ -222,7 +272,7 @@ def train_step_torch(sd, x, target, dtype=None):
     xx = x.detach().clone()
     if dtype is not None:
         xx = xx.to(dtype)
-    logp, trans = forward_torch(work, xx, training=True)
+    logp, trans = forward_torch(work, xx, training=True, choices=choices)
     loss = F.nll_loss(logp, target)
     loss.backward()
     grads = {k: work[k].grad.detach() if work[k].grad is not None else torch.zeros_like(work[k])

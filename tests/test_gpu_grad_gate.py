@@ -1,0 +1,99 @@
+"""Whole-model gradient gate at BASELINE.md §4's bar — every one of the 44 parameter gradients within 1e-3 relative of
+the fp64 oracle — at the benched size (configs[1]: B = N = 1024) and at the full-view geometry (configs[3]: N = 4096),
+with NO fp32 yardstick.
+
+The gradient of PointNetCls is a discontinuous function of its inputs: an arg-max of the pool or a ReLU of the FC stacks
+that sits within fp32 round-off of its threshold flips between any two correct fp32 implementations and moves whole
+gradient tensors by percent (tests/test_gpu_train_large.py keeps that flip-AWARE comparison).  Here the comparison is
+made flip-FREE instead: the fp64 oracle (autograd over the reference's op sequence, pointnet.py:27-45,137-154,189-194
+under main_1v.py:72-75, run through ATen on the device) is evaluated with the HIP run's own discrete decisions imposed
+— max over N -> gather at the HIP run's arg-max points, the STN's ReLU-before-max and the four FC ReLUs -> the HIP run's
+activation patterns (``oracle.pointnet_oracle.forward_torch(choices=...)``).  With those fixed both sides evaluate the
+same smooth function and must agree to rounding error.  The forward is NOT excused by this: loss / log-probs / trans
+are also compared with the oracle's own free-running forward."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.helpers import build_model, state_dict_cpu, synth_cloud, oracle_train_step_on_device, capture_choices
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a = a.double().flatten(); b = b.double().flatten()
+    return (a - b).norm().item() / max(b.norm().item(), 1e-300)
+
+
+def _gate(B, N, k, kind, dev, seed):
+    m = build_model(N, k, 310 + seed, 5200 + seed).train()
+    sd = state_dict_cpu(m)
+    x = synth_cloud(B, N, 1800 + seed, kind)
+    y = (torch.arange(B) * 7 % k).long()
+    mg = m.to(dev)
+    xd, yd = x.to(dev), y.to(dev)
+
+    def run():
+        logp, trans = mg(xd)
+        loss = F.nll_loss(logp, yd)
+        loss.backward()
+        return loss.detach(), logp.detach(), trans.detach()
+
+    (loss, logp, trans), ch = capture_choices(run)
+    torch.cuda.synchronize()
+    assert "libpngpd.so" in open("/proc/self/maps").read()
+    grads = {n: p.grad.detach().cpu().clone() for n, p in mg.named_parameters()}
+    # the same step through the fused entries must give the same bits (what the CLI runs)
+    m2 = build_model(N, k, 310 + seed, 5200 + seed).train().to(dev)
+    lp2, _ = m2(xd)
+    F.nll_loss(lp2, yd).backward()
+    for n, p in m2.named_parameters():
+        assert torch.equal(p.grad.cpu(), grads[n]), n
+    del m2, lp2
+    torch.cuda.empty_cache()
+    # free-running oracle forward (no choices): the flip-free quantities
+    loss_f, logp_f, trans_f, _, _ = oracle_train_step_on_device(sd, x, y, torch.float64, dev)
+    assert abs(loss.item() - loss_f.item()) <= 1e-3 * max(1.0, abs(loss_f.item()))
+    assert (logp.cpu() - logp_f).abs().max().item() <= 1e-3 and (trans.cpu() - trans_f).abs().max().item() <= 1e-3
+    # the oracle at the HIP run's discrete decisions
+    loss_r, logp_r, trans_r, g64, _ = oracle_train_step_on_device(sd, x, y, torch.float64, dev, choices=ch)
+    # how many decisions differ from the oracle's own is reported, not asserted (it is what makes the plain
+    # comparison flip-limited); the imposed evaluation must still reproduce the forward
+    assert abs(loss_r.item() - loss_f.item()) <= 1e-5 and (logp_r - logp_f).abs().max().item() <= 1e-4
+    worst, rows = ("", 0.0), []
+    for n, g in grads.items():
+        ref = g64[n]
+        if ".bias" in n and ("conv" in n or n.endswith("fc1.bias") or n.endswith("fc2.bias")):
+            # a bias ahead of a train-mode BatchNorm: exactly zero in exact arithmetic
+            scale = max(v.double().abs().max().item() for v in g64.values())
+            assert ref.double().abs().max().item() <= 1e-9 * max(scale, 1.0), n
+            assert g.abs().max().item() <= 1e-4, (n, g.abs().max().item())
+            continue
+        r = _rel(g, ref)
+        rows.append((n, r))
+        if r > worst[1]:
+            worst = (n, r)
+        assert r <= 1e-3, (n, r)
+    print(f"[gate B={B} N={N} k={k} {kind}] loss {loss.item():.6f} (oracle {loss_f.item():.6f}); "
+          f"worst gradient {worst[0]} rel {worst[1]:.2e}; "
+          + " ".join(f"{n.replace('feat.', 'f.').replace('weight', 'w').replace('bias', 'b')}:{r:.1e}" for n, r in rows))
+
+
+def test_gradient_gate_bench_size(cuda_device):
+    """BASELINE configs[1]: B = N = 1024, the headline's iid box clouds."""
+    free, _ = torch.cuda.mem_get_info()
+    assert free > 150e9, "needs ~100 GB of HBM for the fp64 oracle's activations"
+    _gate(1024, 1024, 2, "box", cuda_device, 1)
+
+
+def test_gradient_gate_fullview_geometry(cuda_device):
+    """BASELINE configs[3]'s geometry (N = 4096, 64 tiles per cloud) at the batch the device-side fp64 oracle holds."""
+    free, _ = torch.cuda.mem_get_info()
+    assert free > 150e9
+    _gate(256, 4096, 2, "box", cuda_device, 2)
+
+
+@pytest.mark.parametrize("B,N,k,kind", [(64, 750, 2, "box"), (128, 1024, 3, "diverse"), (33, 200, 3, "gauss")])
+def test_gradient_gate_small(B, N, k, kind, cuda_device):
+    """The reference's own recipe (B = 64, N = 750), the 3-class variants, ragged tiles."""
+    _gate(B, N, k, kind, cuda_device, 3 + B)

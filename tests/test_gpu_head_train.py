@@ -1,0 +1,193 @@
+"""The FC-stack TRAINING kernels alone (VERDICT r3 missing #4): ``pngpd_head_train_fwd/_bwd`` and the per-kernel
+entries ``pngpd_fc_bwd``, ``pngpd_bn1d_fwd_train``, ``pngpd_bn1d_bwd``, ``pngpd_log_softmax_bwd`` against fp64 autograd
+of the reference's op sequence ``Linear -> BatchNorm1d(train) -> ReLU -> Linear -> BatchNorm1d -> ReLU -> Linear
+(+ eye(3) | log_softmax)`` (PointNetGPD/model/pointnet.py:35-43 and :191-194 under main_1v.py:74-75).
+
+Inputs are built so that every pre-ReLU activation is >= 1e-3 away from zero (tests/helpers.head_case): no ReLU can flip
+between the fp32 kernels and the fp64 oracle, so the bars are plain relative errors — every output and every gradient
+<= 1e-4 of the tensor's largest reference entry, running statistics <= 1e-6 — with no fp32 yardstick.  Quantities that
+are exactly zero in exact arithmetic (the bias gradient ahead of a train-mode BatchNorm) are bounded by 2e-6 of the sum
+of the absolute terms they cancel from; at B = 2, where a column's two normalised values are -/+1 up to O(eps / var) and
+every gradient upstream of a BatchNorm is such a residue, the bound is 1e-4 relative + that cancellation floor (and the
+case keeps the two rows >= 0.1 apart in every column — a BatchNorm over two nearly equal values is ill-conditioned in
+any fp32 implementation, the reference's included)."""
+import pytest
+import torch
+
+from oracle import pointnet_oracle as po
+from tests.helpers import head_case, rel_max
+
+pytestmark = pytest.mark.gpu
+
+TAILS = {"iden": 2, "log_softmax": 3, "none": 0}       # ops.EPI_* codes, checked in the test
+
+
+def _unsigned_scales(inp, P, acts, dout, eps=1e-5):
+    """Sums of ABSOLUTE terms behind each gradient (the natural magnitude a cancelling sum's rounding error is
+    proportional to), propagated through the backward with |.| everywhere."""
+    z1 = inp @ P["W1"].t() + P["b1"]
+    s1 = (z1.var(0, unbiased=False) + eps).sqrt()
+    zh1 = (z1 - z1.mean(0)) / s1
+    y1 = acts[0].clamp_min(0)
+    z2 = y1 @ P["W2"].t() + P["b2"]
+    s2 = (z2.var(0, unbiased=False) + eps).sqrt()
+    zh2 = (z2 - z2.mean(0)) / s2
+    y2 = acts[1].clamp_min(0)
+    U = {}
+    g = dout.abs()
+    U["W3"], U["b3"] = g.t() @ y2.abs(), g.sum(0)
+    dy2 = (g @ P["W3"].abs()) * (acts[1] > 0)
+    U["g2"], U["be2"] = (dy2 * zh2.abs()).sum(0), dy2.sum(0)
+    dz2 = (P["g2"].abs() / s2) * (dy2 + dy2.mean(0) + zh2.abs() * (dy2 * zh2.abs()).mean(0))
+    U["W2"], U["b2"] = dz2.t() @ y1.abs(), dz2.sum(0)
+    dy1 = (dz2 @ P["W2"].abs()) * (acts[0] > 0)
+    U["g1"], U["be1"] = (dy1 * zh1.abs()).sum(0), dy1.sum(0)
+    dz1 = (P["g1"].abs() / s1) * (dy1 + dy1.mean(0) + zh1.abs() * (dy1 * zh1.abs()).mean(0))
+    U["W1"], U["b1"] = dz1.t() @ inp.abs(), dz1.sum(0)
+    U["inp"] = dz1 @ P["W1"].abs()
+    return U
+
+
+@pytest.mark.parametrize("tail,k", [("log_softmax", 2), ("log_softmax", 3), ("iden", 9)])
+@pytest.mark.parametrize("B", [2, 33, 512, 1024])
+def test_head_train_entries_vs_fp64_autograd(B, tail, k, cuda_device):
+    from pointnetgpd_amd import ops, train
+    assert (ops.EPI_ADD_IDEN3, ops.EPI_LOG_SOFTMAX, ops.EPI_NONE) == (TAILS["iden"], TAILS["log_softmax"], TAILS["none"])
+    K0, H1, H2 = 1024, 512, 256
+    inp64, P64 = head_case(B, K0, H1, H2, k, seed=9000 + 7 * B + k)
+    # ---- fp64 oracle: autograd through the reference's op sequence
+    leaf = {n: v.clone().requires_grad_(n[:2] not in ("rm", "rv")) for n, v in P64.items()}
+    xin = inp64.clone().requires_grad_(True)
+    out_ref, acts = po.head_stack_torch(xin, leaf, tail, training=True)
+    assert min(a.detach().abs().min().item() for a in acts) >= 1e-3          # no ReLU can flip
+    gen = torch.Generator().manual_seed(77 + B)
+    dout = torch.randn(B, k, generator=gen, dtype=torch.float64)
+    (out_ref * dout).sum().backward()
+    # ---- the kernels: one FusedHeadFn forward / backward (pngpd_head_train_fwd / _bwd)
+    dev = cuda_device
+    f32 = lambda t: t.detach().float().to(dev).contiguous()
+    mk = lambda n: torch.nn.Parameter(f32(P64[n]))
+    W1, b1, g1, be1, W2, b2, g2, be2, W3, b3 = [mk(n) for n in ("W1", "b1", "g1", "be1", "W2", "b2", "g2", "be2", "W3", "b3")]
+    bufs1 = (f32(P64["rm1"]), f32(P64["rv1"]), torch.zeros((), dtype=torch.long, device=dev))
+    bufs2 = (f32(P64["rm2"]), f32(P64["rv2"]), torch.zeros((), dtype=torch.long, device=dev))
+    x = f32(inp64).requires_grad_(True)
+    out = train.FusedHeadFn.apply(x, W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, TAILS[tail], 1e-5, 0.1, bufs1, bufs2, None)
+    (out * f32(dout)).sum().backward()
+    torch.cuda.synchronize()
+    assert "libpngpd.so" in open("/proc/self/maps").read()
+    worst = {}
+    r = rel_max(out, out_ref.detach()); worst["out"] = r
+    assert r <= 1e-4, ("out", r)
+    for (rm, rv, nbt), i in ((bufs1, 1), (bufs2, 2)):
+        for got, name in ((rm, f"rm{i}"), (rv, f"rv{i}")):
+            r = rel_max(got, leaf[name].detach()); worst[name] = r
+            assert r <= 1e-6 * (4 if B == 2 else 1), (name, r)      # B = 2: unbiased var = 2 x a difference of two fp32 values
+        assert int(nbt.item()) == 1
+    U = _unsigned_scales(inp64, P64, [a.detach() for a in acts], dout)
+    got = dict(W1=W1.grad, b1=b1.grad, g1=g1.grad, be1=be1.grad, W2=W2.grad, b2=b2.grad, g2=g2.grad, be2=be2.grad,
+               W3=W3.grad, b3=b3.grad, inp=x.grad)
+    ref = {n: leaf[n].grad for n in got if n != "inp"}; ref["inp"] = xin.grad
+    # b1 / b2 sit ahead of a train-mode BatchNorm: exactly zero in exact arithmetic for every B.  At B = 2 the two
+    # normalised values of a column are -/+ (1 - O(eps / var)), so EVERYTHING upstream of a BatchNorm is a residue
+    # 1e-4..1e-9 of the terms it cancels from: there the bound is relative-or-cancellation.
+    for n, gt in got.items():
+        err = (gt.double().cpu() - ref[n]).abs().max().item()
+        top, u = ref[n].abs().max().item(), U[n].max().item()
+        if n in ("b1", "b2"):
+            assert top <= 1e-9 * u, (n, "oracle not ~0")
+            bound = 2e-6 * u
+        elif B == 2:
+            bound = 1e-4 * top + 2e-6 * u
+        else:
+            bound = 1e-4 * top
+        worst[n] = err / max(top if n not in ("b1", "b2") else u, 1e-300)
+        assert err <= bound, (n, err, bound, top, u)
+    print(f"[head B={B} {tail} k={k}] " + " ".join(f"{n}:{v:.1e}" for n, v in worst.items()))
+
+
+@pytest.mark.parametrize("B,K,Nout", [(2, 1024, 512), (33, 512, 256), (512, 256, 9), (1024, 256, 2), (1024, 1024, 512),
+                                       (33, 256, 3), (100, 512, 256)])
+def test_fc_bwd_kernel_vs_fp64(B, K, Nout, cuda_device):
+    """pngpd_fc_bwd: dW = g^T x, dx = g W, db = sum_b g in one launch (backward of F.linear, pointnet.py:35-37)."""
+    from pointnetgpd_amd import ops
+    gen = torch.Generator().manual_seed(B * 131 + K + Nout)
+    g = torch.randn(B, Nout, generator=gen, dtype=torch.float64)
+    x = torch.randn(B, K, generator=gen, dtype=torch.float64) + 0.3
+    W = torch.randn(Nout, K, generator=gen, dtype=torch.float64) / K ** 0.5
+    f = lambda t: t.float().to(cuda_device).contiguous()
+    dinp, dW, db = ops.fc_bwd(f(g), f(x), f(W))
+    for name, got, ref in (("dinp", dinp, g @ W), ("dW", dW, g.t() @ x), ("db", db, g.sum(0))):
+        r = rel_max(got, ref)
+        assert r <= 1e-5, (name, r)
+
+
+def _bn_case(B, C, seed, margin=2e-3):
+    gen = torch.Generator().manual_seed(seed)
+    z = torch.randn(B, C, generator=gen, dtype=torch.float64) * 0.7 + torch.randn(1, C, generator=gen, dtype=torch.float64)
+    gam = torch.rand(C, generator=gen, dtype=torch.float64) + 0.5
+    gam = torch.where(torch.rand(C, generator=gen) < 0.2, -gam, gam)
+    bet = torch.randn(C, generator=gen, dtype=torch.float64) * 0.3
+    if B == 2:      # keep the two rows apart: the variance of two nearly equal values is ill-conditioned in any fp32 code
+        d = z[0] - z[1]
+        fix = torch.where(d.abs() < 0.2, torch.where(d >= 0, 0.2, -0.2).to(d.dtype) - d, torch.zeros_like(d)) / 2
+        z = z + torch.stack([fix, -fix])
+    for _ in range(100):
+        mu, sd = z.mean(0), (z.var(0, unbiased=False) + 1e-5).sqrt()
+        a = gam * (z - mu) / sd + bet
+        bad = a.abs() < margin
+        if not bad.any():
+            return z, gam, bet
+        if B == 2:
+            bet = torch.where(bad.any(0), bet + 8 * margin, bet)
+        else:
+            z = torch.where(bad, z + torch.sign(a + 1e-30) * torch.sign(gam) * 6 * margin * sd / gam.abs(), z)
+    raise AssertionError("no flip-free BatchNorm case")
+
+
+@pytest.mark.parametrize("relu", [1, 0])
+@pytest.mark.parametrize("B,C", [(2, 512), (33, 256), (512, 512), (1024, 512), (1024, 256), (700, 96)])
+def test_bn1d_train_kernels_vs_fp64(B, C, relu, cuda_device):
+    """pngpd_bn1d_fwd_train / pngpd_bn1d_bwd against F.batch_norm(training=True) [+ ReLU] in fp64 (nn.BatchNorm1d at
+    pointnet.py:24-25,185-186): outputs, batch statistics, running statistics (momentum 0.1, unbiased variance),
+    dz / dgamma / dbeta."""
+    import torch.nn.functional as F
+    from pointnetgpd_amd import ops
+    z64, gam, bet = _bn_case(B, C, 500 + B + C)
+    gen = torch.Generator().manual_seed(B + C)
+    rm0 = torch.randn(C, generator=gen, dtype=torch.float64) * 0.1
+    rv0 = torch.rand(C, generator=gen, dtype=torch.float64) + 0.5
+    dy64 = torch.randn(B, C, generator=gen, dtype=torch.float64)
+    zr, gr, br = z64.clone().requires_grad_(True), gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    rm, rv = rm0.clone(), rv0.clone()
+    a = F.batch_norm(zr, rm, rv, gr, br, True, 0.1, 1e-5)
+    yref = F.relu(a) if relu else a
+    (yref * dy64).sum().backward()
+    f = lambda t: t.detach().float().to(cuda_device).contiguous()
+    bufs = (f(rm0), f(rv0), torch.zeros((), dtype=torch.long, device=cuda_device))
+    y, mean, var = ops.bn1d_fwd_train(f(z64), f(gam), f(bet), 1e-5, relu, 0.1, bufs)
+    dz, dg, db = ops.bn1d_bwd(f(dy64), f(z64), y, f(gam), mean, var, 1e-5, relu)
+    assert rel_max(y, yref.detach()) <= 1e-5
+    assert rel_max(mean, z64.mean(0)) <= 1e-6 and rel_max(var, z64.var(0, unbiased=False)) <= 4e-6
+    assert rel_max(bufs[0], rm) <= 1e-6 and rel_max(bufs[1], rv) <= 4e-6 and int(bufs[2].item()) == 1
+    assert rel_max(dg, gr.grad) <= 1e-4 and rel_max(db, br.grad) <= 1e-4
+    if B == 2:
+        # both normalised values are -/+1 whatever z is: dz is exactly 0 in exact arithmetic
+        sd = (z64.var(0, unbiased=False) + 1e-5).sqrt()
+        U = (gam.abs() / sd) * 3 * dy64.abs().max(0).values
+        assert (dz.double().cpu().abs() <= 2e-6 * U + 1e-12).all()
+    else:
+        assert rel_max(dz, zr.grad) <= 1e-4, rel_max(dz, zr.grad)
+
+
+@pytest.mark.parametrize("B,k", [(2, 2), (33, 3), (1024, 2), (1024, 3), (513, 9)])
+def test_log_softmax_bwd_kernel_vs_fp64(B, k, cuda_device):
+    """pngpd_log_softmax_bwd: d logits = g - exp(logp) * sum_k g (backward of F.log_softmax, pointnet.py:194)."""
+    from pointnetgpd_amd import ops
+    gen = torch.Generator().manual_seed(B * 17 + k)
+    logits = (torch.randn(B, k, generator=gen, dtype=torch.float64) * 3).requires_grad_(True)
+    g = torch.randn(B, k, generator=gen, dtype=torch.float64)
+    logp = torch.log_softmax(logits, -1)
+    (logp * g).sum().backward()
+    f = lambda t: t.detach().float().to(cuda_device).contiguous()
+    got = ops.log_softmax_bwd(f(g), f(logp))
+    assert rel_max(got, logits.grad) <= 1e-5
