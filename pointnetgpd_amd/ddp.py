@@ -24,7 +24,7 @@ import torch.distributed as dist
 
 
 class GradAverager:
-    def __init__(self, model, process_group=None, optimizer=None):
+    def __init__(self, model, process_group=None, optimizer=None, early_bucket_at_world_1=False):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.model = model
@@ -36,6 +36,11 @@ class GradAverager:
         self._hooked = False
         self._early = None          # (offset, length) of the bucket that can leave mid-backward
         self._late = None
+        # a single-rank group has nothing to overlap, so the mid-backward bucket normally stays with the late one;
+        # the flag sends it from the tensor hook anyway — the way to EXECUTE the multi-rank code path (async all-reduce
+        # on a slice of the flat buffer, issued from inside autograd, ordered against the fused backward's stream) on
+        # a one-GPU box (tests/test_gpu_rccl.py, ``torchrun --nproc-per-node 1 bench.py``)
+        self.early_at_world_1 = bool(early_bucket_at_world_1)
         self.sync_parameters()
         if optimizer is not None:
             self.attach(optimizer)
@@ -83,7 +88,8 @@ class GradAverager:
             self._late, self._early = (0, optimizer.numel), None
 
     def _stn_forward_hook(self, module, inputs, output):
-        if self.opt is not None and self.world > 1 and torch.is_tensor(output) and output.requires_grad:
+        if (self.opt is not None and (self.world > 1 or self.early_at_world_1) and torch.is_tensor(output)
+                and output.requires_grad):
             output.register_hook(self._early_ready)
 
     def _early_ready(self, grad):
