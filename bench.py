@@ -94,6 +94,65 @@ def synth_clouds(b, n, seed, device):
     return (u * torch.tensor([w / 2, w, w / 2]).view(1, 3, 1)).float().contiguous().to(device)
 
 
+def synth_scene(G, P, seed_cloud=77, seed_grasps=78):
+    """BASELINE configs[4] / SURVEY.md §8d: scene cloud of P points ~ U(-0.15, 0.15)^2 x U(0, 0.2) (seed 77) and G grasp
+    candidates — random unit quaternion -> rows approach / binormal / minor, bottom centre = a cloud point - 0.05 m along
+    the approach axis (seed 78) — in the (G,5,3) row layout of GpgGraspSamplerPcl.sample_grasps
+    (dex-net/src/dexnet/grasping/grasp_sampler.py:1616-1618)."""
+    import numpy as np
+    rc, rg = np.random.default_rng(seed_cloud), np.random.default_rng(seed_grasps)
+    pc = np.stack([rc.uniform(-0.15, 0.15, P), rc.uniform(-0.15, 0.15, P), rc.uniform(0, 0.2, P)], 1)
+    q = rg.normal(size=(G, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    w, x, y, z = q.T
+    R = np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], 1),
+                  np.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], 1),
+                  np.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], 1)], 1)
+    approach, binormal, minor = R[:, :, 0], R[:, :, 1], R[:, :, 2]
+    bottom = pc[rg.integers(0, P, G)] - 0.05 * approach
+    return pc.astype(np.float32), np.stack([bottom, approach, binormal, minor, bottom], 1)
+
+
+def config5_leg(dev, dist, world, G=100000, P=50000, N=1024, k=3, reps=3):
+    """BASELINE configs[4] ("inference-only: 100k sampled grasp candidates, in-gripper crop + PointNet scoring, batched
+    across 8 GPUs"; replaces the per-grasp loop of dex-net/apps/kinect2grasp.py:238-258,454-497): the scene cloud is
+    replicated, every rank crops + resamples + scores its contiguous slice of the candidates, ONE all_gather of the
+    packed per-candidate results (scoring.score_scene_distributed).  The candidate count is fixed, so this leg scales
+    STRONG.  Timed with barrier + synchronize on both sides, max over ranks, median of ``reps``."""
+    import statistics
+    import numpy as np
+    import torch
+    from pointnetgpd_amd import scoring
+    model = build_model(N, k, dev)
+    pc, grasps = synth_scene(G, P)
+    scorer = scoring.GraspScorer(model, num_points=N, repeat=1, batch=4096, seed=1, max_keep=8192)
+    cloud = torch.from_numpy(pc).to(dev)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+    scoring.score_scene_distributed(scorer.score, cloud, grasps[:4096 * world])      # warm-up (fold cache, workspaces)
+    times = []
+    for _ in range(reps):
+        sync()
+        t0 = time.perf_counter()
+        res = scoring.score_scene_distributed(scorer.score, cloud, grasps)
+        sync()
+        t = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([t], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t = tt.item()
+        times.append(t)
+    t = statistics.median(times)
+    return {"workload": f"BASELINE configs[4]: {G} candidates x {P}-point scene, crop + resample to N={N} + {k}-class "
+                        f"PointNet scoring + one all_gather of the results",
+            "value": round(G / t, 1), "unit": "grasps/s", "seconds": round(t, 4), "candidates": G,
+            "candidates_per_gpu": (G + world - 1) // world, "scaling": "strong", "dtype": "f32",
+            "valid_frac": round(float(res["valid"].float().mean().item()), 4), "reps": reps}
+
+
 def synth_clouds_diverse(b, n, seed, device):
     """Clouds that differ from each other (per-cloud anisotropic scale, rotation, offset; box / gaussian / shell mix) —
     the recipe of the parity tests' "diverse" clouds.  With iid box clouds the pooled features are nearly identical
@@ -412,6 +471,8 @@ def main():
     ap.add_argument("--no-train", action="store_true", help="skip the training-step legs")
     ap.add_argument("--no-fast", action="store_true", help="skip the opt-in bf16x3 legs")
     ap.add_argument("--graph", action="store_true", help="also time the train step replayed from a HIP graph")
+    ap.add_argument("--no-config5", action="store_true",
+                    help="skip the BASELINE configs[4] leg (100k candidates: crop + scoring, sharded over the ranks)")
     ap.add_argument("--pmc", action="store_true",
                     help="measure roofline.traffic NOW with two rocprofv3 --pmc passes over the dominant kernel "
                          "(N = 1 only; ~15 s) instead of citing the stored figure of profiles/pmc_trunk.json")
@@ -644,6 +705,11 @@ def main():
                                       "the headline are the adversarial case (near-identical pooled features)")
                 train_res["fast_" + prec] = leg
 
+    # ---- BASELINE configs[4]: 100k candidates of one scene, crop + scoring, candidates sharded over the ranks
+    c5 = None
+    if not args.no_config5:
+        c5 = config5_leg(dev, dist, world)
+
     # ---- dominant kernel (fused trunk) timed live with events on the launch stream
     wts = pn._trunk_infer_weights(model.feat.stn, dev)
     reps = max(20, args.steps)
@@ -727,6 +793,8 @@ def main():
             res["train"] = train_res
             res["value_train"] = train_res["value"]
             res["value_train_is"] = "training-step leg (fwd + nll_loss + bwd + Adam, exact fp32), grasps/s, same batch"
+        if c5 is not None:
+            res["config5"] = c5
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(N, k)
         print(json.dumps(res), flush=True)

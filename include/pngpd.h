@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PNGPD_ABI_VERSION 3
+#define PNGPD_ABI_VERSION 4
 
 enum {
     PNGPD_OK = 0,
@@ -163,6 +163,23 @@ int pngpd_trunk_fwd_train(const float *x, int B, int N, const float *trans,
                           const float *w1, const float *b1, const float *s1c, const float *t1c,
                           const float *w2p, const float *s2c, const float *t2c, const float *w3sp, int S,
                           float *pmax, int *parg, float *psum, float *psh, const float *z2t, void *stream);
+
+/* Pool refinement of the reduced-precision modes (precision 1 / 3): zex (B,1024) = the EXACT fp32 value of
+ *   z3s[b][c] = (sign(gamma3) W3)[c] . h2[b][:, idx[b][c]]
+ * at the arg-max point idx the bf16 / bf16x3 pass C chose (layers 1-2 re-evaluated in fp32 for the B*1024 points, then
+ * one 128-long contraction each — the arithmetic of pngpd_trunk_fwd_train, operation for operation, so that wherever
+ * idx is the fp32 arg-max the value is bit-identical to the fp32 pass's maximum).  Feed zex to pngpd_pool_finalize
+ * (S = 1) in place of the bf16 pass's pmax: the reduced-precision matrix pass then contributes only the CHOICE of the
+ * point to max over N of bn3(conv3(.)) (PointNetGPD/model/pointnet.py:31-32, :147-148).
+ *   w2p: fp32 MFMA_B-packed conv2 weight; w3sp: sign-folded MFMA_B-packed conv3 weight (variant 0) or NULL;
+ *   w3 / g3: raw conv3 weight (1024,128) and bn3.weight (variants 1-3) or NULL;
+ *   variant: 0 = contraction on the fp32 matrix pipe (default), 1-3 = on the VALU (candidate orders of the matrix
+ *   instruction's two products; tests/test_gpu_refine.py probes which one reproduces it bit for bit).               */
+int pngpd_trunk_pool_refine(const float *x, int B, int N, const float *trans,
+                            const float *w1, const float *b1, const float *s1c, const float *t1c,
+                            const float *w2p, const float *s2c, const float *t2c,
+                            const float *w3sp, const float *w3, const float *g3, const int *idx,
+                            int clouds_per_range, int variant, float *zex, void *stream);
 
 /* sparse (arg-extremum) term of dW3:  Gp (ceil(B/clouds_per_range),1024,128),
  *   Gp[r][c][:] = sum_{b in range r} coef[b][c] * h2[b][:, idx[b][c]]                         */
@@ -307,6 +324,8 @@ typedef struct pngpd_trunk_train {
     int relu_last;         /* ReLU after bn3 (STN3d trunk, pointnet.py:31) or not (PointNetfeat, :147)               */
     int precision;         /* arithmetic of the contractions: 0 fp32 (exact), 3 bf16x3, 1 plain bf16                 */
     int fp32_side;         /* precision != 0: keep passes B / gather / D / E on the fp32 kernels                     */
+    int refine;            /* precision != 0: pooled maxima re-evaluated in exact fp32 at the chosen arg-max points
+                              (pngpd_trunk_pool_refine): 0 off, 1 on the fp32 matrix pipe, 2 on the VALU                 */
     int need_bwd;          /* forward: a backward will follow (keep z2 and the transposed layer-2 weights)           */
     float eps, momentum;   /* of the three BatchNorm1d layers                                                        */
     const float *w1, *b1, *g1, *be1;   /* conv1.weight (64,3), conv1.bias, bn1.weight, bn1.bias                      */

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PNGPD_LIB") or os.path.join(_HERE, "libpngpd.so")   # PNGPD_LIB: A/B builds only
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 _load_error = None
@@ -23,7 +23,7 @@ _P, _I, _F, _Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 class TrunkTrainArgs(ctypes.Structure):
     """``pngpd_trunk_train_t`` of include/pngpd.h (field for field)."""
     _fields_ = ([("x", _P), ("trans", _P), ("B", _I), ("N", _I), ("S", _I), ("relu_last", _I), ("precision", _I),
-                 ("fp32_side", _I), ("need_bwd", _I), ("eps", _F), ("momentum", _F)] +
+                 ("fp32_side", _I), ("refine", _I), ("need_bwd", _I), ("eps", _F), ("momentum", _F)] +
                 [(n, _P) for n in ("w1", "b1", "g1", "be1", "w2", "b2", "g2", "be2", "w3", "b3", "g3", "be3",
                                    "rm1", "rv1", "nbt1", "rm2", "rv2", "nbt2", "rm3", "rv3", "nbt3",
                                    "pooled", "idx", "zhat", "dp",
@@ -70,6 +70,8 @@ SIGNATURES = {
                               [c_f32p] * 5 + [c_void]),
     "pngpd_trunk_bwd_gather": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 10 +
                                [ctypes.c_int, c_f32p, c_void]),
+    "pngpd_trunk_pool_refine": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 12 +
+                                [ctypes.c_int, ctypes.c_int, c_f32p, c_void]),
     "pngpd_trunk_bwd_d": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 16 + [ctypes.c_int] +
                           [c_f32p] * 3 + [c_void]),
     "pngpd_trunk_bwd_e": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 16 + [ctypes.c_int] +

@@ -23,3 +23,7 @@ int pngpd_reduce_fin_launch(RFArgs &A, int nseg, void *stream);
 struct PackJob { const float *W; const float *sgn_src; void *out; int C, K, transpose, src_packed, fmt; };
 struct PackArgs { PackJob job[PACK_MAX_JOBS]; int first[PACK_MAX_JOBS + 1]; };
 int pngpd_train_pack_launch(PackArgs &A, int njobs, void *stream);
+
+// The VALU order of pngpd_trunk_pool_refine that reproduces v_mfma_f32_32x32x2_f32 bit for bit (probed on the device:
+// tests/test_gpu_refine.py::test_valu_variant_matches_matrix_pipe).
+#define PNGPD_REFINE_VALU_VARIANT 1

@@ -433,6 +433,133 @@ __global__ __launch_bounds__(256, 4) void trunk_bwd_gather_kernel(   // 4 workgr
 }
 
 // ---------------------------------------------------------------------------------------
+// pool refinement (the reduced-precision modes): zex[b][c] = (sgn W3)[c] . h2[b][:, idx[b][c]] in EXACT fp32
+// arithmetic at the arg-max point the bf16 / bf16x3 pass C chose.
+//   BatchNorm's mean / variance are averages over B*N products, where the bf16 product error largely averages out;
+//   the pooled maxima are single values and carried that error in full (2^-9 .. 2^-16 relative) into the FC stacks,
+//   whose batch-statistics BatchNorms amplify it on near-identical clouds.  After this pass the bf16 matrix pass
+//   contributes only the CHOICE of the point.
+// The arithmetic is the fp32 pass C's, operation for operation — x' = x^T T, layer 1 (layer1_tile), layer 2 on the fp32
+// MFMA with the same fragment order (layer2_compute), h2 = relu(fma(z2, s2c, t2c)), and the layer-3 contraction as the
+// same chain of v_mfma_f32_32x32x2_f32 over kb = 0..15, t = 0..3 on the sign-folded MFMA_B weights — so that wherever
+// the chosen point IS the fp32 arg-max, the refined value is BIT-identical to the fp32 pass C's maximum (given the same
+// BatchNorm-1/2 affine forms).  VARIANT 0 evaluates the 32x32 diagonal blocks on the matrix pipe (each wave of a pair
+// owns (point block, channel block) = (w, w) and keeps its diagonal); VARIANTs 1-3 evaluate the 128-long chain on the
+// VALU in the order the matrix instruction contracts its two k's (probed on the device by tests/test_gpu_refine.py).
+// workgroup = (64-channel chunk cc, cloud range rng) like the gather pass.
+// ---------------------------------------------------------------------------------------
+#define REFINE_LDS_FLOATS (TP * H1S + TP * H2S + 8 * TP)
+
+template <int VARIANT>
+__global__ __launch_bounds__(256, 3) void trunk_pool_refine_kernel(
+    const float *__restrict__ x, int B, int N, const float *__restrict__ trans, TrainChan P,
+    const float *__restrict__ w3sp, const float *__restrict__ w3, const float *__restrict__ g3,
+    const int *__restrict__ idx, int clouds_per_range, float *__restrict__ zex) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *h1 = smem;
+    float *h2 = h1 + TP * H1S;    // [TP][H2S]
+    float *xcf = h2 + TP * H2S;   // 2 x [3][TP] points (+ TP spare): double-buffered by cloud parity
+    const Lane L;
+    const int cc = blockIdx.x & 15, rng = blockIdx.x >> 4;
+    const int b0 = rng * clouds_per_range;
+    const int b1 = (b0 + clouds_per_range < B) ? b0 + clouds_per_range : B;
+    const bool has_t = trans != nullptr;
+    const int cb = L.wave, c2 = cb * 32 + L.j;
+    const float sc = P.s2c[c2], sh = P.t2c[c2];
+    f32x4 w2f[8];
+    load_w2frag(w2f, P.w2p, L.wave, L);
+    const L1C l1c = load_l1c(P.w1, P.b1, P.s1c, P.t1c, L);
+    f32x4 w3f[16];   // VARIANT 0, waves 0 / 1: the sign-folded layer-3 fragments of channel block 2 cc + wave, resident
+    if (VARIANT == 0 && L.wave < 2) load_wfrag(w3f, w3sp, cc * 2 + L.wave, L);
+    // VARIANT > 0: lane p of the cloud's duty wave owns channel c = 64 cc + p: its raw weight row and sign
+    const float *wrow = w3 + (size_t)(cc * 64 + L.lane) * 128;
+    const bool neg = VARIANT > 0 && g3[cc * 64 + L.lane] < 0.f;
+    float nx0 = 0.f, nx1 = 0.f, nx2 = 0.f;
+    auto fetch = [&](int b) {
+        if (L.tid < TP && b < b1) {
+            const int n = idx[(size_t)b * 1024 + cc * 64 + L.tid];
+            const float *xb = x + (size_t)b * 3 * N;
+            nx0 = xb[n]; nx1 = xb[N + n]; nx2 = xb[2 * N + n];
+        }
+    };
+    fetch(b0);
+    for (int b = b0; b < b1; ++b) {
+        float *xs = xcf + ((b - b0) & 1) * 4 * TP;
+        if (L.tid < TP) {
+            float x0 = nx0, x1 = nx1, x2 = nx2;
+            fetch(b + 1);
+            if (has_t) {
+                const float *tm = trans + (size_t)b * 9;
+                float y0 = fmaf(x2, tm[6], fmaf(x1, tm[3], x0 * tm[0]));
+                float y1 = fmaf(x2, tm[7], fmaf(x1, tm[4], x0 * tm[1]));
+                float y2 = fmaf(x2, tm[8], fmaf(x1, tm[5], x0 * tm[2]));
+                x0 = y0; x1 = y1; x2 = y2;
+            }
+            xs[L.tid] = x0; xs[TP + L.tid] = x1; xs[2 * TP + L.tid] = x2;
+        }
+        __syncthreads();   // points staged; every wave is done with cloud b-1's h1 (layer 2) and h2 (layer 3 ends before it)
+        layer1_tile(xs, l1c, h1, L);
+        __syncthreads();
+        f32x16 a0, a1;
+        layer2_compute(h1, w2f, L, a0, a1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = mfma_row(r, L.lane);
+            h2[row * H2S + c2] = fmaxf(fmaf(a0[r], sc, sh), 0.f);
+            h2[(32 + row) * H2S + c2] = fmaxf(fmaf(a1[r], sc, sh), 0.f);
+        }
+        __syncthreads();   // h2 complete
+        float *o = zex + (size_t)b * 1024 + cc * 64;
+        if constexpr (VARIANT == 0) {
+            if (L.wave < 2) {
+                const float *ap = h2 + (L.wave * 32 + L.j) * H2S + L.h * 4;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                f32x4 av = *(const f32x4 *)ap;
+#pragma unroll
+                for (int kb = 0; kb < 16; ++kb) {
+                    f32x4 nv = av;
+                    if (kb + 1 < 16) nv = *(const f32x4 *)(ap + (kb + 1) * 8);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc = mfma32(av[t], w3f[kb][t], acc);
+                    av = nv;
+                }
+                // diagonal element (i == j) of the block: register r = (j & 3) + 4 (j >> 3) of the lane half h = (j >> 2) & 1
+                const int rs = (L.j & 3) + 4 * (L.j >> 3);
+                float dv = acc[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) dv = (rs == r) ? acc[r] : dv;
+                if (L.h == ((L.j >> 2) & 1)) o[L.wave * 32 + L.j] = dv;
+            }
+        } else {
+            if (L.wave == ((b - b0) & 3)) {   // the duty wave rotates over the SIMDs with the cloud
+                const float *hr = h2 + L.lane * H2S;
+                float acc = 0.f;
+                double accd = 0.0;
+#pragma unroll 4
+                for (int kb = 0; kb < 16; ++kb) {
+                    const f32x4 alo = *(const f32x4 *)(hr + kb * 8), ahi = *(const f32x4 *)(hr + kb * 8 + 4);
+                    f32x4 wlo = *(const f32x4 *)(wrow + kb * 8), whi = *(const f32x4 *)(wrow + kb * 8 + 4);
+                    if (neg) { wlo = -wlo; whi = -whi; }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (VARIANT == 1) { acc = fmaf(alo[t], wlo[t], acc); acc = fmaf(ahi[t], whi[t], acc); }
+                        else if (VARIANT == 2) { acc = fmaf(ahi[t], whi[t], acc); acc = fmaf(alo[t], wlo[t], acc); }
+                        else {   // both products exact, one rounding per instruction
+                            accd = (double)acc + (double)alo[t] * (double)wlo[t] + (double)ahi[t] * (double)whi[t];
+                            acc = (float)accd;
+                        }
+                    }
+                }
+                o[L.lane] = acc;
+            }
+        }
+        // no end-of-cloud barrier: xs is double-buffered; h1 / h2 are rewritten only behind the next cloud's barriers
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // backward pass D: g2 = dL/d(bn2 output) per point; also the 128x128 second moments of h2 (the old separate
 // "h-moments" pass: h2 is in LDS here anyway and this pass has idle MFMA slots).
 //   dh2[point][k] = cvec[k] - (h2 A)[point][k] + sum_{c: idx[b][c]==point} coef[b][c] W3[c][k]
@@ -1549,6 +1676,34 @@ int pngpd_trunk_bwd_gather_bf(const float *x, int B, int N, const float *trans,
     if (nterms != 1 && nterms != 3) return PNGPD_ERR_INVALID_ARG;
     return bwd_gather_impl(x, B, N, trans, w1, b1, s1c, t1c, nullptr, w2x, nterms, s2c, t2c, idx, coef,
                            clouds_per_range, Gp, stream);
+}
+
+int pngpd_trunk_pool_refine(const float *x, int B, int N, const float *trans,
+                            const float *w1, const float *b1, const float *s1c, const float *t1c,
+                            const float *w2p, const float *s2c, const float *t2c,
+                            const float *w3sp, const float *w3, const float *g3, const int *idx,
+                            int clouds_per_range, int variant, float *zex, void *stream) {
+    if (!x || !w1 || !b1 || !s1c || !t1c || !w2p || !s2c || !t2c || !idx || !zex || B <= 0 || N <= 0 ||
+        clouds_per_range <= 0 || variant < 0 || variant > 3 || (variant == 0 ? !w3sp : (!w3 || !g3)))
+        return PNGPD_ERR_INVALID_ARG;
+    const int R = (B + clouds_per_range - 1) / clouds_per_range;
+    TrainChan P = make_chan(w1, b1, s1c, t1c, w2p, s2c, t2c);
+    const size_t lds = REFINE_LDS_FLOATS * sizeof(float);
+    const void *fn = variant == 0 ? (const void *)trunk_pool_refine_kernel<0>
+                   : variant == 1 ? (const void *)trunk_pool_refine_kernel<1>
+                   : variant == 2 ? (const void *)trunk_pool_refine_kernel<2> : (const void *)trunk_pool_refine_kernel<3>;
+    int st = pngpd_allow_lds(fn, lds);
+    if (st != PNGPD_OK) return st;
+    const dim3 grid((unsigned)R * 16);
+    hipStream_t sm = (hipStream_t)stream;
+#define PNGPD_REFINE_LAUNCH(V) hipLaunchKernelGGL(trunk_pool_refine_kernel<V>, grid, dim3(256), lds, sm, x, B, N, trans, \
+                                                  P, w3sp, w3, g3, idx, clouds_per_range, zex)
+    if (variant == 0) PNGPD_REFINE_LAUNCH(0);
+    else if (variant == 1) PNGPD_REFINE_LAUNCH(1);
+    else if (variant == 2) PNGPD_REFINE_LAUNCH(2);
+    else PNGPD_REFINE_LAUNCH(3);
+#undef PNGPD_REFINE_LAUNCH
+    return pngpd_launch_status();
 }
 
 int pngpd_trunk_bwd_d(const float *x, int B, int N, const float *trans,

@@ -30,6 +30,7 @@ struct TrunkDims {
 bool trunk_dims(const pngpd_trunk_train_t *a, TrunkDims &d) {
     if (!a || a->B <= 0 || a->N <= 0) return false;
     if (a->precision != 0 && a->precision != 1 && a->precision != 3) return false;
+    if (a->refine < 0 || a->refine > 2) return false;
     d.B = a->B; d.N = a->N; d.S = a->S;
     d.T = (a->N + 63) / 64;
     if (d.S < 1 || d.S > d.T) return false;
@@ -69,7 +70,7 @@ bool carve_save(Carve &c, const TrunkDims &d, TrunkSave &s) {
     return c.ok;
 }
 
-struct TrunkFwdScratch { float *part, *pmax, *psum, *psh, *w3sp; int *parg; unsigned short *w3sx; };
+struct TrunkFwdScratch { float *part, *pmax, *psum, *psh, *w3sp, *zex; int *parg; unsigned short *w3sx; };
 
 bool carve_fwd(Carve &c, const TrunkDims &d, TrunkFwdScratch &f) {
     f.part = c.take<float>((size_t)d.blk * 256);
@@ -79,6 +80,7 @@ bool carve_fwd(Carve &c, const TrunkDims &d, TrunkFwdScratch &f) {
     f.psh = c.take<float>((size_t)d.B * d.Sc * (d.nt ? 2 : 1) * 128);
     f.w3sp = c.take<float>(1024 * 128);
     f.w3sx = c.take<unsigned short>(2 * 1024 * 128);
+    f.zex = c.take<float>((size_t)d.B * 1024);
     return c.ok;
 }
 
@@ -157,14 +159,14 @@ int pngpd_trunk_train_fwd(const pngpd_trunk_train_t *a, void *stream) {
     {
         PackArgs P; int n = 0;
         const bool need_f32_side = d.nt_side == 0;
-        if (need_f32_side) {
-            P.job[n++] = PackJob{a->w2, nullptr, s.w2p, 128, 64, 0, 0, 0};
-            if (a->need_bwd) P.job[n++] = PackJob{a->w2, nullptr, s.w2tp, 64, 128, 1, 0, 0};
-        }
+        const bool refine = d.nt && a->refine;
+        if (need_f32_side || refine) P.job[n++] = PackJob{a->w2, nullptr, s.w2p, 128, 64, 0, 0, 0};
+        if (need_f32_side && a->need_bwd) P.job[n++] = PackJob{a->w2, nullptr, s.w2tp, 64, 128, 1, 0, 0};
         if (d.nt) {
             P.job[n++] = PackJob{a->w2, nullptr, s.w2x, 128, 64, 0, 0, 1};
             P.job[n++] = PackJob{a->w3, a->g3, f.w3sx, 1024, 128, 0, 0, 1};
             if (d.nt_side && a->need_bwd) P.job[n++] = PackJob{a->w2, nullptr, s.w2tx, 64, 128, 1, 0, 1};
+            if (a->refine == 1) P.job[n++] = PackJob{a->w3, a->g3, f.w3sp, 1024, 128, 0, 0, 0};
         } else {
             P.job[n++] = PackJob{a->w3, a->g3, f.w3sp, 1024, 128, 0, 0, 0};
         }
@@ -206,8 +208,18 @@ int pngpd_trunk_train_fwd(const pngpd_trunk_train_t *a, void *stream) {
         A.seg[1] = h;
         CHK(pngpd_reduce_fin_launch(A, 2, stream));
     }
-    return pngpd_pool_finalize(f.pmax, f.parg, B, d.Sc, s.stats3, a->g3, a->be3, a->eps, a->relu_last, a->pooled,
-                               a->idx, a->zhat, stream);
+    CHK(pngpd_pool_finalize(f.pmax, f.parg, B, d.Sc, s.stats3, a->g3, a->be3, a->eps, a->relu_last, a->pooled,
+                            a->idx, a->zhat, stream));
+    if (d.nt && a->refine) {
+        // the reduced-precision pass C chose the points; their values are re-evaluated in exact fp32 (layers 1-2 for
+        // the B*1024 arg-max points + one 128-long contraction each) and the pooled outputs rebuilt from those
+        CHK(pngpd_trunk_pool_refine(x, B, N, T, a->w1, a->b1, s1c, t1c, s.w2p, s2c, t2c,
+                                    a->refine == 1 ? f.w3sp : nullptr, a->w3, a->g3, a->idx, d.cpr,
+                                    a->refine == 1 ? 0 : PNGPD_REFINE_VALU_VARIANT, f.zex, stream));
+        CHK(pngpd_pool_finalize(f.zex, a->idx, B, 1, s.stats3, a->g3, a->be3, a->eps, a->relu_last, a->pooled, a->idx,
+                                a->zhat, stream));
+    }
+    return PNGPD_OK;
 }
 
 int pngpd_trunk_train_bwd(const pngpd_trunk_train_t *a, void *stream) {

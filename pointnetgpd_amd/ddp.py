@@ -73,7 +73,7 @@ class GradAverager:
     def attach(self, optimizer):
         """Use ``optimizer``'s (optim.FlatAdam) flat gradient buffer for the collectives, in two buckets."""
         self.opt = optimizer
-        self._count = torch.zeros(64, device=optimizer.device, dtype=torch.float32)
+        self._count = optimizer.flat_g[:1]       # header slot 0 of the flat gradient buffer (optim.FlatAdam)
         stn = getattr(getattr(self.model, "feat", None), "stn", None)
         if stn is not None:
             lo, n = optimizer.segment(list(stn.parameters()))
@@ -85,7 +85,18 @@ class GradAverager:
                     stn.register_forward_hook(self._stn_forward_hook)
                     self._hooked = True
         if self._early is None:
-            self._late, self._early = (0, optimizer.numel), None
+            self._late, self._early = (optimizer.header, optimizer.numel - optimizer.header), None
+        # the kept-sample count sits in the header right in front of the first slice: whichever bucket starts there
+        # takes the header along, so gradients and count share one all-reduce
+        hdr = optimizer.header
+        if self._late[0] == hdr:
+            self._late = (0, self._late[1] + hdr)
+            self._count_with = "late"
+        elif self._early is not None and self._early[0] == hdr:
+            self._early = (0, self._early[1] + hdr)
+            self._count_with = "early"
+        else:
+            self._count_with = None
 
     def _stn_forward_hook(self, module, inputs, output):
         if (self.opt is not None and (self.world > 1 or self.early_at_world_1) and torch.is_tensor(output)
@@ -117,14 +128,16 @@ class GradAverager:
         sit_out = loss_sum is None or n_local < 2
         if self.opt is not None:
             self._skip = False
+            # the count is written BEFORE any bucket can leave (the early one goes from inside backward())
             if sit_out:
-                self.opt.flat_g.zero_()
+                self.opt.flat_g.zero_()      # header included: count 0
                 self._skip = True            # no hook will fire: send the early bucket here
                 if self._early is not None:
                     lo, n = self._early
                     self._pending.append(dist.all_reduce(self.opt.flat_g[lo:lo + n], op=dist.ReduceOp.SUM,
                                                          group=self.group, async_op=True))
             else:
+                self._count.fill_(float(n_local))
                 self._active, self._early_sent = True, False
                 try:
                     loss_sum.backward()
@@ -136,12 +149,12 @@ class GradAverager:
                     lo, n = self._early
                     self._pending.append(dist.all_reduce(self.opt.flat_g[lo:lo + n], op=dist.ReduceOp.SUM,
                                                          group=self.group, async_op=True))
-            self._count.zero_()
-            self._count[0] = float(0 if sit_out else n_local)
             lo, n = self._late
             self._pending.append(dist.all_reduce(self.opt.flat_g[lo:lo + n], op=dist.ReduceOp.SUM, group=self.group,
                                                  async_op=True))
-            self._pending.append(dist.all_reduce(self._count, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if self._count_with is None:     # (cannot happen with FlatAdam's layout; kept for foreign layouts)
+                self._pending.append(dist.all_reduce(self._count, op=dist.ReduceOp.SUM, group=self.group,
+                                                     async_op=True))
             for w in self._pending:
                 w.wait()                     # stream-ordered for NCCL/RCCL: no host block
             self._pending = []
@@ -171,8 +184,9 @@ class GradAverager:
         if self.world == 1:
             return
         if self.opt is not None:
-            dist.all_reduce(self.opt.flat_g, op=dist.ReduceOp.SUM, group=self.group)
-            self.opt.flat_g.div_(self.world)
+            g = self.opt.flat_g[self.opt.header:]
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+            g.div_(self.world)
             return
         grads = []
         for p in self.params:

@@ -307,6 +307,17 @@ def trunk_bwd_gather_bf(x, trans, w1, b1, s1c, t1c, w2x, s2c, t2c, idx, coef, nt
     return Gp
 
 
+def trunk_pool_refine(x, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, idx, w3sp=None, w3=None, g3=None, variant=0,
+                      clouds_per_range=None):
+    """zex (B,1024): the exact fp32 value of z3s at the arg-max points ``idx`` (pngpd_trunk_pool_refine)."""
+    B, _, N = x.shape
+    cpr = int(clouds_per_range) if clouds_per_range else max(1, min(16, B // 16))
+    zex = torch.empty(B, 1024, device=x.device, dtype=torch.float32)
+    _call("pngpd_trunk_pool_refine", x, x, B, N, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, w3sp, w3, g3, idx, cpr,
+          int(variant), zex)
+    return zex
+
+
 def unpack_mfma_b_128(Ap):
     """pngpd_a_cvec_finalize's MFMA_B-packed 128x128 matrix -> row-major (128,128)."""
     return Ap.view(4, 16, 2, 32, 4).permute(0, 3, 1, 2, 4).reshape(128, 128)

@@ -69,8 +69,11 @@ class FlatAdam(torch.optim.Optimizer):
         if dev.type != "cuda" or any(p.device != dev or p.dtype != torch.float32 for p in ps):
             raise RuntimeError("FlatAdam needs float32 parameters on one CUDA device (libpngpd has no CPU path)")
         self.device = dev
-        # 256-byte aligned slices (the kernels write gradients with 16-byte stores)
-        self.offsets, off = [], 0
+        # 256-byte aligned slices (the kernels write gradients with 16-byte stores) behind a 64-float header: slot 0 of
+        # the GRADIENT buffer's header carries the kept-sample count of a data-parallel step, so that it travels in the
+        # same all-reduce as the adjacent (first) gradient slice (ddp.GradAverager) — one collective fewer per step
+        self.header = 64
+        self.offsets, off = [], self.header
         for p in ps:
             self.offsets.append(off)
             off += (p.numel() + 63) // 64 * 64
@@ -159,8 +162,10 @@ class FlatAdam(torch.optim.Optimizer):
         with _lib.device_guard(self.device):
             if self.step_dev is not None:
                 _lib.check(lib.pngpd_adam_step_inc(self.step_dev.data_ptr(), stream), "adam_step_inc")
-            _lib.check(lib.pngpd_adam_flat(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
-                                           self.flat_v.data_ptr(), self.numel, lr_host, lr_dev, float(b1), float(b2),
+            h = self.header * 4
+            _lib.check(lib.pngpd_adam_flat(self.flat_p.data_ptr() + h, self.flat_g.data_ptr() + h,
+                                           self.flat_m.data_ptr() + h, self.flat_v.data_ptr() + h,
+                                           self.numel - self.header, lr_host, lr_dev, float(b1), float(b2),
                                            float(eps), float(self._step),
                                            self.step_dev.data_ptr() if self.step_dev is not None else None,
                                            float(grad_scale), grad_div.data_ptr() if grad_div is not None else None,

@@ -39,14 +39,24 @@ F64 = torch.float64
 _TRAIN_PRECISION = "fp32"
 _FP32_SIDE_PASSES = False
 _NTERMS = {"bf16x3": 3, "bf16": 1}
+# Reduced-precision modes only: re-evaluate the pooled maxima in exact fp32 at the arg-max points the bf16 / bf16x3
+# pass C chose (pngpd_trunk_pool_refine).  0 off (round 3's behaviour), 1 on the fp32 matrix pipe, 2 on the VALU.
+# The pooled values are single numbers that carried the full bf16 product error into the FC stacks' batch-statistics
+# BatchNorms; after the refinement the matrix pass contributes only the CHOICE of the point.
+_REFINE_POOL = 2
+_REFINE_VALU_VARIANT = 1      # == PNGPD_REFINE_VALU_VARIANT (pngpd_internal.h)
 
 
-def set_train_precision(mode, fp32_side_passes=False):
-    global _TRAIN_PRECISION, _FP32_SIDE_PASSES
+def set_train_precision(mode, fp32_side_passes=False, refine_pool=None):
+    global _TRAIN_PRECISION, _FP32_SIDE_PASSES, _REFINE_POOL
     if mode not in ("fp32", "bf16x3", "bf16"):
         raise ValueError("precision must be 'fp32', 'bf16x3' or 'bf16'")
     _TRAIN_PRECISION = mode
     _FP32_SIDE_PASSES = bool(fp32_side_passes)
+    if refine_pool is not None:
+        if int(refine_pool) not in (0, 1, 2):
+            raise ValueError("refine_pool must be 0 (off), 1 (matrix pipe) or 2 (VALU)")
+        _REFINE_POOL = int(refine_pool)
 
 
 _SEQUENCING = "fused"
@@ -169,6 +179,16 @@ class TrunkTrainFn(torch.autograd.Function):
         pooled, idx, zhat = _e(dev, B, 1024), _e(dev, B, 1024, dtype=torch.int32), _e(dev, B, 1024)
         _call("pngpd_pool_finalize", x, pmax, parg, B, Sc, stats3, g3c, be3c, float(eps), int(relu_last), pooled,
               idx, zhat)
+        if nt and _REFINE_POOL:
+            # the reduced-precision pass chose the points; their values are re-evaluated in exact fp32
+            if _REFINE_POOL == 1:
+                zex = ops.trunk_pool_refine(x, T, w1, b1c, s1c, t1c, w2p, s2c, t2c, idx,
+                                            w3sp=ops.pack_mfma_b(w3, scale=sgn), variant=0)
+            else:
+                zex = ops.trunk_pool_refine(x, T, w1, b1c, s1c, t1c, w2p, s2c, t2c, idx, w3=w3, g3=g3c,
+                                            variant=_REFINE_VALU_VARIANT)
+            _call("pngpd_pool_finalize", x, zex, idx, B, 1, stats3, g3c, be3c, float(eps), int(relu_last), pooled,
+                  idx, zhat)
         ctx.relu_last, ctx.eps, ctx.has_t, ctx.S = relu_last, eps, T is not None, S
         ctx.z2t = z2t          # a plain workspace buffer, not part of the autograd graph
         ctx.nt_side, ctx.w2x = nt_side, w2x
@@ -375,6 +395,7 @@ class FusedTrunkFn(torch.autograd.Function):
         a.relu_last = int(bool(relu_last))
         a.precision = _PREC_CODE[_TRAIN_PRECISION]
         a.fp32_side = int(_FP32_SIDE_PASSES)
+        a.refine = _REFINE_POOL if a.precision else 0
         need_bwd = any(ctx.needs_input_grad) or grad_outs is not None
         a.need_bwd = int(need_bwd)
         a.eps, a.momentum = float(eps), float(momentum)
@@ -383,7 +404,7 @@ class FusedTrunkFn(torch.autograd.Function):
             if bufs is not None:
                 setattr(a, f"rm{i}", bufs[0].data_ptr()); setattr(a, f"rv{i}", bufs[1].data_ptr())
                 setattr(a, f"nbt{i}", _dp(bufs[2]))
-        key = (B, N, a.S, a.precision, a.fp32_side)
+        key = (B, N, a.S, a.precision, a.fp32_side, a.refine)
         sizes = _SIZE_CACHE.get(key)
         if sizes is None:
             lib = _lib.load()

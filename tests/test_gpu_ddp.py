@@ -163,7 +163,10 @@ def test_two_ranks_flat_gradient_buckets(tmp_path, cuda_device):
     r0, r1 = torch.load(tmp_path / "f0.pt"), torch.load(tmp_path / "f1.pt")
     assert r0["total"] == 12.0 and r1["total"] == 12.0 and r0["total2"] == 7.0 and r1["total2"] == 7.0
     assert torch.equal(r0["summed"], r1["summed"])
-    assert torch.allclose(r0["summed"], r0["local"] + r1["local"], atol=1e-6, rtol=1e-6)
+    # the flat gradient buffer starts with a 64-float header whose slot 0 carries the kept-sample count in the same
+    # all-reduce as the first gradient slice
+    assert r0["summed"][0].item() == 12.0 and r0["local"][:64].abs().max().item() == 0.0
+    assert torch.allclose(r0["summed"][64:], r0["local"][64:] + r1["local"][64:], atol=1e-6, rtol=1e-6)
     assert torch.equal(r0["params"], r1["params"])                       # replicas stay identical through both steps
     assert torch.equal(r0["rm"], r1["rm"]) and torch.equal(r0["ev"], r1["ev"])   # eval: rank 0's statistics everywhere
 
@@ -224,3 +227,7 @@ def test_bench_self_spawns_two_ranks(cuda_device):
     assert res["config"]["batch_per_gpu"] == 64 and res["value"] > 0
     assert res["train"]["weak"]["value"] > 0 and res["train"]["strong"]["value"] > 0
     assert "all-reduce" in res["train"]["step"]
+    # BASELINE configs[4]: the 100k-candidate scene, candidates sharded over the ranks (strong scaling)
+    c5 = res["config5"]
+    assert c5["candidates"] == 100000 and c5["candidates_per_gpu"] == 50000 and c5["scaling"] == "strong"
+    assert c5["value"] > 0 and 0.0 < c5["valid_frac"] <= 1.0

@@ -11,6 +11,8 @@ under main_1v.py:72-75, run through ATen on the device) is evaluated with the HI
 activation patterns (``oracle.pointnet_oracle.forward_torch(choices=...)``).  With those fixed both sides evaluate the
 same smooth function and must agree to rounding error.  The forward is NOT excused by this: loss / log-probs / trans
 are also compared with the oracle's own free-running forward."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -60,23 +62,31 @@ def _gate(B, N, k, kind, dev, seed):
     # how many decisions differ from the oracle's own is reported, not asserted (it is what makes the plain
     # comparison flip-limited); the imposed evaluation must still reproduce the forward
     assert abs(loss_r.item() - loss_f.item()) <= 1e-5 and (logp_r - logp_f).abs().max().item() <= 1e-4
-    worst, rows = ("", 0.0), []
+    worst, rows, zeros = ("", 0.0), [], []
     for n, g in grads.items():
         ref = g64[n]
         if ".bias" in n and ("conv" in n or n.endswith("fc1.bias") or n.endswith("fc2.bias")):
             # a bias ahead of a train-mode BatchNorm: exactly zero in exact arithmetic
             scale = max(v.double().abs().max().item() for v in g64.values())
             assert ref.double().abs().max().item() <= 1e-9 * max(scale, 1.0), n
-            assert g.abs().max().item() <= 1e-4, (n, g.abs().max().item())
+            zeros.append((n, g.abs().max().item()))
             continue
         r = _rel(g, ref)
         rows.append((n, r))
         if r > worst[1]:
             worst = (n, r)
-        assert r <= 1e-3, (n, r)
+    short = lambda n: n.replace("feat.", "f.").replace("weight", "w").replace("bias", "b")
+    extra = ""
+    if os.environ.get("PNGPD_GATE_DIAG") == "1":
+        # diagnosis only (never part of the bar): the oracle's own fp32 run at the same imposed decisions
+        _, _, _, g32, _ = oracle_train_step_on_device(sd, x, y, torch.float32, dev, choices=ch)
+        extra = " | ATen-fp32 at the same decisions: " + " ".join(f"{short(n)}:{_rel(g32[n], g64[n]):.1e}" for n, _ in rows)
     print(f"[gate B={B} N={N} k={k} {kind}] loss {loss.item():.6f} (oracle {loss_f.item():.6f}); "
-          f"worst gradient {worst[0]} rel {worst[1]:.2e}; "
-          + " ".join(f"{n.replace('feat.', 'f.').replace('weight', 'w').replace('bias', 'b')}:{r:.1e}" for n, r in rows))
+          f"worst gradient {worst[0]} rel {worst[1]:.2e}; " + " ".join(f"{short(n)}:{r:.1e}" for n, r in rows) + extra)
+    for n, v in zeros:
+        assert v <= 1e-4, (n, v)
+    for n, r in rows:
+        assert r <= 1e-3, (n, r)
 
 
 def test_gradient_gate_bench_size(cuda_device):

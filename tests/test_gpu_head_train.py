@@ -171,10 +171,12 @@ def test_bn1d_train_kernels_vs_fp64(B, C, relu, cuda_device):
     assert rel_max(bufs[0], rm) <= 1e-6 and rel_max(bufs[1], rv) <= 4e-6 and int(bufs[2].item()) == 1
     assert rel_max(dg, gr.grad) <= 1e-4 and rel_max(db, br.grad) <= 1e-4
     if B == 2:
-        # both normalised values are -/+1 whatever z is: dz is exactly 0 in exact arithmetic
+        # both normalised values are -/+ (1 - O(eps / var)) whatever z is: dz is a residue of terms that cancel —
+        # relative bar + 2e-6 of the terms it cancels from
         sd = (z64.var(0, unbiased=False) + 1e-5).sqrt()
-        U = (gam.abs() / sd) * 3 * dy64.abs().max(0).values
-        assert (dz.double().cpu().abs() <= 2e-6 * U + 1e-12).all()
+        U = ((gam.abs() / sd) * 3 * dy64.abs().max(0).values).max().item()
+        err = (dz.double().cpu() - zr.grad).abs().max().item()
+        assert err <= 1e-4 * zr.grad.abs().max().item() + 2e-6 * U, (err, zr.grad.abs().max().item(), U)
     else:
         assert rel_max(dz, zr.grad) <= 1e-4, rel_max(dz, zr.grad)
 
