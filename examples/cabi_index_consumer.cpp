@@ -1,0 +1,363 @@
+// A second torch-free consumer of libpngpd.so for the INDEX-HEAVY kernels — the stream-compaction / radix-select /
+// gather kernels of the crop, the GPG sampler and the GPD baseline (include/pngpd.h sections "Batched in-gripper crop",
+// "GPG grasp-candidate sampler", "GPD baseline"): the entries most likely to index out of bounds.  It exists to be run
+// under AddressSanitizer (`make asan`, tools/asan_run.sh; VERDICT r3 missing #5), on shapes chosen to hit the edges:
+// more in-box points than max_keep (truncated index lists + the re-scan path of the resampler), fewer than N (with
+// replacement), empty hands, arena ranges and gather lists, a pose count that lives on the device, out-of-box points
+// and NaN normals in the projection, a ragged last block in the depth scan.  Every result is summarised in one line so
+// that the uninstrumented build can be compared with the Python binding if wanted; under ASan the point is a clean exit.
+//
+// build:  hipcc --offload-arch=gfx950 -O2 -Iinclude examples/cabi_index_consumer.cpp -Lpointnetgpd_amd -lpngpd \
+//               -Wl,-rpath,'$ORIGIN/../pointnetgpd_amd' -o examples/cabi_index_consumer
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <limits>
+#include <vector>
+
+#include "pngpd.h"
+
+#define HIP_OK(e)                                                                        \
+    do {                                                                                 \
+        hipError_t _e = (e);                                                             \
+        if (_e != hipSuccess) { std::fprintf(stderr, "HIP: %s (line %d)\n", hipGetErrorString(_e), __LINE__); return 2; } \
+    } while (0)
+#define PN_OK(e)                                                                         \
+    do {                                                                                 \
+        int _s = (e);                                                                    \
+        if (_s != PNGPD_OK) { std::fprintf(stderr, "pngpd: %s (%d) at line %d\n", pngpd_strerror(_s), _s, __LINE__); return 3; } \
+    } while (0)
+
+struct Lcg {
+    uint32_t s;
+    double next() { s = s * 1664525u + 1013904223u; return (double)(s >> 8) * (1.0 / 16777216.0) - 0.5; }   // [-0.5, 0.5)
+    int below(int n) { s = s * 1664525u + 1013904223u; return (int)((s >> 8) % (uint32_t)n); }
+};
+
+template <class T>
+static int upload(const std::vector<T> &h, T **d) {
+    HIP_OK(hipMalloc((void **)d, (h.size() ? h.size() : 1) * sizeof(T)));
+    if (h.size()) HIP_OK(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+template <class T>
+static int dalloc(T **d, size_t n) {
+    HIP_OK(hipMalloc((void **)d, (n ? n : 1) * sizeof(T)));
+    HIP_OK(hipMemset(*d, 0, (n ? n : 1) * sizeof(T)));
+    return 0;
+}
+template <class T>
+static int download(const T *d, std::vector<T> &h) {
+    HIP_OK(hipMemcpy(h.data(), d, h.size() * sizeof(T), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// an orthonormal frame from a pseudo-random unit quaternion: rows approach, binormal, minor
+static void random_rows(Lcg &g, double R[9]) {
+    double q[4], n = 0;
+    for (double &v : q) { v = g.next() * 2; n += v * v; }
+    n = std::sqrt(n > 1e-12 ? n : 1.0);
+    const double w = q[0] / n, x = q[1] / n, y = q[2] / n, z = q[3] / n;
+    const double M[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                         2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                         2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[i * 3 + j] = M[j * 3 + i];   // rows = columns of M
+}
+
+static int run();
+
+int main() {
+    const int rc = run();
+    std::fflush(stdout);
+    std::fflush(stderr);
+#if defined(__SANITIZE_ADDRESS__)
+    std::_Exit(rc);
+#elif defined(__has_feature)
+#if __has_feature(address_sanitizer)
+    std::_Exit(rc);
+#endif
+#endif
+    return rc;
+}
+
+static int run() {
+    if (pngpd_abi_version() != PNGPD_ABI_VERSION) { std::fprintf(stderr, "ABI mismatch\n"); return 1; }
+    hipStream_t st;
+    HIP_OK(hipStreamCreate(&st));
+    Lcg g{2024u};
+    // robotiq_85 (dex-net/data/grippers/robotiq_85/params.json)
+    const double OD = 0.218, FW = 0.0255, HD = 0.125, HH = 0.030, BITE = 0.01;
+    const double OW = OD - 2 * FW;
+
+    // ---- scene cloud: P points in [-0.1, 0.1]^2 x [0, 0.12], fp32 like kinect2grasp.py:112 (and an fp64 copy)
+    const int P = 3000;
+    std::vector<float> pc32((size_t)P * 3);
+    std::vector<double> pc64((size_t)P * 3), nrm((size_t)P * 3);
+    for (int i = 0; i < P; ++i) {
+        const double v[3] = {g.next() * 0.2, g.next() * 0.2, (g.next() + 0.5) * 0.12};
+        for (int k = 0; k < 3; ++k) { pc32[i * 3 + k] = (float)v[k]; pc64[i * 3 + k] = (double)(float)v[k]; nrm[i * 3 + k] = g.next(); }
+    }
+    float *dpc32; double *dpc64, *dnrm;
+    if (upload(pc32, &dpc32) || upload(pc64, &dpc64) || upload(nrm, &dnrm)) return 2;
+
+    // =====================================================================================================
+    // crop: count / compact (plain, arena ranges, gather lists) and resample
+    // =====================================================================================================
+    const int G = 12, MAXK = 64, N = 128;
+    std::vector<double> fr((size_t)G * 18);
+    for (int gi = 0; gi < G; ++gi) {
+        double *f = &fr[(size_t)gi * 18];
+        double R[9];
+        random_rows(g, R);
+        const int p = g.below(P);
+        for (int k = 0; k < 3; ++k) f[k] = pc64[p * 3 + k] - 0.05 * R[k];          // hand bottom 5 cm behind a point
+        for (int k = 0; k < 9; ++k) f[3 + k] = R[k];
+        double lo[3] = {0.0, -OW / 2, -OW / 4}, hi[3] = {HD, OW / 2, OW / 4};       // kinect2grasp.py:218-221
+        if (gi == 0) { lo[0] = lo[1] = lo[2] = -10; hi[0] = hi[1] = hi[2] = 10; }    // every point: count = P >> max_keep
+        if (gi == 1) { for (int k = 0; k < 3; ++k) f[k] = 50.0; }                     // empty hand
+        if (gi == 2) { hi[0] = 0.02; hi[1] = 0.02; lo[1] = -0.02; }                   // a handful of points: count < N
+        if (gi == 3) { lo[0] = lo[1] = lo[2] = -0.08; hi[0] = hi[1] = hi[2] = 0.08; } // max_keep < count, partly
+        for (int k = 0; k < 3; ++k) { f[12 + k] = lo[k]; f[15 + k] = hi[k]; }
+    }
+    double *dfr; int *dcnt, *didx; float *dout; unsigned char *dvalid;
+    if (upload(fr, &dfr) || dalloc(&dcnt, G) || dalloc(&didx, (size_t)G * MAXK) || dalloc(&dout, (size_t)G * 3 * N) ||
+        dalloc(&dvalid, G)) return 2;
+    std::vector<int> cnt(G);
+    std::vector<unsigned char> valid(G);
+    std::vector<float> out((size_t)G * 3 * N);
+    auto report = [&](const char *tag) -> int {
+        HIP_OK(hipStreamSynchronize(st));
+        if (download(dcnt, cnt) || download(dvalid, valid) || download(dout, out)) return 2;
+        long csum = 0; int nv = 0; double a = 0;
+        for (int i = 0; i < G; ++i) { csum += cnt[i]; nv += valid[i]; }
+        for (float v : out) a += std::fabs(v);
+        std::printf("%s counts_sum %ld c0 %d c1 %d c2 %d valid %d out_abs %.6e\n", tag, csum, cnt[0], cnt[1], cnt[2], nv, a);
+        return 0;
+    };
+    for (int f64 = 0; f64 < 2; ++f64) {
+        const void *cl = f64 ? (const void *)dpc64 : (const void *)dpc32;
+        PN_OK(pngpd_crop_count_compact(cl, f64, P, dfr, G, MAXK, dcnt, didx, st));
+        for (int mode = 0; mode < 2; ++mode)
+            PN_OK(pngpd_crop_resample(cl, f64, P, dfr, nullptr, nullptr, 0, G, dcnt, didx, MAXK, N, mode, 20, 77ull + mode,
+                                      nullptr, dout, dvalid, st));
+        if (report(f64 ? "crop_f64" : "crop_f32")) return 2;
+    }
+    {   // injected ranks (tests' path): sel (G,N) in [0, min(count, max_keep))
+        PN_OK(pngpd_crop_count_compact(dpc32, 0, P, dfr, G, MAXK, dcnt, didx, st));
+        HIP_OK(hipStreamSynchronize(st));
+        if (download(dcnt, cnt)) return 2;
+        std::vector<int> sel((size_t)G * N);
+        for (int gi = 0; gi < G; ++gi) {
+            const int m = cnt[gi] < MAXK ? cnt[gi] : MAXK;
+            for (int i = 0; i < N; ++i) sel[(size_t)gi * N + i] = m > 0 ? g.below(m) : 0;
+        }
+        int *dsel;
+        if (upload(sel, &dsel)) return 2;
+        PN_OK(pngpd_crop_resample(dpc32, 0, P, dfr, nullptr, nullptr, 0, G, dcnt, didx, MAXK, N, 1, 20, 0ull, dsel, dout,
+                                  dvalid, st));
+        if (report("crop_sel")) return 2;
+    }
+    {   // arena ranges: grasp g sees [start, start + len) only; the last range ends exactly at P, one is empty
+        std::vector<int> rng((size_t)G * 2);
+        for (int gi = 0; gi < G; ++gi) { rng[gi * 2] = (gi * 251) % (P - 700); rng[gi * 2 + 1] = 700; }
+        rng[0] = 0; rng[1] = P;                       // the whole arena (count > max_keep: re-scan over a range)
+        rng[2 * 5] = P - 700; rng[2 * 5 + 1] = 700;   // touches the end of the arena
+        rng[2 * 6 + 1] = 0;                           // an empty range
+        int *drng;
+        if (upload(rng, &drng)) return 2;
+        PN_OK(pngpd_crop_count_compact_ranges(dpc64, 1, P, dfr, drng, G, MAXK, dcnt, didx, st));
+        PN_OK(pngpd_crop_resample(dpc64, 1, P, dfr, drng, nullptr, 0, G, dcnt, didx, MAXK, N, 0, 50, 5ull, nullptr, dout,
+                                  dvalid, st));
+        if (report("crop_ranges")) return 2;
+    }
+    {   // gather lists: Pg rows per grasp, arena-absolute, duplicates allowed (full-view datasets, dataset.py:252-254)
+        const int Pg = 500;
+        std::vector<int> gat((size_t)G * Pg);
+        for (auto &v : gat) v = g.below(P);
+        for (int i = 0; i < Pg; ++i) gat[i] = P - 1 - (i % 7);        // grasp 0 (the all-inclusive box): the arena's tail
+        int *dgat;
+        if (upload(gat, &dgat)) return 2;
+        PN_OK(pngpd_crop_count_compact_gather(dpc64, 1, P, dfr, dgat, Pg, G, MAXK, dcnt, didx, st));
+        PN_OK(pngpd_crop_resample(dpc64, 1, P, dfr, nullptr, dgat, Pg, G, dcnt, didx, MAXK, N, 0, 50, 9ull, nullptr, dout,
+                                  dvalid, st));
+        if (report("crop_gather")) return 2;
+    }
+
+    // =====================================================================================================
+    // GPG sampler kernels
+    // =====================================================================================================
+    {
+        const int K = 9;
+        std::vector<double> q((size_t)K * 3);
+        for (int i = 0; i < K; ++i) { const int p = g.below(P); for (int k = 0; k < 3; ++k) q[i * 3 + k] = pc64[p * 3 + k]; }
+        q[0] = q[1] = q[2] = 9.0;                                     // a query with an empty ball
+        double *dq, *dM; int *dns;
+        if (upload(q, &dq) || dalloc(&dM, (size_t)K * 9) || dalloc(&dns, K)) return 2;
+        const double rball = OD - FW;
+        PN_OK(pngpd_gpg_normal_moments(dpc32, 0, dnrm, P, dq, K, rball, 100, dM, dns, st));
+        PN_OK(pngpd_gpg_normal_moments(dpc64, 1, dnrm, P, dq, K, rball, 7, dM, dns, st));   // max_nn << ball: the cut path
+        HIP_OK(hipStreamSynchronize(st));
+        std::vector<int> ns(K);
+        if (download(dns, ns)) return 2;
+        std::printf("gpg_moments nsel %d %d %d\n", ns[0], ns[1], ns[K - 1]);
+    }
+    // hand boxes in the grasp frame (the four boxes of check_collision_square, coarse but valid bounds)
+    std::vector<double> boxes = {0.0, HD, -OW / 2, OW / 2, -HH / 2, HH / 2,              // open region
+                                 0.0, HD, -OW / 2 - FW, -OW / 2, -HH / 2, HH / 2,        // left finger
+                                 0.0, HD, OW / 2, OW / 2 + FW, -HH / 2, HH / 2,          // right finger
+                                 -HH, 0.0, -OW / 2 - FW, OW / 2 + FW, -HH / 2, HH / 2};  // bottom
+    double *dboxes;
+    if (upload(boxes, &dboxes)) return 2;
+    // The sampler chain runs on an OBJECT-like cloud — a 2 cm thick wall the hand can straddle — so that the sweep finds
+    // admissible poses and the select / push-in / finish kernels see non-empty lists (in the random volume above every
+    // finger collides and the chain would only exercise its empty path).
+    const int PW = 3000;
+    std::vector<float> wall((size_t)PW * 3);
+    std::vector<double> wall64((size_t)PW * 3);
+    for (int i = 0; i < PW; ++i) {
+        const double v[3] = {g.next() * 0.02, g.next() * 0.16, 0.03 + (g.next() + 0.5) * 0.09};
+        for (int k = 0; k < 3; ++k) { wall[i * 3 + k] = (float)v[k]; wall64[i * 3 + k] = (double)(float)v[k]; }
+    }
+    float *dwall;
+    if (upload(wall, &dwall)) return 2;
+    // spheres of consecutive 64-point chunks of the (unsorted) cloud: valid bounds, just looser than Morton order's
+    const int C = (PW + 63) / 64;
+    std::vector<double> sph((size_t)C * 4);
+    for (int c = 0; c < C; ++c) {
+        double lo[3] = {1e9, 1e9, 1e9}, hi[3] = {-1e9, -1e9, -1e9};
+        for (int i = c * 64; i < (c + 1) * 64 && i < PW; ++i)
+            for (int k = 0; k < 3; ++k) { lo[k] = std::fmin(lo[k], wall64[i * 3 + k]); hi[k] = std::fmax(hi[k], wall64[i * 3 + k]); }
+        double r = 0;
+        for (int k = 0; k < 3; ++k) { sph[c * 4 + k] = 0.5 * (lo[k] + hi[k]); r += 0.25 * (hi[k] - lo[k]) * (hi[k] - lo[k]); }
+        sph[c * 4 + 3] = std::sqrt(r) + 1e-9;
+    }
+    double *dsph;
+    if (upload(sph, &dsph)) return 2;
+    {
+        // the whole selection chain for L live sample points
+        const int L = 14, R = 19, D = 21, S = (int)(HD / 0.005);
+        std::vector<double> frames((size_t)L * 12, 0.0), prm(160, 0.0);
+        for (int l = 0; l < L; ++l) {
+            double *f = &frames[(size_t)l * 12];
+            if (l < 12) {   // minor = e_a, normal = +-e_b (a != b), major = minor x normal: every axis assignment of the wall
+                const int a = l % 3, b = (a + 1 + (l / 3) % 2) % 3;
+                const double sg = (l / 6) ? -1.0 : 1.0;
+                f[a] = 1.0; f[3 + b] = sg;
+                f[6] = f[1] * f[5] - f[2] * f[4]; f[7] = f[2] * f[3] - f[0] * f[5]; f[8] = f[0] * f[4] - f[1] * f[3];
+            } else {
+                random_rows(g, f);
+            }
+            const int p = g.below(PW);
+            for (int k = 0; k < 3; ++k) f[9 + k] = wall64[p * 3 + k];
+        }
+        const double head[13] = {BITE, HD, HD * 0.5, 0.005, 0.01, HH * 0.5, -(HH * 0.5), -(OW * 0.5), OW * 0.5, -FW, FW, -HH, 3.0};
+        for (int i = 0; i < 13; ++i) prm[i] = head[i];
+        for (int r = 0; r < R; ++r) prm[16 + r] = (-90.0 + 10.0 * r) / 180.0 * M_PI;
+        for (int d = 0; d < D; ++d) prm[48 + d] = -10 * FW + d * FW;
+        for (int s = 0; s < S; ++s) prm[80 + s] = (double)s;
+        const int cap = L * R;
+        double *dframes, *dprm, *dposes, *dab, *dposes2, *dback, *dmod, *dres;
+        int *dcounts, *dflag, *ddsel, *dlist, *dtotal, *dcounts2, *dfound, *dsfirst, *dolist, *dototal;
+        if (upload(frames, &dframes) || upload(prm, &dprm) || dalloc(&dposes, (size_t)cap * D * 12) || dalloc(&dab, (size_t)cap * 6) ||
+            dalloc(&dcounts, (size_t)cap * D * 4) || dalloc(&dflag, cap) || dalloc(&ddsel, cap) || dalloc(&dlist, cap) ||
+            dalloc(&dtotal, 1) || dalloc(&dposes2, (size_t)cap * S * 2 * 12) || dalloc(&dback, (size_t)cap * S * 3) ||
+            dalloc(&dmod, (size_t)cap * S * 3) || dalloc(&dcounts2, (size_t)cap * S * 2 * 4) || dalloc(&dfound, cap) ||
+            dalloc(&dsfirst, cap) || dalloc(&dolist, cap) || dalloc(&dototal, 1) || dalloc(&dres, (size_t)1 + L + cap * 15)) return 2;
+        PN_OK(pngpd_gpg_enumerate(dframes, L, R, D, dprm, dposes, dab, st));
+        // brute force and indexed sweeps must agree
+        int *dcounts_bf;
+        if (dalloc(&dcounts_bf, (size_t)cap * D * 4)) return 2;
+        PN_OK(pngpd_hand_box_counts(dwall, 0, PW, dposes, cap * D, dboxes, 4, dcounts_bf, st));
+        PN_OK(pngpd_hand_box_counts_indexed(dwall, 0, PW, dsph, C, dposes, cap * D, dboxes, 4, dcounts, st));
+        PN_OK(pngpd_gpg_select(dcounts, dposes, dab, L, R, D, dprm, dflag, ddsel, dlist, dtotal, st));
+        PN_OK(pngpd_gpg_pushin(dlist, dtotal, ddsel, dposes, dab, dframes, L, R, D, S, dprm, dposes2, dback, dmod, st));
+        // the number of valid poses lives on the device: the launch covers the buffer's capacity
+        PN_OK(pngpd_hand_box_counts_indexed_n(dwall, 0, PW, dsph, C, dposes2, cap * S * 2, dboxes, 4, dtotal, 2 * S, dcounts2, st));
+        PN_OK(pngpd_gpg_finish(dcounts2, dlist, dtotal, dab, dframes, dback, dmod, L, R, S, 10, dfound, dsfirst, dolist,
+                               dototal, dres, st));
+        HIP_OK(hipStreamSynchronize(st));
+        std::vector<int> c1((size_t)cap * D * 4), c2((size_t)cap * D * 4), tot(1);
+        std::vector<double> res((size_t)1 + L + cap * 15);
+        if (download(dcounts_bf, c1) || download(dcounts, c2) || download(dtotal, tot) || download(dres, res)) return 2;
+        long diff = 0, s1 = 0;
+        for (size_t i = 0; i < c1.size(); ++i) { diff += c1[i] != c2[i]; s1 += c1[i]; }
+        std::printf("gpg_chain sweep_counts %ld indexed_vs_bruteforce_mismatches %ld potential %d found %.0f\n", s1, diff, tot[0], res[0]);
+        if (diff) { std::fprintf(stderr, "indexed counts differ from brute force\n"); return 4; }
+        // single-box variant and Q = 1
+        PN_OK(pngpd_hand_box_counts(dwall, 0, PW, dposes, 1, dboxes, 1, dcounts_bf, st));
+        PN_OK(pngpd_hand_box_counts_indexed_n(dwall, 0, PW, dsph, C, dposes, 1, dboxes, 1, nullptr, 1, dcounts, st));
+        HIP_OK(hipStreamSynchronize(st));
+    }
+
+    // =====================================================================================================
+    // GPD baseline: projection images (out-of-box points, NaN normals), depth registration, LeNet stem
+    // =====================================================================================================
+    {
+        const int Gp = 3;
+        std::vector<int> off = {0, 700, 700, 1500};                     // the middle grasp has no points at all
+        std::vector<double> pts((size_t)off[Gp] * 3), nr((size_t)off[Gp] * 3), wid = {0.085, 0.085, 0.06};
+        for (size_t i = 0; i < pts.size(); ++i) { pts[i] = g.next() * 0.12; nr[i] = g.next(); }   // |coord| up to 0.06 > w/2: out of the image
+        for (int i = 0; i < 40; ++i) pts[(size_t)i * 3 + (i % 3)] = (i & 1 ? 1 : -1) * (0.5 + i);   // far outside on either side
+        nr[5 * 3 + 1] = std::numeric_limits<double>::quiet_NaN();
+        nr[900 * 3] = std::numeric_limits<double>::quiet_NaN();
+        double *dpts, *dnr, *dwid, *dimg; int *doff;
+        if (upload(pts, &dpts) || upload(nr, &dnr) || upload(wid, &dwid) || upload(off, &doff) ||
+            dalloc(&dimg, (size_t)Gp * 60 * 60 * 12)) return 2;
+        for (int chann : {12, 3}) {
+            PN_OK(pngpd_gpd_projection(dpts, dnr, doff, dwid, Gp, chann, 60, 1, 50, dimg, st));
+            HIP_OK(hipStreamSynchronize(st));
+            std::vector<double> img((size_t)Gp * 60 * 60 * chann);
+            HIP_OK(hipMemcpy(img.data(), dimg, img.size() * sizeof(double), hipMemcpyDeviceToHost));
+            double a = 0;
+            for (double v : img) a += std::fabs(v);
+            std::printf("gpd_projection chann %d abs %.9e\n", chann, a);
+        }
+        // depth registration on images whose size is not a multiple of the 256-pixel scan block
+        const int hd = 50, wd = 70, hr = 45, wr = 66;
+        std::vector<double> depth((size_t)hd * wd), cam20(20), cam28(28);
+        for (auto &v : depth) v = g.below(5) == 0 ? 0.0 : 0.6 + (g.next() + 0.5) * 0.4;
+        const double k1[4] = {60.0, 60.0, wd / 2.0, hd / 2.0}, k2[4] = {58.0, 58.0, wr / 2.0, hr / 2.0};
+        for (int i = 0; i < 4; ++i) { cam20[i] = k1[i]; cam20[4 + i] = k2[i]; cam28[i] = k2[i]; }
+        const double Hm[12] = {1, 0, 0, 0.01, 0, 1, 0, -0.02, 0, 0, 1, 0.005};
+        for (int i = 0; i < 12; ++i) { cam20[8 + i] = Hm[i]; cam28[4 + i] = Hm[i]; cam28[16 + i] = Hm[(i + 4) % 12 == 3 ? i : i]; }
+        std::vector<unsigned char> rgb((size_t)hr * wr * 3);
+        for (auto &v : rgb) v = (unsigned char)g.below(256);
+        double *ddepth, *dc20, *dc28, *dreg, *dxyz; unsigned char *drgb, *drgbo; int *dcount; void *dws;
+        const size_t wsb = pngpd_depth_cloud_workspace_bytes(hr, wr);
+        if (upload(depth, &ddepth) || upload(cam20, &dc20) || upload(cam28, &dc28) || dalloc(&dreg, (size_t)hr * wr) ||
+            dalloc(&dxyz, (size_t)hr * wr * 3) || upload(rgb, &drgb) || dalloc(&drgbo, (size_t)hr * wr * 3) || dalloc(&dcount, 1)) return 2;
+        HIP_OK(hipMalloc(&dws, wsb ? wsb : 4));
+        PN_OK(pngpd_depth_register(ddepth, hd, wd, dc20, hr, wr, dreg, st));
+        if (wsb > 8 && pngpd_depth_to_cloud(dreg, hr, wr, dc28, drgb, dxyz, drgbo, dcount, dws, 8, st) != PNGPD_ERR_WORKSPACE) {
+            std::fprintf(stderr, "workspace check missing\n"); return 4;
+        }
+        PN_OK(pngpd_depth_to_cloud(dreg, hr, wr, dc28, drgb, dxyz, drgbo, dcount, dws, wsb, st));
+        PN_OK(pngpd_depth_to_cloud(dreg, hr, wr, dc28, nullptr, dxyz, nullptr, dcount, dws, wsb, st));   // no colours
+        HIP_OK(hipStreamSynchronize(st));
+        std::vector<int> cn(1);
+        if (download(dcount, cn)) return 2;
+        std::printf("depth_cloud points %d of %d\n", cn[0], hr * wr);
+        // GPDClassifier stem: conv5 + pool2 twice (gpd.py:8-13), odd batch
+        const int Bc = 3;
+        std::vector<float> in((size_t)Bc * 12 * 60 * 60), w1((size_t)20 * 12 * 25), b1(20), w2((size_t)50 * 20 * 25), b2(50);
+        for (auto &v : in) v = (float)g.next();
+        for (auto &v : w1) v = (float)g.next() * 0.1f;
+        for (auto &v : w2) v = (float)g.next() * 0.1f;
+        float *din, *dw1, *db1, *dw2, *db2, *dh1, *dh2;
+        if (upload(in, &din) || upload(w1, &dw1) || upload(b1, &db1) || upload(w2, &dw2) || upload(b2, &db2) ||
+            dalloc(&dh1, (size_t)Bc * 20 * 28 * 28) || dalloc(&dh2, (size_t)Bc * 50 * 12 * 12)) return 2;
+        PN_OK(pngpd_conv5_pool2(din, Bc, 12, 60, dw1, db1, 20, dh1, st));
+        PN_OK(pngpd_conv5_pool2(dh1, Bc, 20, 28, dw2, db2, 50, dh2, st));
+        HIP_OK(hipStreamSynchronize(st));
+        std::vector<float> h2((size_t)Bc * 50 * 12 * 12);
+        if (download(dh2, h2)) return 2;
+        double a = 0;
+        for (float v : h2) a += std::fabs(v);
+        std::printf("gpd_stem abs %.6e\n", a);
+    }
+    std::printf("index consumer done\n");
+    return 0;
+}

@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256, 4) void trunk_bwd_gather_kernel(   // 4 workgr
 #define REFINE_LDS_FLOATS (TP * H1S + TP * H2S + 8 * TP)
 
 template <int VARIANT>
-__global__ __launch_bounds__(256, 3) void trunk_pool_refine_kernel(
+__global__ __launch_bounds__(256, 2) void trunk_pool_refine_kernel(
     const float *__restrict__ x, int B, int N, const float *__restrict__ trans, TrainChan P,
     const float *__restrict__ w3sp, const float *__restrict__ w3, const float *__restrict__ g3,
     const int *__restrict__ idx, int clouds_per_range, float *__restrict__ zex) {
@@ -471,9 +471,18 @@ __global__ __launch_bounds__(256, 3) void trunk_pool_refine_kernel(
     const L1C l1c = load_l1c(P.w1, P.b1, P.s1c, P.t1c, L);
     f32x4 w3f[16];   // VARIANT 0, waves 0 / 1: the sign-folded layer-3 fragments of channel block 2 cc + wave, resident
     if (VARIANT == 0 && L.wave < 2) load_wfrag(w3f, w3sp, cc * 2 + L.wave, L);
-    // VARIANT > 0: lane p of the cloud's duty wave owns channel c = 64 cc + p: its raw weight row and sign
-    const float *wrow = w3 + (size_t)(cc * 64 + L.lane) * 128;
+    // VARIANT > 0: lane p of a cloud's duty wave owns channel c = 64 cc + p.  Its sign-folded weight row (128 values)
+    // stays in REGISTERS for the whole kernel (every wave holds it: the duty rotates over the SIMDs with the cloud) —
+    // fetched per cloud from L2 it was 32 uncoalesced 16-byte loads (64 lines each) on the critical path of every
+    // cloud: 293 us per launch at B = N = 1024 against 96 us for the gather pass that does the same layers 1-2.
+    constexpr bool WREG = VARIANT == 1 || VARIANT == 2;     // (variant 3 is a probe only: it streams its row from L2)
+    f32x4 wr[WREG ? 32 : 1];
+    const f32x4 *wrow = (const f32x4 *)(w3 + (size_t)(cc * 64 + L.lane) * 128);
     const bool neg = VARIANT > 0 && g3[cc * 64 + L.lane] < 0.f;
+    if constexpr (WREG) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { wr[i] = wrow[i]; if (neg) wr[i] = -wr[i]; }
+    }
     float nx0 = 0.f, nx1 = 0.f, nx2 = 0.f;
     auto fetch = [&](int b) {
         if (L.tid < TP && b < b1) {
@@ -537,11 +546,12 @@ __global__ __launch_bounds__(256, 3) void trunk_pool_refine_kernel(
                 const float *hr = h2 + L.lane * H2S;
                 float acc = 0.f;
                 double accd = 0.0;
-#pragma unroll 4
+#pragma unroll
                 for (int kb = 0; kb < 16; ++kb) {
                     const f32x4 alo = *(const f32x4 *)(hr + kb * 8), ahi = *(const f32x4 *)(hr + kb * 8 + 4);
-                    f32x4 wlo = *(const f32x4 *)(wrow + kb * 8), whi = *(const f32x4 *)(wrow + kb * 8 + 4);
-                    if (neg) { wlo = -wlo; whi = -whi; }
+                    f32x4 wlo, whi;
+                    if constexpr (WREG) { wlo = wr[2 * kb]; whi = wr[2 * kb + 1]; }
+                    else { wlo = wrow[2 * kb]; whi = wrow[2 * kb + 1]; if (neg) { wlo = -wlo; whi = -whi; } }
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         if (VARIANT == 1) { acc = fmaf(alo[t], wlo[t], acc); acc = fmaf(ahi[t], whi[t], acc); }
