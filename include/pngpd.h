@@ -366,7 +366,8 @@ typedef struct pngpd_head_train {
     float *out;            /* (B,k) forward output (read again by the backward of log_softmax)                       */
     const float *gout;     /* (B,k) backward input: dL/dout                                                          */
     float *dinp;           /* (B,K0) backward output or NULL                                                         */
-    float *dW1, *db1, *dg1, *dbe1, *dW2, *db2, *dg2, *dbe2, *dW3, *db3;
+    float *dW1, *db1, *dg1, *dbe1, *dW2, *db2, *dg2, *dbe2, *dW3, *db3;   /* db1 / db2 (biases ahead of a train-mode
+                              BatchNorm: exactly zero in exact arithmetic) are written as exact zeros               */
     void *save;    size_t save_bytes;
     void *scratch; size_t scratch_bytes;   /* backward only */
 } pngpd_head_train_t;

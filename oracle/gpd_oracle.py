@@ -6,7 +6,7 @@ Restates, in vectorised numpy / functional torch (citations relative to /root/re
 
 * ``cal_projection`` / ``project_pc``              PointNetGPD/model/dataset.py:88-198
 * ``registerDepthMap``                             PointNetGPD/ycb_cloud_generate.py:60-121
-* ``registeredDepthMapToPointCloud`` (unorganised) PointNetGPD/ycb_cloud_generate.py:124-184
+* ``registeredDepthMapToPointCloud`` (unorganised and organised) PointNetGPD/ycb_cloud_generate.py:124-184
 * ``GPDClassifier.forward``                        PointNetGPD/model/gpd.py:21-31
 
 Parity pin: ``oracle/make_golden_gpd.py`` EXECUTES the unmodified reference functions in the build container (the
@@ -114,6 +114,18 @@ def depth_map_to_cloud(depth, rgbK, refFromRGB, objFromref):
     return np.stack([O[0, 0] * x1 + O[0, 1] * y1 + O[0, 2] * z1 + O[0, 3],
                      O[1, 0] * x1 + O[1, 1] * y1 + O[1, 2] * z1 + O[1, 3],
                      O[2, 0] * x1 + O[2, 1] * y1 + O[2, 2] * z1 + O[2, 3]], 1)
+
+
+def depth_map_to_cloud_organized(depth, rgb, rgbK, refFromRGB, objFromref):
+    """ycb_cloud_generate.py:124-184 with organized=True: (h,w,6) — xyz + colour where depth > 0, NaN xyz and zero colour
+    where depth <= 0 (:147-155)."""
+    h, w = depth.shape
+    out = np.zeros((h, w, 6))
+    out[:, :, :3] = np.nan
+    good = depth > 0
+    out[good, :3] = depth_map_to_cloud(depth, rgbK, refFromRGB, objFromref)
+    out[good, 3:] = np.asarray(rgb)[good]
+    return out
 
 
 def gpd_forward_torch(sd, x):

@@ -112,6 +112,9 @@ def cloudgen_cases():
         rec[f"{tag}/cloud_rows"] = rows; rec[f"{tag}/cloud_val"] = cloud[rows]
         if tag == "small":
             rec[f"{tag}/registered"] = reg; rec[f"{tag}/cloud"] = cloud
+            # organized=True (:130-155): the (h,w,6) grid with NaN xyz / zero colour at the pixels without depth
+            rec[f"{tag}/cloud_organized"] = to_cloud(reg_m, sc["rgb"], sc["rgbK"], sc["refFromRGB"], sc["objFromref"],
+                                                     organized=True)
         print("cloudgen", tag, "registered nonzero", int((reg > 0).sum()), "cloud points", len(cloud))
     np.savez_compressed(os.path.join(OUT, "gpd_cloudgen.npz"), tags=np.array(list(synth_gpd.SCENES)), **rec)
 

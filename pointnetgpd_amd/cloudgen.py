@@ -17,8 +17,9 @@ def registerDepthMap(unregisteredDepthMap, rgbImage, depthK, rgbK, H_RGBFromDept
 
 
 def registeredDepthMapToPointCloud(depthMap, rgbImage, rgbK, refFromRGB, objFromref, organized=False):
-    if organized:
-        raise NotImplementedError("organized=True is never used by the reference's generate() (:370)")
+    if organized:      # (h,w,6): NaN xyz / zero colour where depth <= 0 (:147-155); never used by the reference's generate() (:370)
+        return gpd_ops.depth_map_to_cloud_organized(np.asarray(depthMap, dtype=np.float64), rgbK, refFromRGB, objFromref,
+                                                    np.asarray(rgbImage)).cpu().numpy()
     xyz, col = gpd_ops.depth_map_to_cloud(np.asarray(depthMap, dtype=np.float64), rgbK, refFromRGB, objFromref,
                                           rgb=np.asarray(rgbImage))
     cloud = np.empty((1, xyz.shape[0], 6))

@@ -27,3 +27,7 @@ int pngpd_train_pack_launch(PackArgs &A, int njobs, void *stream);
 // The VALU order of pngpd_trunk_pool_refine that reproduces v_mfma_f32_32x32x2_f32 bit for bit (probed on the device:
 // tests/test_gpu_refine.py::test_valu_variant_matches_matrix_pipe).
 #define PNGPD_REFINE_VALU_VARIANT 1
+
+// pngpd_fc_bwd with the bias gradient written as an exact zero (zero_db != 0): layers that feed a train-mode BatchNorm.
+int pngpd_fc_bwd_impl(const float *g, const float *x, const float *W, int B, int K, int Nout,
+                      float *dW, float *dx, float *db, int zero_db, void *stream);

@@ -1384,7 +1384,7 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void fc_bwd_kernel(const float *__restrict__ g, const float *__restrict__ x,
                                                      const float *__restrict__ W, int B, int K, int Nout,
                                                      int tilesW, int tilesX, float *__restrict__ dW,
-                                                     float *__restrict__ dx, float *__restrict__ db) {
+                                                     float *__restrict__ dx, float *__restrict__ db, int zero_db) {
     // One WORKGROUP = one 32x32 output tile; its four waves each contract a quarter of the reduction range and meet in
     // LDS (a tile's contraction is a chain of up to 512 dependent MFMAs: one wave per tile left the launch 4x off the
     // MFMA time with 1.5 workgroups per CU; split four ways there are 6 balanced workgroups per CU).
@@ -1506,7 +1506,9 @@ __global__ __launch_bounds__(256) void fc_bwd_kernel(const float *__restrict__ g
             }
         }
         const int n = orow0 + j;
-        if (kbk == 0 && h == 0 && n < Nout) db[n] = dbs + dred[j] + dred[32 + j] + dred[64 + j];
+        // zero_db: the layer feeds a train-mode BatchNorm, whose backward makes sum_b g exactly zero in exact arithmetic
+        // (the conv biases of the trunks are treated the same way): write the exact value, not its rounding residue
+        if (kbk == 0 && h == 0 && n < Nout) db[n] = zero_db ? 0.f : dbs + dred[j] + dred[32 + j] + dred[64 + j];
     } else if (dx) {
         if (ocol < K) {
 #pragma unroll
@@ -1796,19 +1798,28 @@ int pngpd_trunk_bwd_e_bf(const float *x, int B, int N, const float *trans,
                        : launch_bwd_e<true, 3>(grid, lds, (hipStream_t)stream, x, N, trans, P, E, T, S, z2t, g2t, pc, pR, pW2);
 }
 
-int pngpd_fc_bwd(const float *g, const float *x, const float *W, int B, int K, int Nout,
-                 float *dW, float *dx, float *db, void *stream) {
+}  // extern "C"
+
+int pngpd_fc_bwd_impl(const float *g, const float *x, const float *W, int B, int K, int Nout,
+                      float *dW, float *dx, float *db, int zero_db, void *stream) {
     if (!g || !x || !W || !dW || !db || B <= 0 || K <= 0 || Nout <= 0) return PNGPD_ERR_INVALID_ARG;
     const int kblocks = (K + 31) / 32;
     const int tilesW = ((Nout + 31) / 32) * kblocks, tilesX = dx ? ((B + 31) / 32) * kblocks : 0;
     const unsigned grid = (unsigned)(tilesW + tilesX);   // one workgroup per output tile (its waves split the contraction)
     if ((Nout & 7) == 0)
         hipLaunchKernelGGL(fc_bwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, x, W, B, K, Nout,
-                           tilesW, tilesX, dW, dx, db);
+                           tilesW, tilesX, dW, dx, db, zero_db);
     else
         hipLaunchKernelGGL(fc_bwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, x, W, B, K, Nout,
-                           tilesW, tilesX, dW, dx, db);
+                           tilesW, tilesX, dW, dx, db, zero_db);
     return pngpd_launch_status();
+}
+
+extern "C" {
+
+int pngpd_fc_bwd(const float *g, const float *x, const float *W, int B, int K, int Nout,
+                 float *dW, float *dx, float *db, void *stream) {
+    return pngpd_fc_bwd_impl(g, x, W, B, K, Nout, dW, dx, db, 0, stream);
 }
 
 int pngpd_bn1d_fwd_train(const float *z, int B, int C, const float *gamma, const float *beta, float eps,

@@ -356,10 +356,11 @@ int pngpd_head_train_bwd(const pngpd_head_train_t *a, void *stream) {
     CHK(pngpd_fc_bwd(g, s.y2, a->W3, a->B, a->H2, a->k, a->dW3, w.dy2, a->db3, stream));
     CHK(pngpd_bn1d_bwd(w.dy2, s.z2, s.y2, a->B, a->H2, a->g2, s.mean2, s.var2, a->eps, 1, w.dz2, a->dg2, a->dbe2,
                        stream));
-    CHK(pngpd_fc_bwd(w.dz2, s.y1, a->W2, a->B, a->H1, a->H2, a->dW2, w.dy1, a->db2, stream));
+    // fc2.bias / fc1.bias sit ahead of a train-mode BatchNorm: their gradient is exactly zero (as for the conv biases)
+    CHK(pngpd_fc_bwd_impl(w.dz2, s.y1, a->W2, a->B, a->H1, a->H2, a->dW2, w.dy1, a->db2, 1, stream));
     CHK(pngpd_bn1d_bwd(w.dy1, s.z1, s.y1, a->B, a->H1, a->g1, s.mean1, s.var1, a->eps, 1, w.dz1, a->dg1, a->dbe1,
                        stream));
-    return pngpd_fc_bwd(w.dz1, a->inp, a->W1, a->B, a->K0, a->H1, a->dW1, a->dinp, a->db1, stream);
+    return pngpd_fc_bwd_impl(w.dz1, a->inp, a->W1, a->B, a->K0, a->H1, a->dW1, a->dinp, a->db1, 1, stream);
 }
 
 }  // extern "C"

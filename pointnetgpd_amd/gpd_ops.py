@@ -83,6 +83,21 @@ def depth_map_to_cloud(depth, rgbK, refFromRGB, objFromref, rgb=None, device=Non
     return (xyz[:n], col_out[:n]) if rgb is not None else xyz[:n]
 
 
+def depth_map_to_cloud_organized(depth, rgbK, refFromRGB, objFromref, rgb, device=None):
+    """ycb_cloud_generate.py:124-184 with ``organized=True`` -> (h,w,6) float64 CUDA tensor: xyz (object frame) and the
+    pixel's colour where depth > 0, NaN xyz and zero colour elsewhere (:147-155).  The kernel's ordered emit is scattered
+    back to the pixel grid: the compacted rows ARE the depth > 0 pixels in row-major order."""
+    dev = device or (depth.device if isinstance(depth, torch.Tensor) else torch.device("cuda", torch.cuda.current_device()))
+    d = _f64(depth, dev)
+    h, w = d.shape
+    xyz, col = depth_map_to_cloud(d, rgbK, refFromRGB, objFromref, rgb=rgb, device=dev)
+    out = torch.zeros(h, w, 6, device=dev, dtype=torch.float64)
+    out[:, :, :3] = float("nan")
+    good = d > 0
+    out[good] = torch.cat([xyz, col.to(torch.float64)], 1)
+    return out
+
+
 def conv5_pool2(x, weight, bias):
     """Conv2d(Cin,Cout,5) + bias + MaxPool2d(2,2): x (B,Cin,H,H) fp32 CUDA -> (B,Cout,(H-4)/2,(H-4)/2)."""
     B, Cin, H, W = x.shape

@@ -42,20 +42,58 @@ def grad_view(param):
     return view
 
 
-def mark_written(params):
-    """Called by the fused backward after it has written the gradient slices of ``params`` in place."""
-    for p in params:
-        e = _GRAD_VIEWS.get(p)
-        if e is None:
-            continue
-        opt = e[1]()
+class GradGroup:
+    """The in-place gradient targets of ONE fused piece (a trunk's 12 parameters, an FC stack's 10): the flat
+    optimizer's views in the piece's parameter order, resolved once and re-validated per step by identity checks only
+    (the registry look-ups cost ~2 us per parameter — 0.1 ms per step at the reference's batch of 64, where the eager
+    loop is host-bound)."""
+    __slots__ = ("views", "params", "idx", "owner")
+
+    def __init__(self, views, params, idx, owner):
+        self.views, self.params, self.idx, self.owner = views, params, idx, owner
+
+    def valid(self, params):
+        if self.owner() is None or len(params) != len(self.params):
+            return False
+        for p, q, v in zip(params, self.params, self.views):
+            if p is not q() or p.grad is not v:
+                return False
+        return True
+
+    def mark_written(self):
+        """Called by the fused backward after it has written the gradient slices of the piece in place."""
+        opt = self.owner()
         if opt is None:
-            continue
-        if opt._written[e[2]]:
-            raise RuntimeError("FlatAdam: a gradient slice was written twice before step() — the fused backward "
-                               "OVERWRITES gradients (no accumulation over micro-batches or repeated module calls); "
-                               "use train.set_sequencing('passes') or torch.optim.Adam for accumulation")
-        opt._written[e[2]] = 1
+            return
+        w = opt._written
+        for i in self.idx:
+            if w[i]:
+                raise RuntimeError("FlatAdam: a gradient slice was written twice before step() — the fused backward "
+                                   "OVERWRITES gradients (no accumulation over micro-batches or repeated module "
+                                   "calls); use train.set_sequencing('passes') or torch.optim.Adam for accumulation")
+            w[i] = 1
+
+
+_GROUPS = {}          # id(first parameter of the piece) -> GradGroup (validated by identity on every use)
+
+
+def grad_group(params):
+    """The GradGroup of a fused piece whose parameters ALL have live flat views (``grad_view``), None if none has one;
+    a mix raises (the fused backward writes the whole piece's gradients in place)."""
+    g = _GROUPS.get(id(params[0]))
+    if g is not None and g.valid(params):
+        return g
+    entries = [_GRAD_VIEWS.get(p) for p in params]
+    live = [e is not None and e[1]() is not None and p.grad is e[0] for e, p in zip(entries, params)]
+    if not any(live):
+        _GROUPS.pop(id(params[0]), None)
+        return None
+    if not all(live) or len({id(e[1]()) for e in entries}) != 1:
+        raise RuntimeError("optim.FlatAdam must own all parameters of a trunk / FC stack or none of them "
+                           "(the fused backward writes the whole piece's gradients in place)")
+    g = GradGroup([e[0] for e in entries], [weakref.ref(p) for p in params], [e[2] for e in entries], entries[0][1])
+    _GROUPS[id(params[0])] = g
+    return g
 
 
 class FlatAdam(torch.optim.Optimizer):

@@ -306,7 +306,9 @@ class LinearBnReluFn(torch.autograd.Function):
         inp, W, gamma, z, y, mean, var = ctx.saved_tensors
         dz, dgamma, dbeta = ops.bn1d_bwd(dy.contiguous(), z, y, gamma, mean, var, ctx.eps, 1)
         dinp, dW, db = _linear_bwd(dz, inp, W)
-        return dinp, dW, db, dgamma, dbeta, None, None, None
+        # a bias ahead of a train-mode BatchNorm: sum_b dz is exactly zero in exact arithmetic — the fused entry writes
+        # the exact value instead of its rounding residue (as the trunks do for the conv biases)
+        return dinp, dW, torch.zeros_like(db), dgamma, dbeta, None, None, None
 
 
 class LinearEpiFn(torch.autograd.Function):
@@ -439,7 +441,7 @@ class FusedTrunkFn(torch.autograd.Function):
         dp = dp.contiguous()
         a.dp = dp.data_ptr()
         if ctx.grad_outs is not None:
-            outs = ctx.grad_outs
+            outs = ctx.grad_outs.views
             views = None
         else:
             buf = torch.empty(sum(n for _, n in _TRUNK_GRAD_LAYOUT), device=dev, dtype=torch.float32)
@@ -455,7 +457,7 @@ class FusedTrunkFn(torch.autograd.Function):
         a.scratch, a.scratch_bytes = ws.data_ptr(), ctx.sizes[1]
         _ccall("pngpd_trunk_train_bwd", a, dev)
         if views is None:
-            _mark_written(ctx.grad_outs)
+            ctx.grad_outs.mark_written()
         if views is None:
             grads = (None,) * 12
         else:
@@ -509,7 +511,7 @@ class FusedHeadFn(torch.autograd.Function):
         a.gout = g.data_ptr()
         shapes = [tuple(t.shape) for t in P]
         if ctx.grad_outs is not None:
-            outs, views = ctx.grad_outs, None
+            outs, views = ctx.grad_outs.views, None
         else:
             sizes = [((t.numel() + 63) // 64) * 64 for t in P]        # 256-byte aligned segments
             buf = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
@@ -523,7 +525,7 @@ class FusedHeadFn(torch.autograd.Function):
         a.scratch, a.scratch_bytes = ws.data_ptr(), ctx.sizes[1]
         _ccall("pngpd_head_train_bwd", a, dev)
         if views is None:
-            _mark_written(ctx.grad_outs)
+            ctx.grad_outs.mark_written()
         grads = (None,) * 10 if views is None else tuple(views)
         return (dinp,) + grads + (None,) * 6
 
@@ -536,28 +538,10 @@ def _use_fused():
     return _SEQUENCING == "fused" and DEBUG_STASH is None
 
 
-class _GradOuts(list):
-    """The in-place gradient targets of one fused piece: the flat optimizer's views, plus the parameters they belong to
-    (``optim.mark_written`` records the write so that FlatAdam.step() can tell stale slices from fresh ones)."""
-    params = ()
-
-
 def _grad_outs(params):
-    outs = [_grad_out(p) for p in params]
-    have = sum(o is not None for o in outs)
-    if have == 0:
-        return None
-    if have != len(outs):
-        raise RuntimeError("optim.FlatAdam must own all parameters of a trunk / FC stack or none of them "
-                           "(the fused backward writes the whole piece's gradients in place)")
-    g = _GradOuts(outs)
-    g.params = tuple(params)
-    return g
-
-
-def _mark_written(grad_outs):
-    from .optim import mark_written
-    mark_written(grad_outs.params)
+    """The optim.GradGroup of a fused piece (its ``views`` are the in-place gradient targets), or None."""
+    from .optim import grad_group
+    return grad_group(params)
 
 
 def trunk_train(mod, x, trans, relu_last):

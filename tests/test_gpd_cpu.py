@@ -41,6 +41,11 @@ def test_cloudgen_oracle_matches_reference_record():
         if tag == "small":
             np.testing.assert_array_equal(reg, fx["small/registered"])
             np.testing.assert_array_equal(cloud, fx["small/cloud"][:, :3])
+            org = go.depth_map_to_cloud_organized(regm, sc["rgb"], sc["rgbK"], sc["refFromRGB"], sc["objFromref"])
+            ref = fx["small/cloud_organized"]            # executed reference, organized=True (ycb_cloud_generate.py:130-155)
+            assert org.shape == ref.shape == regm.shape + (6,)
+            assert np.isnan(ref[regm <= 0, :3]).all() and (ref[regm <= 0, 3:] == 0).all()
+            np.testing.assert_array_equal(org, ref)      # NaNs compare equal position-wise
 
 
 def test_classifier_oracle_and_mirror_match_reference_record():

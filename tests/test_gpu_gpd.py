@@ -80,6 +80,9 @@ def test_depth_registration_and_cloud(tag, cuda_device):
         reg2[sc["mask"]] = 0
         cloud = cloudgen.registeredDepthMapToPointCloud(reg2, sc["rgb"], sc["rgbK"], sc["refFromRGB"], sc["objFromref"])
         np.testing.assert_array_equal(cloud[0], fx["small/cloud"])
+        org = cloudgen.registeredDepthMapToPointCloud(reg2, sc["rgb"], sc["rgbK"], sc["refFromRGB"], sc["objFromref"],
+                                                      organized=True)
+        np.testing.assert_array_equal(org, fx["small/cloud_organized"])      # executed reference, NaN where no depth
 
 
 @pytest.mark.parametrize("chann", [3, 12])

@@ -154,35 +154,42 @@ def test_train_step_vs_oracle(B, N, k, cuda_device):
 
 
 def test_sgd_steps_track_oracle(cuda_device):
-    """Three Adam steps (main_1v.py:60,75-76: Adam lr 0.005) on the HIP path vs the oracle's
-    functional model under the same optimizer: losses stay together."""
-    B, N, k = 16, 128, 2
+    """Three steps of the CLI's optimizer (main_1v.py:60,75-76: Adam lr 0.005; here optim.FlatAdam, one launch over the
+    flat buffer, gradients written in place by the fused backward) on clouds that differ from each other, against the
+    oracle's functional model in fp64 under torch.optim.Adam: training losses within 1e-3, eval-mode log-probs after the
+    three steps (running statistics updated, inference weights re-folded) within 2e-3."""
+    from pointnetgpd_amd.optim import FlatAdam
+    B, N, k = 32, 256, 2
     m = build_model(N, k, 91, 4600).train()
     sd = state_dict_cpu(m)
-    x = synth_cloud(B, N, 1234, "box"); y = (torch.arange(B) % k).long()
-    # oracle side: parameters as leaf tensors
-    work = {n: v.clone().requires_grad_(v.is_floating_point() and "running_" not in n) for n, v in sd.items()}
+    x = synth_cloud(B, N, 1234, "diverse"); y = (torch.arange(B) % k).long()
+    # oracle side: parameters as fp64 leaf tensors
+    work = {n: (v.double() if v.is_floating_point() else v).clone().requires_grad_(v.is_floating_point() and "running_" not in n)
+            for n, v in sd.items()}
     opt_ref = torch.optim.Adam([v for v in work.values() if v.requires_grad], lr=0.005)
     losses_ref = []
     for _ in range(3):
         opt_ref.zero_grad()
-        lp, _ = po.forward_torch(work, x, training=True)
+        lp, _ = po.forward_torch(work, x.double(), training=True)
         l = F.nll_loss(lp, y); l.backward(); opt_ref.step(); losses_ref.append(l.item())
     m = m.to(cuda_device)
-    opt = torch.optim.Adam(m.parameters(), lr=0.005)
+    opt = FlatAdam(m.parameters(), lr=0.005)
     xg, yg = x.to(cuda_device), y.to(cuda_device)
     losses = []
     for _ in range(3):
         opt.zero_grad()
         lp, _ = m(xg)
         l = F.nll_loss(lp, yg); l.backward(); opt.step(); losses.append(l.item())
-    np.testing.assert_allclose(losses, losses_ref, atol=5e-3)
+    print("losses", losses, "oracle", losses_ref)
+    np.testing.assert_allclose(losses, losses_ref, atol=1e-3)
     # eval after training uses the updated running stats through the (re-folded) inference path
     m.eval()
     with torch.no_grad():
         lp_e, _ = m(xg)
-        lp_ref, _ = po.forward_torch({n: v.detach() for n, v in work.items()}, x, training=False)
-    np.testing.assert_allclose(lp_e.cpu().numpy(), lp_ref.numpy(), atol=2e-2)
+        lp_ref, _ = po.forward_torch({n: v.detach() for n, v in work.items()}, x.double(), training=False)
+    d = (lp_e.cpu().double() - lp_ref).abs().max().item()
+    print("eval max|dlogp| after 3 steps", d)
+    assert d <= 2e-3, d
 
 
 def test_train_batch_of_one_raises(cuda_device):
