@@ -11,7 +11,7 @@ enum { RF_F64 = 0, RF_F32 = 1, RF_BN2 = 2, RF_BN3 = 3, RF_EPREP = 4, RF_ZERO = 5
 //   RF_EPREP: p0 = g2, d0 = stats2, f0 = dg2, f1 = dbe2, f2 = evec (3,128)
 //   RF_ZERO:  f0 (64), f1 (128), f2 (1024) zero-filled (any may be NULL)
 struct RFSeg {
-    const float *in; void *out; int outer, R, n, bpo, kind;
+    const float *in; void *out; int outer, R, n, bpo, kind, vec;
     const float *p0, *p1, *p2; const double *d0;
     float *rm, *rv; long long *nbt;
     float *f0, *f1, *f2; double *s0;

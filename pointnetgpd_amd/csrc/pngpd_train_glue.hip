@@ -544,6 +544,44 @@ __global__ __launch_bounds__(32 * PNGPD_RED_RL) void reduce_fin_kernel(RFArgs A)
         return;
     }
     const int o = lb / sg.bpo, jb = lb - o * sg.bpo;
+    if (sg.vec) {
+        // wide variant for the big plain reductions (Gram blocks, dW2 shares, the gathered G): a workgroup owns 128
+        // consecutive columns and every thread FOUR of them (one 16-byte load per row, 512 contiguous bytes per row and
+        // workgroup instead of 128).  Per column the arithmetic is unchanged — row lane ry adds rows ry, ry + RL, ... in
+        // order, then the lanes are added in order — so the result is bit-identical to the narrow path.
+        const int j4 = jb * 128 + cx * 4;
+        double s4[4] = {0.0, 0.0, 0.0, 0.0};
+        const f32x4 *p = (const f32x4 *)(sg.in + (size_t)o * sg.R * sg.n + j4);
+        const size_t rs = (size_t)sg.n >> 2;
+        #pragma unroll 8
+        for (int r = ry; r < sg.R; r += PNGPD_RED_RL) {
+            const f32x4 v = p[(size_t)r * rs];
+            s4[0] += (double)v[0]; s4[1] += (double)v[1]; s4[2] += (double)v[2]; s4[3] += (double)v[3];
+        }
+        double t4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (e) __syncthreads();
+            red[ry][cx] = s4[e];
+            __syncthreads();
+            if (ry == 0) {
+                double a = 0.0;
+#pragma unroll
+                for (int i = 0; i < PNGPD_RED_RL; ++i) a += red[i][cx];
+                t4[e] = a;
+            }
+        }
+        if (ry == 0) {
+            if (sg.kind == RF_F64) {
+                double *out = (double *)sg.out + (size_t)o * sg.n + j4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) out[e] = t4[e];
+            } else {
+                *(f32x4 *)((float *)sg.out + (size_t)o * sg.n + j4) = f32x4{(float)t4[0], (float)t4[1], (float)t4[2], (float)t4[3]};
+            }
+        }
+        return;
+    }
     const int j = jb * 32 + cx;
     const int planes = sg.kind == RF_BN3 ? 2 : 1;
     const size_t stride = (size_t)sg.n * planes;
@@ -593,7 +631,9 @@ int pngpd_reduce_fin_launch(RFArgs &A, int nseg, void *stream) {
         RFSeg &s = A.seg[g];
         if (s.kind == RF_ZERO) { s.bpo = 1; total += 1; continue; }
         if (!s.in || s.outer <= 0 || s.R <= 0 || s.n <= 0) return PNGPD_ERR_INVALID_ARG;
-        s.bpo = (s.n + 31) / 32;
+        s.vec = ((s.kind == RF_F64 || s.kind == RF_F32) && (s.n & 127) == 0 && s.n >= 1024 &&
+                 (((uintptr_t)s.in | (uintptr_t)s.out) & 15) == 0) ? 1 : 0;
+        s.bpo = s.vec ? s.n / 128 : (s.n + 31) / 32;
         total += s.outer * s.bpo;
     }
     A.first[4] = total;

@@ -298,11 +298,12 @@ class GpgGraspSamplerPcl:
         cnt2 = hand_box_counts(cloud_d, poses2, boxes_d, index=index, valid_units=total, per_unit=2 * S)
         found, sfirst, olist, ototal = (torch.empty(cap, **i32), torch.empty(cap, **i32), torch.empty(cap, **i32),
                                         torch.empty(1, **i32))
-        out = torch.empty(1 + L + cap * 15, **f64)
+        out = torch.empty(1 + L + cap * 15 + 1, **f64)
         _call("pngpd_gpg_finish", up_d, cnt2, plist, total, ab, frames_d, back, mod, L, R, S, MIN_OPEN_POINTS, found,
               sfirst, olist, ototal, out)
+        out[-1:].copy_(total)               # the potential-grasp count rides in the same download (it was a third sync)
         host = out.cpu().numpy()                                                                # download 2: packed result
-        self.last_stats["potential"] = self.last_stats.get("potential", 0) + int(total.item())
+        self.last_stats["potential"] = self.last_stats.get("potential", 0) + int(host[-1])
         n = int(host[0])
         per = host[1:1 + L].astype(np.int64)
         grasps = host[1 + L:1 + L + n * 15].reshape(n, 5, 3)
