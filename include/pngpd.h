@@ -117,6 +117,15 @@ int pngpd_trunk_fwd_infer_bf(const void *x, int x_is_bf16, int B, int N, const f
                              const float *w1, const float *b1, const void *w2x, const float *b2,
                              const void *w3x, const float *b3, int relu_last, int nterms, int splits,
                              float *out_pool, void *workspace, size_t workspace_bytes, void *stream);
+/* The same launch, also returning out_arg (B,1024) int32 = the point whose reduced-precision value was the maximum of
+ * every (cloud, channel) — the input of pngpd_trunk_pool_refine for EVAL-mode refinement (the folded inference weights
+ * take the place of the train-mode affine forms there: s1c = t1c = NULL, s2c = ones, t2c = the folded conv2 bias,
+ * g3 = ones, w3 = the folded conv3 weight, row-major).  workspace (splits > 1): B*S*1024 * (4 + 4) bytes.           */
+int pngpd_trunk_fwd_infer_bf_arg(const void *x, int x_is_bf16, int B, int N, const float *trans,
+                                 const float *w1, const float *b1, const void *w2x, const float *b2,
+                                 const void *w3x, const float *b3, int relu_last, int nterms, int splits,
+                                 float *out_pool, int *out_arg, void *workspace, size_t workspace_bytes,
+                                 void *stream);
 /* the same arithmetic for pass C of the training path (pngpd_trunk_fwd_train below): identical outputs/semantics.
  * w2x = split_pack_bf16(raw W2), w3sx = split_pack_bf16(sign(gamma3)*W3).  S = workgroups per cloud
  * (1 <= S <= ceil(N/128)); pmax/parg (B*S,1024), psum (B*S,2,1024), psh (B*S*2,128).  BatchNorm statistics and every
@@ -171,7 +180,7 @@ int pngpd_trunk_fwd_train(const float *x, int B, int N, const float *trans,
  * idx is the fp32 arg-max the value is bit-identical to the fp32 pass's maximum).  Feed zex to pngpd_pool_finalize
  * (S = 1) in place of the bf16 pass's pmax: the reduced-precision matrix pass then contributes only the CHOICE of the
  * point to max over N of bn3(conv3(.)) (PointNetGPD/model/pointnet.py:31-32, :147-148).
- *   w2p: fp32 MFMA_B-packed conv2 weight; w3sp: sign-folded MFMA_B-packed conv3 weight (variant 0) or NULL;
+ *   s1c / t1c: layer-1 affine form or both NULL (none).  w2p: fp32 MFMA_B-packed conv2 weight; w3sp: sign-folded MFMA_B-packed conv3 weight (variant 0) or NULL;
  *   w3 / g3: raw conv3 weight (1024,128) and bn3.weight (variants 1-3) or NULL;
  *   variant: 0 = contraction on the fp32 matrix pipe (default), 1-3 = on the VALU (candidate orders of the matrix
  *   instruction's two products; tests/test_gpu_refine.py probes which one reproduces it bit for bit).               */

@@ -58,6 +58,9 @@ SIGNATURES = {
     "pngpd_trunk_infer_bf_splits": (ctypes.c_int, [ctypes.c_int] * 3),
     "pngpd_trunk_fwd_infer_bf": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p] + [c_f32p] * 6 +
                                  [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, c_void, ctypes.c_size_t, c_void]),
+    "pngpd_trunk_fwd_infer_bf_arg": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p] +
+                                     [c_f32p] * 6 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, c_void, c_void,
+                                                     ctypes.c_size_t, c_void]),
     "pngpd_trunk_fwd_train_bf": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int] + [c_f32p] * 9 +
                                  [ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_void]),
     # ---- training passes (S = workgroups per cloud is an explicit argument everywhere)

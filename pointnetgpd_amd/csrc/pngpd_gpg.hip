@@ -91,15 +91,19 @@ __global__ __launch_bounds__(256) void gpg_normal_moments_kernel(
                 const bool match = pos == 7 ? true : (key >> sh_hi) == lo;
                 const bool cand = p < P && d2 < r2 && match;
                 const int digit = (int)((key >> (8 * pos)) & 255ull);
-                // wave-aggregated: in the high bytes (sign / exponent) every candidate of a wave lands in the same bin —
-                // one LDS atomic per distinct digit and wave instead of one per point
-                unsigned long long active = __ballot(cand);
-                while (active) {
-                    const int leader = __ffsll((long long)active) - 1;
-                    const int dl = __shfl(digit, leader);
-                    const unsigned long long same = __ballot(cand && digit == dl);
-                    if ((tid & 63) == leader) atomicAdd(&hist[dl], __popcll(same));
-                    active &= ~same;
+                if (pos == 7) {
+                    // sign / exponent byte: every candidate of a wave lands in one or two bins — wave-aggregated, one LDS
+                    // atomic per distinct digit and wave instead of 64 colliding ones
+                    unsigned long long active = __ballot(cand);
+                    while (active) {
+                        const int leader = __ffsll((long long)active) - 1;
+                        const int dl = __shfl(digit, leader);
+                        const unsigned long long same = __ballot(cand && digit == dl);
+                        if ((tid & 63) == leader) atomicAdd(&hist[dl], __popcll(same));
+                        active &= ~same;
+                    }
+                } else if (cand) {
+                    atomicAdd(&hist[digit], 1);      // mantissa bytes: the digits of a wave are spread over the bins
                 }
             }
             __syncthreads();

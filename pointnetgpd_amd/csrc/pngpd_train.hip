@@ -1695,7 +1695,7 @@ int pngpd_trunk_pool_refine(const float *x, int B, int N, const float *trans,
                             const float *w2p, const float *s2c, const float *t2c,
                             const float *w3sp, const float *w3, const float *g3, const int *idx,
                             int clouds_per_range, int variant, float *zex, void *stream) {
-    if (!x || !w1 || !b1 || !s1c || !t1c || !w2p || !s2c || !t2c || !idx || !zex || B <= 0 || N <= 0 ||
+    if (!x || !w1 || !b1 || (!s1c != !t1c) || !w2p || !s2c || !t2c || !idx || !zex || B <= 0 || N <= 0 ||
         clouds_per_range <= 0 || variant < 0 || variant > 3 || (variant == 0 ? !w3sp : (!w3 || !g3)))
         return PNGPD_ERR_INVALID_ARG;
     const int R = (B + clouds_per_range - 1) / clouds_per_range;

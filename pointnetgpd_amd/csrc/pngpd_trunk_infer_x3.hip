@@ -59,13 +59,17 @@ __device__ __forceinline__ float ldx(const void *__restrict__ base, size_t i) {
     return XBF ? bf16_val(((const u16 *)base)[i]) : ((const float *)base)[i];
 }
 
-template <int NT, bool XBF>
+// ARG: also track WHICH point gave every channel's maximum (out_arg, one int per (cloud, split, channel)) — the input of
+// the pool refinement (pngpd_trunk_pool_refine): the reduced-precision pass then only CHOOSES the point, its value is
+// re-evaluated in exact fp32.  The arg search (64 compare / select pairs per block) runs only in blocks where some lane
+// of the wave saw a new maximum.
+template <int NT, bool XBF, bool ARG>
 __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
     const void *__restrict__ x, int N, const float *__restrict__ trans,
     const float *__restrict__ w1, const float *__restrict__ b1,
     const u16 *__restrict__ w2x, const float *__restrict__ b2,
     const u16 *__restrict__ w3x, const float *__restrict__ b3,
-    int relu_last, int T, int S, float *__restrict__ out) {
+    int relu_last, int T, int S, float *__restrict__ out, int *__restrict__ out_arg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16 *h1h = (u16 *)smem_raw;                 // [XP][X1S]
     u16 *h1l = h1h + XP * X1S;
@@ -73,6 +77,7 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
     u16 *h2l = h2h + XP * X2S;
     float *xs = (float *)(h2l + XP * X2S);      // [3][XP]
     float *rm = xs + 3 * XP;                    // [1024]
+    int *ri = (int *)(rm + 1024);               // [1024] running arg-max (ARG only; the launch adds the 4 KB)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
 #pragma unroll
         for (int i = 0; i < 9; ++i) tm[i] = trans[(size_t)b * 9 + i];
     }
-    for (int i = tid; i < 1024; i += 512) rm[i] = -INFINITY;
+    for (int i = tid; i < 1024; i += 512) { rm[i] = -INFINITY; if (ARG) ri[i] = 0; }
     __shared__ int s_bad;   // non-finite input coordinate seen: poison the pooled row (see trunk_infer_kernel)
     if (tid == 0) s_bad = 0;
     __syncthreads();
@@ -98,8 +103,9 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
     // block and tile from L2 (2 KB per point and workgroup; with all 256 CUs on the same 256 KB of weights: half of each
     // XCD's L2 bandwidth), and tools/phase_times_x3.py showed 2,150 cycles per block waiting for the fragments to land —
     // 35 % of the kernel.  (NT == 3 would need 256 VGPRs for hi + lo of four blocks and keeps streaming.)
-    f32x4 wres[NT == 1 ? 4 : 1][8];
-    if (NT == 1) {
+    constexpr bool WRES = NT == 1 && !ARG;   // (the arg search needs the registers: the ARG variant streams its weights)
+    f32x4 wres[WRES ? 4 : 1][8];
+    if (WRES) {
 #pragma unroll
         for (int ci = 0; ci < 4; ++ci) {
             const f32x4 *p = (const f32x4 *)w3x + (size_t)((wave + 8 * ci) * 8) * 2 * 64 + lane;
@@ -231,9 +237,33 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
             for (int r = 0; r < 16; ++r) m = max3f(m, max3f(c0[r], c1[r], c2[r]), c3[r]);
             float mlo, mhi;
             half_pair(m, mlo, mhi);   // v_permlane32_swap: the LDS is this kernel's scarcest resource, no ds_bpermute
-            if (h == 0) rm[cb * 32 + j] = fmaxf(rmc, fmaxf(mlo, mhi));
+            if constexpr (!ARG) {
+                if (h == 0) rm[cb * 32 + j] = fmaxf(rmc, fmaxf(mlo, mhi));
+            } else {
+                const float mw = fmaxf(mlo, mhi);
+                if (__ballot(mw > rmc)) {     // some channel of this block has a new maximum: find its first row
+                    int am = 0;               // descending rows, so that the smallest row holding the maximum wins
+#pragma unroll
+                    for (int r = 15; r >= 0; --r) am = (c3[r] == m) ? 96 + mfma_row(r, lane) : am;
+#pragma unroll
+                    for (int r = 15; r >= 0; --r) am = (c2[r] == m) ? 64 + mfma_row(r, lane) : am;
+#pragma unroll
+                    for (int r = 15; r >= 0; --r) am = (c1[r] == m) ? 32 + mfma_row(r, lane) : am;
+#pragma unroll
+                    for (int r = 15; r >= 0; --r) am = (c0[r] == m) ? mfma_row(r, lane) : am;
+                    int alo, ahi;
+                    half_pair(am, alo, ahi);
+                    const bool hi_wins = mhi > mlo || (mhi == mlo && ahi < alo);
+                    const int aw = hi_wins ? ahi : alo;
+                    if (h == 0 && mw > rmc) {
+                        rm[cb * 32 + j] = mw;
+                        int n = tile * XP + aw;
+                        ri[cb * 32 + j] = n < N ? n : N - 1;
+                    }
+                }
+            }
         };
-        if (NT == 1) {
+        if constexpr (WRES) {
 #pragma unroll
             for (int ci = 0; ci < 4; ++ci) block4(wave + 8 * ci, wres[ci], wres[ci]);
         } else {
@@ -255,6 +285,7 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
             float v = rm[c] + b3[c];
             if (relu_last) v = fmaxf(v, 0.f);
             o[c] = s_bad ? __builtin_nanf("") : v;
+            if (ARG) out_arg[((size_t)b * S + s) * 1024 + c] = ri[c];
         }
     }
 }
@@ -534,16 +565,37 @@ __global__ void pool_reduce_x3_kernel(const float *__restrict__ part, int S, flo
     out[idx] = nan ? __builtin_nanf("") : m;
 }
 
+// the same with the arg-max carried along (the earliest split wins ties; a NaN partial poisons the row as above)
+__global__ void pool_reduce_arg_x3_kernel(const float *__restrict__ part, const int *__restrict__ parg, int S,
+                                          float *__restrict__ out, int *__restrict__ out_arg, int total) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    int b = idx >> 10, c = idx & 1023;
+    const float *p = part + (size_t)b * S * 1024 + c;
+    const int *a = parg + (size_t)b * S * 1024 + c;
+    float m = p[0];
+    int am = a[0];
+    bool nan = m != m;
+    for (int s = 1; s < S; ++s) {
+        const float v = p[(size_t)s * 1024];
+        nan |= v != v;
+        if (v > m) { m = v; am = a[(size_t)s * 1024]; }
+    }
+    out[idx] = nan ? __builtin_nanf("") : m;
+    out_arg[idx] = am;
+}
+
 #define X3_DEFAULT_TARGET_BLOCKS 1024
 
-template <int NT, bool XBF>
+template <int NT, bool XBF, bool ARG>
 static int launch_infer_bf(const void *x, int B, int N, const float *trans, const float *w1, const float *b1,
                            const u16 *w2x, const float *b2, const u16 *w3x, const float *b3, int relu_last, int T,
-                           int S, float *dst, hipStream_t stream) {
-    int st = pngpd_allow_lds((const void *)trunk_infer_x3_kernel<NT, XBF>, X3_LDS_BYTES);
+                           int S, float *dst, int *dst_arg, hipStream_t stream) {
+    const size_t lds = X3_LDS_BYTES + (ARG ? 4096 : 0);
+    int st = pngpd_allow_lds((const void *)trunk_infer_x3_kernel<NT, XBF, ARG>, lds);
     if (st != PNGPD_OK) return st;
-    hipLaunchKernelGGL((trunk_infer_x3_kernel<NT, XBF>), dim3((unsigned)B * S), dim3(512), X3_LDS_BYTES, stream,
-                       x, N, trans, w1, b1, w2x, b2, w3x, b3, relu_last, T, S, dst);
+    hipLaunchKernelGGL((trunk_infer_x3_kernel<NT, XBF, ARG>), dim3((unsigned)B * S), dim3(512), lds, stream,
+                       x, N, trans, w1, b1, w2x, b2, w3x, b3, relu_last, T, S, dst, dst_arg);
     return pngpd_launch_status();
 }
 
@@ -576,37 +628,66 @@ int pngpd_split_pack_bf16(const float *W, int C, int K, void *out, void *stream)
     return pngpd_launch_status();
 }
 
-int pngpd_trunk_fwd_infer_bf(const void *x, int x_is_bf16, int B, int N, const float *trans,
-                             const float *w1, const float *b1, const void *w2x, const float *b2,
-                             const void *w3x, const float *b3, int relu_last, int nterms, int splits,
-                             float *out_pool, void *workspace, size_t workspace_bytes, void *stream) {
+static int infer_bf_impl(const void *x, int x_is_bf16, int B, int N, const float *trans,
+                         const float *w1, const float *b1, const void *w2x, const float *b2,
+                         const void *w3x, const float *b3, int relu_last, int nterms, int splits,
+                         float *out_pool, int *out_arg, void *workspace, size_t workspace_bytes, void *stream) {
     if (!x || !w1 || !b1 || !w2x || !b2 || !w3x || !b3 || !out_pool || B <= 0 || N <= 0 ||
         (nterms != 1 && nterms != 3))
         return PNGPD_ERR_INVALID_ARG;
     const int T = (N + XP - 1) / XP;
     const int S = (splits > 0) ? (splits > T ? T : splits) : pngpd_splits_for(B, T, X3_DEFAULT_TARGET_BLOCKS);
     float *dst = out_pool;
+    int *dst_arg = out_arg;
     if (S > 1) {
-        if (!workspace || workspace_bytes < (size_t)B * S * 1024 * sizeof(float)) return PNGPD_ERR_WORKSPACE;
+        const size_t need = (size_t)B * S * 1024 * (sizeof(float) + (out_arg ? sizeof(int) : 0));
+        if (!workspace || workspace_bytes < need) return PNGPD_ERR_WORKSPACE;
         dst = (float *)workspace;
+        if (out_arg) dst_arg = (int *)(dst + (size_t)B * S * 1024);
     }
     const u16 *w2 = (const u16 *)w2x, *w3 = (const u16 *)w3x;
     hipStream_t sm = (hipStream_t)stream;
     int st;
-    if (nterms == 3)
-        st = x_is_bf16 ? launch_infer_bf<3, true>(x, B, N, trans, w1, b1, w2, b2, w3, b3, relu_last, T, S, dst, sm)
-                       : launch_infer_bf<3, false>(x, B, N, trans, w1, b1, w2, b2, w3, b3, relu_last, T, S, dst, sm);
-    else
-        st = x_is_bf16 ? launch_infer_bf<1, true>(x, B, N, trans, w1, b1, w2, b2, w3, b3, relu_last, T, S, dst, sm)
-                       : launch_infer_bf<1, false>(x, B, N, trans, w1, b1, w2, b2, w3, b3, relu_last, T, S, dst, sm);
+#define PNGPD_X3_LAUNCH(NT_, XBF_, ARG_) \
+    launch_infer_bf<NT_, XBF_, ARG_>(x, B, N, trans, w1, b1, w2, b2, w3, b3, relu_last, T, S, dst, dst_arg, sm)
+    if (out_arg) {
+        if (nterms == 3) st = x_is_bf16 ? PNGPD_X3_LAUNCH(3, true, true) : PNGPD_X3_LAUNCH(3, false, true);
+        else st = x_is_bf16 ? PNGPD_X3_LAUNCH(1, true, true) : PNGPD_X3_LAUNCH(1, false, true);
+    } else {
+        if (nterms == 3) st = x_is_bf16 ? PNGPD_X3_LAUNCH(3, true, false) : PNGPD_X3_LAUNCH(3, false, false);
+        else st = x_is_bf16 ? PNGPD_X3_LAUNCH(1, true, false) : PNGPD_X3_LAUNCH(1, false, false);
+    }
+#undef PNGPD_X3_LAUNCH
     if (st != PNGPD_OK) return st;
     if (S > 1) {
         const int total = B * 1024;
-        hipLaunchKernelGGL(pool_reduce_x3_kernel, dim3((total + 255) / 256), dim3(256), 0, sm,
-                           (const float *)workspace, S, out_pool, total);
+        if (out_arg)
+            hipLaunchKernelGGL(pool_reduce_arg_x3_kernel, dim3((total + 255) / 256), dim3(256), 0, sm,
+                               (const float *)dst, (const int *)dst_arg, S, out_pool, out_arg, total);
+        else
+            hipLaunchKernelGGL(pool_reduce_x3_kernel, dim3((total + 255) / 256), dim3(256), 0, sm,
+                               (const float *)workspace, S, out_pool, total);
         st = pngpd_launch_status();
     }
     return st;
+}
+
+int pngpd_trunk_fwd_infer_bf(const void *x, int x_is_bf16, int B, int N, const float *trans,
+                             const float *w1, const float *b1, const void *w2x, const float *b2,
+                             const void *w3x, const float *b3, int relu_last, int nterms, int splits,
+                             float *out_pool, void *workspace, size_t workspace_bytes, void *stream) {
+    return infer_bf_impl(x, x_is_bf16, B, N, trans, w1, b1, w2x, b2, w3x, b3, relu_last, nterms, splits, out_pool,
+                         nullptr, workspace, workspace_bytes, stream);
+}
+
+int pngpd_trunk_fwd_infer_bf_arg(const void *x, int x_is_bf16, int B, int N, const float *trans,
+                                 const float *w1, const float *b1, const void *w2x, const float *b2,
+                                 const void *w3x, const float *b3, int relu_last, int nterms, int splits,
+                                 float *out_pool, int *out_arg, void *workspace, size_t workspace_bytes,
+                                 void *stream) {
+    if (!out_arg) return PNGPD_ERR_INVALID_ARG;
+    return infer_bf_impl(x, x_is_bf16, B, N, trans, w1, b1, w2x, b2, w3x, b3, relu_last, nterms, splits, out_pool,
+                         out_arg, workspace, workspace_bytes, stream);
 }
 
 int pngpd_trunk_fwd_train_bf(const float *x, int B, int N, const float *trans,

@@ -47,6 +47,7 @@ MAX_NN = 100                                   # :1475
 TABLE_CLEARANCE = 0.01                         # :1599 safety_dis_above_table
 MIN_OPEN_POINTS = 10                           # :1614
 BOX_OPEN, BOX_LEFT, BOX_RIGHT, BOX_BOTTOM = 0, 1, 2, 3
+_PIN = None                                    # process-wide pinned staging buffer of the sampler's two downloads
 
 
 def _gripper_dict(gripper):
@@ -230,8 +231,27 @@ class GpgGraspSamplerPcl:
         self.config = config
         self.device = torch.device(device) if device is not None else None
         self.last_stats = {}
+        self._const_cache = {}
 
     # -- device work for one batch of draws --------------------------------------------------
+    def _constants(self, g, dev):
+        """Gripper-derived constants (hand boxes on the device, sweep parameter block): pure functions of the gripper
+        dict, built once per sampler and device instead of once per scene."""
+        key = (tuple(sorted(g.items())), str(dev))
+        c = self._const_cache.get(key)
+        if c is None:
+            prm, R, D, S = self._params(g)
+            c = self._const_cache[key] = (torch.from_numpy(hand_boxes(g)).to(dev), prm, R, D, S)
+        return c
+
+    def _pinned(self, n):
+        """A pinned host staging buffer of >= n doubles.  Page-locking costs milliseconds, so the buffer is shared by all
+        samplers of the process (scoring.detect_grasps builds one per scene by default) and grows geometrically."""
+        global _PIN
+        if _PIN is None or _PIN.numel() < n:
+            _PIN = torch.empty(max(2 * n, 1 << 17), dtype=torch.float64).pin_memory()
+        return _PIN[:n]
+
     @staticmethod
     def _params(g):
         """Gripper / sweep constants of the device kernels, computed with numpy exactly as the reference computes them
@@ -251,20 +271,31 @@ class GpgGraspSamplerPcl:
         prm[80:80 + S] = np.arange(S, dtype=np.float64)
         return prm, len(dth), len(dys), S
 
-    def _run_batch(self, g, cloud_d, normals_d, boxes_d, sel_pts, normals_at_ind, index=None):
-        """sel_pts (K,3) sample points, normals_at_ind (K,3) -> (m_zero (K,) bool, per-draw list of (n,5,3) arrays)."""
+    def _run_batch(self, g, cloud_d, normals_d, sel_pts, normals_at_ind, scene):
+        """sel_pts (K,3) sample points, normals_at_ind (K,3) -> (m_zero (K,) bool, counts (K,) grasps per draw,
+        grasps (n,5,3) rows of all draws in draw order).  ``scene``: dict holding the scene's CloudIndex (built lazily,
+        once) — the index is only needed by the sweep, so its device work is enqueued BEHIND the moments kernel and runs
+        while the host waits for the K moment matrices and computes the local frames."""
         dev = cloud_d.device
         K = sel_pts.shape[0]
         fw, hd = g["finger_width"], g["hand_depth"]
         r_ball = max(g["hand_outer_diameter"] - fw, hd, g["hand_height"] / 2.0)                  # :1464
-        M, _ = normal_moments(cloud_d, normals_d, torch.from_numpy(sel_pts).to(dev), r_ball, MAX_NN)
-        M = M.cpu().numpy()                                                                     # download 1: K x 9 doubles
+        boxes_d, prm, R, D, S = self._constants(g, dev)
+        M_d, _ = normal_moments(cloud_d, normals_d, torch.from_numpy(sel_pts).to(dev), r_ball, MAX_NN)
+        M_h = self._pinned(K * 9)
+        M_h.copy_(M_d.view(-1), non_blocking=True)                                              # download 1: K x 9 doubles
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        if self.use_index and scene.get("index") is None:
+            scene["index"] = CloudIndex(cloud_d)          # ~0.4 ms of device work, overlapped with the host's eig below
+        index = scene.get("index")
+        ev.synchronize()
+        M = M_h.numpy().reshape(K, 3, 3).copy()
         m_zero = M.sum((1, 2)) == 0                                                             # :1486
-        empty = np.zeros((0, 5, 3))
-        res = [empty] * K
+        counts = np.zeros(K, dtype=np.int64)
         live = np.nonzero(~m_zero)[0]
         if live.size == 0:
-            return m_zero, res
+            return m_zero, counts, np.zeros((0, 5, 3))
         # local frames (:1493-1512) — np.linalg.eig exactly as the reference calls it, once for the whole batch
         eigval, eigvec = np.linalg.eig(M[live])
         eigval, eigvec = np.real(eigval), np.real(eigvec)
@@ -277,7 +308,6 @@ class GpgGraspSamplerPcl:
         flip = (normals_at_ind[live] * normal).sum(1) < 0
         normal = np.where(flip[:, None], -normal, normal)
         minor = np.where(flip[:, None], -minor, minor)
-        prm, R, D, S = self._params(g)
         L = live.size
         up = np.concatenate([np.concatenate([minor, normal, major, sel_pts[live]], 1).reshape(-1), prm])
         up_d = torch.from_numpy(up).to(dev)                                                     # upload: frames + constants
@@ -289,28 +319,31 @@ class GpgGraspSamplerPcl:
         ab = torch.empty(cap, 6, **f64)
         _call("pngpd_gpg_enumerate", up_d, frames_d, L, R, D, prm_d, poses, ab)
         cnt = hand_box_counts(cloud_d, poses, boxes_d, index=index)                             # (L*R*D,4)
-        flag, dsel, plist, total = (torch.empty(cap, **i32), torch.empty(cap, **i32), torch.empty(cap, **i32),
-                                    torch.empty(1, **i32))
+        ibuf = torch.empty(3 * cap + 1, **i32)
+        flag, dsel, plist, total = ibuf[:cap], ibuf[cap:2 * cap], ibuf[2 * cap:3 * cap], ibuf[3 * cap:]
         _call("pngpd_gpg_select", up_d, cnt, poses, ab, L, R, D, prm_d, flag, dsel, plist, total)
         poses2 = torch.empty(cap * S * 2, 12, **f64)
-        back, mod = torch.empty(cap * S, 3, **f64), torch.empty(cap * S, 3, **f64)
+        bm = torch.empty(2 * cap * S, 3, **f64)
+        back, mod = bm[:cap * S], bm[cap * S:]
         _call("pngpd_gpg_pushin", up_d, plist, total, dsel, poses, ab, frames_d, L, R, D, S, prm_d, poses2, back, mod)
         cnt2 = hand_box_counts(cloud_d, poses2, boxes_d, index=index, valid_units=total, per_unit=2 * S)
-        found, sfirst, olist, ototal = (torch.empty(cap, **i32), torch.empty(cap, **i32), torch.empty(cap, **i32),
-                                        torch.empty(1, **i32))
-        out = torch.empty(1 + L + cap * 15 + 1, **f64)
+        jbuf = torch.empty(3 * cap + 1, **i32)
+        found, sfirst, olist, ototal = jbuf[:cap], jbuf[cap:2 * cap], jbuf[2 * cap:3 * cap], jbuf[3 * cap:]
+        nres = 1 + L + cap * 15 + 1
+        out = torch.empty(nres, **f64)
         _call("pngpd_gpg_finish", up_d, cnt2, plist, total, ab, frames_d, back, mod, L, R, S, MIN_OPEN_POINTS, found,
               sfirst, olist, ototal, out)
         out[-1:].copy_(total)               # the potential-grasp count rides in the same download (it was a third sync)
-        host = out.cpu().numpy()                                                                # download 2: packed result
+        host_t = self._pinned(nres)
+        host_t.copy_(out, non_blocking=True)                                                    # download 2: packed result
+        torch.cuda.current_stream(dev).synchronize()
+        host = host_t.numpy()
         self.last_stats["potential"] = self.last_stats.get("potential", 0) + int(host[-1])
         n = int(host[0])
-        per = host[1:1 + L].astype(np.int64)
-        grasps = host[1 + L:1 + L + n * 15].reshape(n, 5, 3)
-        ends = np.cumsum(per)
-        for j in np.nonzero(per)[0]:
-            res[live[j]] = grasps[ends[j] - per[j]:ends[j]]
-        return m_zero, res
+        counts[live] = host[1:1 + L].astype(np.int64)
+        # rows are packed in (live sample point, rotation) order = draw order: no per-draw regrouping needed
+        grasps = host[1 + L:1 + L + n * 15].reshape(n, 5, 3).copy()
+        return m_zero, counts, grasps
 
     def sample_grasps(self, point_cloud, points_for_sample, all_normal, num_grasps=20, max_num_samples=200,
                       show_final_grasp=False, sample_indices=None, seed=None, as_array=False, **kwargs):
@@ -331,14 +364,13 @@ class GpgGraspSamplerPcl:
         pfs = np.asarray(points_for_sample.cpu() if isinstance(points_for_sample, torch.Tensor) else points_for_sample,
                          dtype=np.float64).reshape(-1, 3)
         normals_d = torch.from_numpy(np.ascontiguousarray(all_normal)).to(dev)
-        boxes_d = torch.from_numpy(hand_boxes(g)).to(dev)
-        index = CloudIndex(cloud_d) if self.use_index else None      # once per scene, shared by both launches
-        out = []
+        scene = {"index": None}                                          # CloudIndex: built once per scene, lazily
+        chunks = []
         if num_grasps <= 0 or max_num_samples <= 0 or pfs.shape[0] == 0:                       # :1432 loop never entered
-            return np.zeros((0, 5, 3)) if as_array else out
+            return np.zeros((0, 5, 3)) if as_array else []
         rng = np.random.default_rng(seed)
         explicit = None if sample_indices is None else np.asarray(sample_indices, dtype=np.int64).reshape(-1)
-        pos, sampled, done = 0, 0, False
+        pos, sampled, found, done = 0, 0, 0, False
         while not done:
             want = min(self.batch_samples, max_num_samples - sampled)
             if explicit is not None:
@@ -350,17 +382,21 @@ class GpgGraspSamplerPcl:
                     break                                            # degenerate cloud: the reference would spin here
                 draws = rng.integers(0, pfs.shape[0], size=want)
             pos += draws.size
-            m_zero, res = self._run_batch(g, cloud_d, normals_d, boxes_d, pfs[draws], all_normal[draws], index)
-            for k in range(draws.size):
-                self.last_stats["draws"] += 1
-                if m_zero[k]:
-                    continue                                         # :1486-1489 — not counted
-                out.extend(res[k])
-                sampled += 1
-                if len(out) >= num_grasps or sampled >= max_num_samples:                      # :1639
-                    done = True
-                    break
+            m_zero, counts, grasps = self._run_batch(g, cloud_d, normals_d, pfs[draws], all_normal[draws], scene)
+            # the reference's loop over the draws (:1486-1489, :1639), without a Python iteration per draw: a draw whose
+            # M is zero consumes a draw but is not counted; stop behind the first counted draw at which num_grasps
+            # grasps have been found or max_num_samples sample points have been processed
+            live_cum = sampled + np.cumsum(~m_zero)
+            found_cum = found + np.cumsum(counts)
+            stop = np.nonzero(~m_zero & ((found_cum >= num_grasps) | (live_cum >= max_num_samples)))[0]
+            last = int(stop[0]) if stop.size else draws.size - 1
+            keep = int(found_cum[last] - found)
+            chunks.append(grasps[:keep])
+            self.last_stats["draws"] += last + 1
+            sampled, found = int(live_cum[last]), int(found_cum[last])
+            done = bool(stop.size)
+        out = np.concatenate(chunks, 0) if chunks else np.zeros((0, 5, 3))
         self.last_stats["sampled"] = sampled
         if as_array:
-            return np.stack(out, 0) if out else np.zeros((0, 5, 3))
+            return out
         return [[v.copy() for v in gr] for gr in out]

@@ -37,14 +37,21 @@ _TRUNK_WIDTHS = (64, 128, 1024)
 # In the two bf16 modes the clouds may also be STORED as bf16 ((B,3,N) torch.bfloat16, 6 B/point): the trunk kernel
 # reads them directly.  In "fp32" mode a bf16 cloud is widened first.
 _INFER_PRECISION = "fp32"
+_INFER_REFINE = False
 _NTERMS = {"bf16x3": 3, "bf16": 1}
 
 
-def set_inference_precision(mode):
-    global _INFER_PRECISION
+def set_inference_precision(mode, refine=False):
+    """``refine`` (reduced-precision modes only): the bf16 / bf16x3 trunk only CHOOSES the arg-max point of every pooled
+    value; the value itself is re-evaluated in exact fp32 at that point (pngpd_trunk_pool_refine — layers 1-2 for the
+    B*1024 chosen points + one 128-long contraction each), so a pooled feature equals the fp32 path's bit for bit
+    wherever the choice agrees.  Costs the arg tracking in the trunk's epilogue plus one gather-sized pass; off by
+    default (eval-mode bf16x3 / bf16 already sit at 2e-7 / 6e-5 of the fp32 log-probs on the bench inputs)."""
+    global _INFER_PRECISION, _INFER_REFINE
     if mode not in ("fp32", "bf16x3", "bf16"):
         raise ValueError("precision must be 'fp32', 'bf16x3' or 'bf16'")
     _INFER_PRECISION = mode
+    _INFER_REFINE = bool(refine) and mode != "fp32"
 
 
 def get_inference_precision():
@@ -53,6 +60,18 @@ def get_inference_precision():
 
 def _trunk_infer(mod, x, trans, relu_last):
     """Eval-mode fused trunk of a module holding conv1..3 / bn1..3 in the selected arithmetic."""
+    if _INFER_PRECISION != "fp32" and _INFER_REFINE:
+        pooled_bf, arg = ops.trunk_fwd_infer_bf(x, trans, *_trunk_infer_weights_x3(mod, x.device), relu_last=relu_last,
+                                                nterms=_NTERMS[_INFER_PRECISION], want_arg=True)
+        w1, b1, w2p, b2, _, b3 = _trunk_infer_weights(mod, x.device)
+        w3f, ones128, ones1024 = _trunk_refine_weights(mod, x.device)
+        zex = ops.trunk_pool_refine(x.float() if x.dtype == torch.bfloat16 else x, trans, w1, b1, None, None, w2p,
+                                    ones128, b2, arg, w3=w3f, g3=ones1024, variant=1)
+        pooled = zex + b3
+        if relu_last:
+            pooled = torch.where(pooled < 0, torch.zeros_like(pooled), pooled)
+        # a non-finite input coordinate poisons its cloud's row in the bf16 pass (torch.max semantics): keep that
+        return torch.where(torch.isnan(pooled_bf), pooled_bf, pooled)
     if _INFER_PRECISION != "fp32":
         return ops.trunk_fwd_infer_bf(x, trans, *_trunk_infer_weights_x3(mod, x.device), relu_last=relu_last,
                                       nterms=_NTERMS[_INFER_PRECISION])
@@ -145,6 +164,18 @@ def _trunk_infer_weights_x3(mod, device):
         return (w1, b1, ops.split_pack_bf16(w2), b2, ops.split_pack_bf16(w3), b3)
 
     return mod._cache().get(("trunk_x3", device), srcs, build)
+
+
+def _trunk_refine_weights(mod, device):
+    """Operands of the eval-mode pool refinement that no other path keeps: the BN-folded conv3 weight row-major, and the
+    unit vectors standing in for the train-mode layer-2 scale / the sign of gamma3 (both folded into the weights)."""
+    srcs = [mod.conv3.weight, mod.conv3.bias] + _bn_tensors(mod.bn3)
+
+    def build():
+        w3, _ = _fold(mod.conv3, mod.bn3, ops.LAYOUT_ROWMAJOR, device)
+        return (w3, torch.ones(128, device=device), torch.ones(1024, device=device))
+
+    return mod._cache().get(("trunk_refine", device), srcs, build)
 
 
 def _fc_infer_weights(mod, names, device):

@@ -108,9 +108,10 @@ def split_pack_bf16(Wf):
     return out
 
 
-def trunk_fwd_infer_bf(x, trans, w1, b1, w2x, b2, w3x, b3, relu_last, nterms=3, splits=0):
+def trunk_fwd_infer_bf(x, trans, w1, b1, w2x, b2, w3x, b3, relu_last, nterms=3, splits=0, want_arg=False):
     """Reduced-precision trunk on the bf16 matrix cores (pngpd_trunk_fwd_infer_bf): nterms = 3 "bf16x3" split
-    products, nterms = 1 plain bf16.  x (B,3,N) float32 or bfloat16 (bf16 cloud storage)."""
+    products, nterms = 1 plain bf16.  x (B,3,N) float32 or bfloat16 (bf16 cloud storage).  ``want_arg``: also return the
+    (B,1024) int32 arg-max points (pngpd_trunk_fwd_infer_bf_arg) — the input of the eval-mode pool refinement."""
     lib = _lib.load()
     if not isinstance(x, torch.Tensor) or not x.is_cuda or x.dtype not in (torch.float32, torch.bfloat16) or \
             not x.is_contiguous():
@@ -125,8 +126,16 @@ def trunk_fwd_infer_bf(x, trans, w1, b1, w2x, b2, w3x, b3, relu_last, nterms=3, 
         raise RuntimeError("w2x/w3x: expected split_pack_bf16 outputs")
     out = torch.empty(B, 1024, device=x.device, dtype=torch.float32)
     S = int(splits) if splits and splits > 0 else lib.pngpd_trunk_infer_bf_splits(B, N, 0)
-    nbytes = B * S * 1024 * 4 if S > 1 else 0
+    nbytes = B * S * 1024 * (8 if want_arg else 4) if S > 1 else 0
     ws = _workspace(x.device, nbytes)
+    if want_arg:
+        arg = torch.empty(B, 1024, device=x.device, dtype=torch.int32)
+        with _lib.device_guard(x.device):
+            _lib.check(lib.pngpd_trunk_fwd_infer_bf_arg(_ptr(x), int(x.dtype == torch.bfloat16), B, N, _ptr(trans),
+                                                        _ptr(w1), _ptr(b1), _ptr(w2x), _ptr(b2), _ptr(w3x), _ptr(b3),
+                                                        int(bool(relu_last)), int(nterms), S, _ptr(out), _ptr(arg),
+                                                        _ptr(ws), nbytes, _stream(x)), "trunk_fwd_infer_bf_arg")
+        return out, arg
     with _lib.device_guard(x.device):
         _lib.check(lib.pngpd_trunk_fwd_infer_bf(_ptr(x), int(x.dtype == torch.bfloat16), B, N, _ptr(trans), _ptr(w1),
                                                 _ptr(b1), _ptr(w2x), _ptr(b2), _ptr(w3x), _ptr(b3),
@@ -313,8 +322,8 @@ def trunk_pool_refine(x, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, idx, w3sp=None,
     B, _, N = x.shape
     cpr = int(clouds_per_range) if clouds_per_range else max(1, min(16, B // 16))
     zex = torch.empty(B, 1024, device=x.device, dtype=torch.float32)
-    _call("pngpd_trunk_pool_refine", x, x, B, N, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, w3sp, w3, g3, idx, cpr,
-          int(variant), zex)
+    _call("pngpd_trunk_pool_refine", x, x, B, N, trans, w1, b1, s1c, t1c, w2p, s2c, t2c, w3sp, w3, g3, idx.contiguous(),
+          cpr, int(variant), zex)
     return zex
 
 

@@ -159,3 +159,45 @@ def test_refinement_closes_train_mode_parity_on_iid_clouds(modes, cuda_device):
     assert res[("bf16x3", 2)] < 1e-3
     assert res[("bf16x3", 2)] < res[("bf16x3", 0)]
     assert res[("bf16", 2)] < res[("bf16", 0)]
+
+
+@pytest.mark.parametrize("B,N,kind", [(64, 750, "box"), (200, 1024, "diverse"), (5, 129, "gauss")])
+def test_eval_mode_refinement(B, N, kind, cuda_device):
+    """``set_inference_precision(mode, refine=True)``: the bf16 / bf16x3 inference trunk (arg-tracking variant,
+    pngpd_trunk_fwd_infer_bf_arg) only chooses the points; pooled values are re-evaluated in fp32 with the FOLDED
+    inference weights.  Wherever the chosen point is the fp32 arg-max the pooled value equals the fp32 trunk's bit for
+    bit, it never exceeds it, and the log-probs move towards the fp32 path's."""
+    from pointnetgpd_amd.model import pointnet as pn
+    m = build_model(N, 3, 911 + B, 7300 + B).eval().to(cuda_device)
+    x = synth_cloud(B, N, 3300 + B, kind).to(cuda_device)
+    res = {}
+    try:
+        with torch.no_grad():
+            pn.set_inference_precision("fp32")
+            p32 = pn._trunk_infer(m.feat.stn, x, None, True)
+            lp32 = m(x)[0]
+            for prec in ("bf16x3", "bf16"):
+                for refine in (False, True):
+                    pn.set_inference_precision(prec, refine=refine)
+                    res[(prec, refine)] = (pn._trunk_infer(m.feat.stn, x, None, True), m(x)[0])
+            # bf16-STORED clouds take the same path (widened for the fp32 re-evaluation)
+            pn.set_inference_precision("bf16", refine=True)
+            lp_st = m(x.to(torch.bfloat16))[0]
+            # a non-finite coordinate still poisons exactly its cloud
+            xb = x.clone(); xb[1, 0, 7] = float("nan")
+            lp_nan = m(xb)[0]
+    finally:
+        pn.set_inference_precision("fp32")
+    assert "libpngpd.so" in open("/proc/self/maps").read()
+    for prec, min_same in (("bf16x3", 0.99), ("bf16", 0.80)):
+        p_raw, lp_raw = res[(prec, False)]
+        p_ref, lp_ref = res[(prec, True)]
+        same = (p_ref == p32).float().mean().item()
+        d_raw, d_ref = (lp_raw - lp32).abs().max().item(), (lp_ref - lp32).abs().max().item()
+        print(f"[eval refine B={B} N={N} {kind} {prec}] pooled entries bit-equal to fp32: {same:.4f} (unrefined "
+              f"{(p_raw == p32).float().mean().item():.4f}); max|dlogp| vs fp32: {d_raw:.2e} -> {d_ref:.2e}")
+        assert same >= min_same
+        assert (p_ref <= p32).all()                        # the fp32 maximum is the maximum
+        assert d_ref <= max(d_raw, 1e-6) and d_ref < 1e-3
+    assert torch.isfinite(lp_st).all() and (lp_st - lp32).abs().max().item() < 5e-2
+    assert torch.isnan(lp_nan[1]).all() and torch.isfinite(lp_nan[0]).all() and torch.isfinite(lp_nan[2:]).all()
