@@ -124,7 +124,9 @@ def config5_leg(dev, dist, world, G=100000, P=50000, N=1024, k=3, reps=3):
     from pointnetgpd_amd import scoring
     model = build_model(N, k, dev)
     pc, grasps = synth_scene(G, P)
-    scorer = scoring.GraspScorer(model, num_points=N, repeat=1, batch=4096, seed=1, max_keep=8192)
+    # scoring batches of 1024 candidates: every trunk launch of this leg then has the headline's shape (B = N = 1024), so
+    # the per-kernel averages of a rocprofv3 trace of this command stay comparable with roofline.avg_launch_ms
+    scorer = scoring.GraspScorer(model, num_points=N, repeat=1, batch=1024, seed=1, max_keep=8192)
     cloud = torch.from_numpy(pc).to(dev)
 
     def sync():
@@ -132,7 +134,7 @@ def config5_leg(dev, dist, world, G=100000, P=50000, N=1024, k=3, reps=3):
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
-    scoring.score_scene_distributed(scorer.score, cloud, grasps[:4096 * world])      # warm-up (fold cache, workspaces)
+    scoring.score_scene_distributed(scorer.score, cloud, grasps[:2048 * world])      # warm-up (fold cache, workspaces)
     times = []
     for _ in range(reps):
         sync()
