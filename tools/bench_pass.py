@@ -6,7 +6,7 @@ import torch
 from pointnetgpd_amd import ops
 import bench
 dev = torch.device("cuda:0")
-B, N = 1024, 1024
+B, N = int(os.environ.get("PNGPD_BENCH_B", "1024")), 1024
 g = torch.Generator(device="cpu").manual_seed(0)
 x = bench.synth_clouds(B, N, 1, dev)
 T = (torch.eye(3)[None] + 0.1 * torch.randn(B, 3, 3, generator=g)).to(dev).contiguous()
@@ -25,7 +25,7 @@ ev = r(3, 128)
 ONLY = [t for t in os.environ.get("PNGPD_PASSES", "").split(",") if t]
 
 
-def timeit(name, fn, reps=10):
+def timeit(name, fn, reps=10 if B >= 512 else 60):
     if ONLY and not any(name.startswith(t) for t in ONLY):
         return fn()
     fn(); torch.cuda.synchronize()
