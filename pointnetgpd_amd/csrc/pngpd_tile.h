@@ -285,6 +285,44 @@ __device__ __forceinline__ void k128_stream(const float *tile, const float *__re
     }
 }
 
+// The same product (one point block, NPB = 1) with the weight fragments of k-blocks [0, K128_LDS_KB) resident in LDS
+// (wl: [kb][cb][lane] f32x4, filled once per workgroup by k128_fill_lds) and only the last 16 - K128_LDS_KB streamed
+// from L2 — requested first, consumed last, so K128_LDS_KB x 256 MFMA cycles cover their round trip.  With one point
+// block a streamed fragment buys only 256 MFMA cycles against a 1,000-2,000-cycle L2 round trip: pass E's first
+// contraction spent 15.3 k cycles per tile on 4.1 k cycles of matrix work (profiles/r03_phase_times.txt).  Same MFMA
+// order as k128_stream (kb, t ascending): bit-identical.
+#define K128_LDS_KB 13
+#define K128_LDS_FLOATS (K128_LDS_KB * 2 * 64 * 4)
+__device__ __forceinline__ void k128_fill_lds(float *wl, const float *__restrict__ wp128, int tid) {
+    const f32x4 *src = (const f32x4 *)wp128;
+    f32x4 *dst = (f32x4 *)wl;
+    for (int e = tid; e < K128_LDS_KB * 2 * 64; e += 256) {
+        const int lane = e & 63, cb = (e >> 6) & 1, kb = e >> 7;
+        dst[e] = src[(size_t)(cb * 16 + kb) * 64 + lane];
+    }
+}
+__device__ __forceinline__ void k128_lds(const float *tile, const float *wl, const float *__restrict__ wp128, int cb,
+                                         int pb, const Lane &L, f32x16 &acc0) {
+    constexpr int NS = 16 - K128_LDS_KB;
+    const f32x4 *wp = (const f32x4 *)wp128 + (size_t)(cb * 16) * 64 + L.lane;
+    const f32x4 *wlp = (const f32x4 *)wl + cb * 64 + L.lane;
+    const float *a0p = tile + (pb * 32 + L.j) * H2S + L.h * 4;
+    f32x4 wq[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) wq[i] = wp[(K128_LDS_KB + i) * 64];
+    f32x4 a0 = *(const f32x4 *)a0p, w0 = wlp[0];
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) {
+        f32x4 n0 = a0, nw = w0;
+        if (kb + 1 < 16) n0 = *(const f32x4 *)(a0p + (kb + 1) * 8);
+        if (kb + 1 < K128_LDS_KB) nw = wlp[(kb + 1) * 128];
+        const f32x4 wv = kb < K128_LDS_KB ? w0 : wq[kb < K128_LDS_KB ? 0 : kb - K128_LDS_KB];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc0 = mfma32(a0[t], wv[t], acc0);
+        a0 = n0; w0 = nw;
+    }
+}
+
 // ---- bf16 matrix-core variants (opt-in reduced precision, pngpd_bf.h): the LDS tiles stay fp32, operands are
 // converted (NT = 1) or split hi/lo (NT = 3) when they are read — the same LDS traffic as the fp32 loops, an eighth of
 // the MFMA issue slots per product term.

@@ -954,8 +954,10 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
     float *h1 = smem;
     float *dz = h1 + TP * H1S;    // [TP][H2S]
     float *xbuf = dz + TP * H2S;  // 2 x ([3][TP] transformed, [3][TP] original): double-buffered per tile parity
+    float *w2l = xbuf + 12 * TP;  // NT == 0: W2^T fragments of k-blocks [0, K128_LDS_KB), K128_LDS_FLOATS
     const Lane L;
     wg_priority();
+    if constexpr (NT == 0) k128_fill_lds(w2l, E.w2tp, L.tid);   // read after the first tile's barriers
     const int b = blockIdx.x / S, s = blockIdx.x - b * S;
     int t0, t1; tile_range(s, S, T, t0, t1);
     const float *xb = x + (size_t)b * 3 * N;
@@ -1094,10 +1096,10 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
         TM(4)
         {
             // dh1[point][c1] = sum_o dz[point][o] * W2[o][c1]   (K = 128), one 32x32 tile per wave
-            f32x16 acc, unused;
+            f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            if constexpr (NT == 0) k128_stream<1>(dz, E.w2tp, cb1, pb1, L, acc, unused);
+            if constexpr (NT == 0) k128_lds(dz, w2l, E.w2tp, cb1, pb1, L, acc);
             else k128_bf<NT>(dz, E.w2tx, cb1, pb1, L, acc);
             if (tile + 1 < t1) { store_points(tile + 1); fetch_tile(tile + 1); }
             TM(5)
@@ -1772,7 +1774,7 @@ int pngpd_trunk_bwd_e(const float *x, int B, int N, const float *trans,
     TrainChan P = make_chan(w1, b1, s1c, t1c, w2p, nullptr, nullptr);
     BwdEParams E; E.is1 = is1; E.nm1 = nm1; E.is2 = is2; E.nm2 = nm2; E.a1m = a1m; E.a2m = a2m; E.dsc2 = dsc2;
     E.w2tp = w2tp; E.w2tx = nullptr;
-    const size_t lds = BWD_E_LDS_FLOATS * sizeof(float);
+    const size_t lds = (BWD_E_LDS_FLOATS + K128_LDS_FLOATS) * sizeof(float);   // 79 KB: two workgroups per CU still fit
     const dim3 grid((unsigned)B * S);
     return z2t ? launch_bwd_e<true, 0>(grid, lds, (hipStream_t)stream, x, N, trans, P, E, T, S, z2t, g2t, pc, pR, pW2)
                : launch_bwd_e<false, 0>(grid, lds, (hipStream_t)stream, x, N, trans, P, E, T, S, nullptr, g2t, pc, pR, pW2);
