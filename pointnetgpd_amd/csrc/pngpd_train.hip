@@ -599,6 +599,8 @@ struct BwdDParams {
 };
 #define BWD_D_HITS 1048   // per list: up to 1024 hit records + 24 zero records (16-hit steps, two steps of read-ahead)
 #define BWD_D_LDS_FLOATS (TP * H2S + TP * H1S + 3 * TP + 1024 + 1024 + 4 * BWD_D_HITS + 16)
+#define BWD_D_APL_KB 5     // k-blocks of A resident in LDS (fp32 kernel reading z2 back): 20 KB, 78.2 KB per workgroup
+#define BWD_D_APL_FLOATS (BWD_D_APL_KB * 4 * 64 * 4)
 
 // LOADZ: the raw layer-2 output z2 was stored by pass B (z2t, lane-major tiles) and is read back here instead of
 // recomputing layers 1-2: 64 of the 324 MFMAs per wave and tile, the layer-1 VALU work, the h1 tile and one of the
@@ -621,7 +623,8 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
     // ONE LDS read per hit (the old u16 list cost a second, dependent read of the coefficient row per hit, and every
     // LDS round trip of this phase queues behind the other waves' A-fragment reads)
     uint2 *hits = (uint2 *)(idxl + 1024);
-    int *hcnt = (int *)(hits + 2 * BWD_D_HITS);               // [2 lists][4 waves]
+    int *hcnt = (int *)(hits + 2 * BWD_D_HITS);               // [2 lists][4 waves] (16 words reserved)
+    float *apl = (float *)(hcnt + 16);    // LOADZ && NT == 0: fragments of A, k-blocks [0, BWD_D_APL_KB), [kb][cb][lane] f32x4
     const Lane L;
     wg_priority();
     const int b = blockIdx.x / S, s = blockIdx.x - b * S;
@@ -636,6 +639,12 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
     for (int i = L.tid; i < 1024; i += 256) {
         cfl[i] = D.coef[(size_t)b * 1024 + i];
         idxl[i] = D.idx[(size_t)b * 1024 + i];
+    }
+    if constexpr (LOADZ && NT == 0) {
+        for (int e = L.tid; e < BWD_D_APL_KB * 4 * 64; e += 256) {
+            const int lane = e & 63, cbb = (e >> 6) & 3, kb = e >> 8;
+            ((f32x4 *)apl)[e] = ((const f32x4 *)D.Ap)[(size_t)(cbb * 16 + kb) * 64 + lane];
+        }
     }
     double a1s = 0.0, a2s = 0.0;   // running sums over the workgroup's tiles (tile partials are fp32)
     const int cb = L.wave;
@@ -791,13 +800,36 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
             const f32x4 *wp = (const f32x4 *)D.Ap + (size_t)(cb * 16) * 64 + L.lane;
             const float *a0p = h2 + L.j * H2S + L.h * 4;
             const float *a1p = h2 + (32 + L.j) * H2S + L.h * 4;
-#pragma unroll 4
-            for (int kb = 0; kb < 16; ++kb) {
-                const f32x4 wv = wp[kb * 64];
-                const f32x4 a0 = *(const f32x4 *)(a0p + kb * 8);
-                const f32x4 a1 = *(const f32x4 *)(a1p + kb * 8);
+            if constexpr (LOADZ) {
+                // k-blocks [0, BWD_D_APL_KB) of A from LDS, the rest through a 4-deep ring requested at the top (the LDS
+                // blocks' 2,560 MFMA cycles cover the first round trip)
+                const f32x4 *al = (const f32x4 *)apl + cb * 64 + L.lane;
+                constexpr int NL = BWD_D_APL_KB, RING = 4;
+                f32x4 wq[RING];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) { d0 = mfma32(a0[t], wv[t], d0); d1 = mfma32(a1[t], wv[t], d1); }
+                for (int i = 0; i < RING; ++i) wq[i] = wp[(NL + i) * 64];
+#pragma unroll
+                for (int kb = 0; kb < 16; ++kb) {
+                    f32x4 wv;
+                    if (kb < NL) wv = al[kb * 256];
+                    else {
+                        wv = wq[(kb - NL) % RING];
+                        if (kb + RING < 16) wq[(kb - NL) % RING] = wp[(kb + RING) * 64];
+                    }
+                    const f32x4 a0 = *(const f32x4 *)(a0p + kb * 8);
+                    const f32x4 a1 = *(const f32x4 *)(a1p + kb * 8);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { d0 = mfma32(a0[t], wv[t], d0); d1 = mfma32(a1[t], wv[t], d1); }
+                }
+            } else {
+#pragma unroll 4
+                for (int kb = 0; kb < 16; ++kb) {
+                    const f32x4 wv = wp[kb * 64];
+                    const f32x4 a0 = *(const f32x4 *)(a0p + kb * 8);
+                    const f32x4 a1 = *(const f32x4 *)(a1p + kb * 8);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { d0 = mfma32(a0[t], wv[t], d0); d1 = mfma32(a1[t], wv[t], d1); }
+                }
             }
         }
         TM(4)
@@ -1734,7 +1766,7 @@ int pngpd_trunk_bwd_d(const float *x, int B, int N, const float *trans,
     if (N > (1 << 30)) return PNGPD_ERR_UNSUPPORTED;
     TrainChan P = make_chan(w1, b1, s1c, t1c, w2p, s2c, t2c);
     BwdDParams D; D.is2 = is2; D.nm2 = nm2; D.Ap = Ap; D.Ax = nullptr; D.cvec = cvec; D.w3 = w3; D.idx = idx; D.coef = coef;
-    const size_t lds = (BWD_D_LDS_FLOATS - (z2t ? TP * H1S : 0)) * sizeof(float);
+    const size_t lds = (z2t ? BWD_D_LDS_FLOATS - TP * H1S + BWD_D_APL_FLOATS : BWD_D_LDS_FLOATS) * sizeof(float);
     const dim3 grid((unsigned)B * S);
     return z2t ? launch_bwd_d<true, 0>(grid, lds, (hipStream_t)stream, x, N, trans, P, D, T, S, z2t, g2t, pa, ps2)
                : launch_bwd_d<false, 0>(grid, lds, (hipStream_t)stream, x, N, trans, P, D, T, S, nullptr, g2t, pa, ps2);
