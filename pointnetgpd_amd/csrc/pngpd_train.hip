@@ -800,7 +800,12 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
             const f32x4 *wp = (const f32x4 *)D.Ap + (size_t)(cb * 16) * 64 + L.lane;
             const float *a0p = h2 + L.j * H2S + L.h * 4;
             const float *a1p = h2 + (32 + L.j) * H2S + L.h * 4;
-            if constexpr (LOADZ) {
+#ifndef PNGPD_DBG_NO_D_LDS
+            constexpr bool apl_on = LOADZ;
+#else
+            constexpr bool apl_on = false;
+#endif
+            if constexpr (apl_on) {
                 // k-blocks [0, BWD_D_APL_KB) of A from LDS, the rest through a 4-deep ring requested at the top (the LDS
                 // blocks' 2,560 MFMA cycles cover the first round trip)
                 const f32x4 *al = (const f32x4 *)apl + cb * 64 + L.lane;
@@ -1131,7 +1136,12 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#ifndef PNGPD_DBG_NO_E_LDS
             if constexpr (NT == 0) k128_lds(dz, w2l, E.w2tp, cb1, pb1, L, acc);
+#else
+            f32x16 unused;
+            if constexpr (NT == 0) k128_stream<1>(dz, E.w2tp, cb1, pb1, L, acc, unused);
+#endif
             else k128_bf<NT>(dz, E.w2tx, cb1, pb1, L, acc);
             if (tile + 1 < t1) { store_points(tile + 1); fetch_tile(tile + 1); }
             TM(5)

@@ -389,15 +389,15 @@ __global__ __launch_bounds__(128 * DW3_KQ) void dw3_finalize_kernel(
 // A = W3^T diag(g3 m2/sig3^2) W3 (written MFMA_B-packed, fp32), cvec = A mh - W3^T (s3 m1).
 // block = row i of A; 512 threads = 128 columns j x 4 quarters of the channel range.  The per-channel
 // coefficient (one fp64 divide + sqrt each) is computed ONCE per block into LDS, so the contraction loop is one
-// coalesced weight load + one LDS broadcast + one FMA per channel, 32 loads in flight; the two scalar sums of the block
-// go through wave shuffles (three barriers in all; the two LDS trees cost sixteen).
+// coalesced weight load + one LDS broadcast + one FMA per channel, 16 loads in flight.
 __global__ __launch_bounds__(512) void a_cvec_finalize_kernel(
     const float *__restrict__ w3, const float *__restrict__ g3, const double *__restrict__ stats,
     const double *__restrict__ m12, const double *__restrict__ sh, double M, double eps,
     float *__restrict__ Ap, float *__restrict__ cvec) {
     __shared__ double tco[1024];     // w3[c][i] * g3[c] m2[c] / var[c]
     __shared__ double part[4][128];
-    __shared__ double usum[8], rsum[2];
+    __shared__ double ured[512];
+    __shared__ double red[128];
     const int tid = threadIdx.x, i = blockIdx.x, j = tid & 127, q = tid >> 7;
     double u = 0.0;
     for (int c = tid; c < 1024; c += 512) {
@@ -406,30 +406,28 @@ __global__ __launch_bounds__(512) void a_cvec_finalize_kernel(
         tco[c] = wi * ((double)g3[c] * m12[1024 + c] / var);
         u += wi * ((double)g3[c] / sqrt(var)) * m12[c];
     }
-    u = wave_sum_f64(u);
-    if ((tid & 63) == 0) usum[tid >> 6] = u;
+    ured[tid] = u;
     __syncthreads();
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     const float *wj = w3 + (size_t)(q * 256) * 128 + j;
     const double *tq = tco + q * 256;
-#pragma unroll 8
+#pragma unroll 4
     for (int c = 0; c < 256; c += 4) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] += tq[c + e] * (double)wj[(size_t)(c + e) * 128];
     }
     part[q][j] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    for (int s = 256; s > 0; s >>= 1) { __syncthreads(); if (tid < s) ured[tid] += ured[tid + s]; }
     __syncthreads();
     if (q == 0) {
         const double a = part[0][j] + part[1][j] + part[2][j] + part[3][j];
         const int cb = i >> 5, jj = i & 31, kb = j >> 3, h = (j >> 2) & 1, t = j & 3;   // MFMA_B packing of (i, j)
         Ap[(((cb * 16 + kb) * 64) + h * 32 + jj) * 4 + t] = (float)a;
-        const double r = wave_sum_f64(a * (sh[j] / M));
-        if ((tid & 63) == 0) rsum[tid >> 6] = r;
+        red[j] = a * (sh[j] / M);
     }
     __syncthreads();
-    if (tid == 0)
-        cvec[i] = (float)((rsum[0] + rsum[1]) -
-                          (((usum[0] + usum[1]) + (usum[2] + usum[3])) + ((usum[4] + usum[5]) + (usum[6] + usum[7]))));
+    for (int s = 64; s > 0; s >>= 1) { if (q == 0 && j < s) red[j] += red[j + s]; __syncthreads(); }
+    if (tid == 0) cvec[i] = (float)(red[0] - ured[0]);
 }
 
 // a12 (128,2) f64 = sum g2, sum g2*zhat2  ->  dg2 = a2, dbe2 = a1 and the pass-E vectors
