@@ -360,6 +360,63 @@ __device__ __forceinline__ void k128_bf(const float *tile, const u16 *__restrict
     }
 }
 
+// Both point blocks of the tile against the same fragments (pass D's h2 A): each fragment pair is fetched once and
+// serves two accumulators (two separate k128_bf calls fetched it twice); per accumulator the order is k128_bf's.
+template <int NT>
+__device__ __forceinline__ void k128_bf2(const float *tile, const u16 *__restrict__ wx, int cb, const Lane &L,
+                                         f32x16 &acc0, f32x16 &acc1) {
+    const float *a0p = tile + L.j * H2S + L.h * 8;
+    const float *a1p = tile + (32 + L.j) * H2S + L.h * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        f32x4 wh, wl, ah, al;
+        bf_wfrag<NT>(wx, 8, cb, ks, L.lane, wh, wl);
+        bf_pack8<NT>(*(const f32x4 *)(a0p + ks * 16), *(const f32x4 *)(a0p + ks * 16 + 4), ah, al);
+        acc0 = bf_mma<NT>(ah, al, wh, wl, acc0);
+        bf_pack8<NT>(*(const f32x4 *)(a1p + ks * 16), *(const f32x4 *)(a1p + ks * 16 + 4), ah, al);
+        acc1 = bf_mma<NT>(ah, al, wh, wl, acc1);
+    }
+}
+
+// The same with the fragments of k-steps [0, K128BF_LDS_KS) resident in LDS (wl: [ks][cb][part][lane] quads, hi only
+// for NT == 1; filled once per workgroup) and the rest streamed — requested first, consumed last.  Pass E's first
+// contraction covers one point block per wave: a streamed fragment pair buys 3 (1) bf16 matrix instructions against an L2
+// round trip.  Same instruction order as k128_bf: bit-identical.
+#define K128BF_LDS_KS(NT) ((NT) == 3 ? 6 : 8)      // 24 KB (hi + lo) / 16 KB (hi): within K128_LDS_FLOATS
+template <int NT>
+__device__ __forceinline__ void k128_bf_fill_lds(float *wl, const u16 *__restrict__ wx, int tid) {
+    constexpr int NK = K128BF_LDS_KS(NT), NP = NT == 3 ? 2 : 1;
+    const f32x4 *src = (const f32x4 *)wx;
+    f32x4 *dst = (f32x4 *)wl;
+    for (int e = tid; e < NK * 2 * NP * 64; e += 256) {
+        const int lane = e & 63, q = e >> 6;
+        const int part = q % NP, cb = (q / NP) & 1, ks = q / (2 * NP);
+        dst[e] = src[((size_t)(cb * 8 + ks) * 2 + part) * 64 + lane];
+    }
+}
+template <int NT>
+__device__ __forceinline__ void k128_bf_lds(const float *tile, const float *wl, const u16 *__restrict__ wx, int cb,
+                                            int pb, const Lane &L, f32x16 &acc) {
+    constexpr int NK = K128BF_LDS_KS(NT), NP = NT == 3 ? 2 : 1, NS = 8 - NK;
+    const float *ap = tile + (pb * 32 + L.j) * H2S + L.h * 8;
+    const f32x4 *wq = (const f32x4 *)wl + (size_t)cb * NP * 64 + L.lane;
+    f32x4 sh[NS > 0 ? NS : 1], sl[NS > 0 ? NS : 1];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) bf_wfrag<NT>(wx, 8, cb, NK + i, L.lane, sh[i], sl[i]);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        f32x4 wh, wlo, ah, al;
+        if (ks < NK) {
+            wh = wq[(size_t)ks * 2 * NP * 64];
+            if (NT == 3) wlo = wq[(size_t)ks * 2 * NP * 64 + 64]; else wlo = wh;
+        } else {
+            wh = sh[ks < NK ? 0 : ks - NK]; wlo = sl[ks < NK ? 0 : ks - NK];
+        }
+        bf_pack8<NT>(*(const f32x4 *)(ap + ks * 16), *(const f32x4 *)(ap + ks * 16 + 4), ah, al);
+        acc = bf_mma<NT>(ah, al, wh, wlo, acc);
+    }
+}
+
 // Experiment hook (variant builds: -DPNGPD_PRIO=n): a static priority for every other resident workgroup of a CU.
 #ifndef PNGPD_PRIO
 #define PNGPD_PRIO 0

@@ -746,8 +746,7 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_d_kernel(
         for (int r = 0; r < 16; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
         if constexpr (NT > 0) {
             // --- the three contractions on bf16 / bf16x3 operands: 16 k indices per instruction ---
-            k128_bf<NT>(h2, D.Ax, cb, 0, L, d0);       // d = h2 A
-            k128_bf<NT>(h2, D.Ax, cb, 1, L, d1);
+            k128_bf2<NT>(h2, D.Ax, cb, L, d0, d1);     // d = h2 A
             {   // sparse term: 16 hits per k-step; lane (j, h) supplies hits e0 + 8h .. 8h+7
                 const float *w3c = D.w3 + c2;
                 auto sparse = [&](const uint2 *hl, int n, f32x16 &d) {
@@ -991,10 +990,11 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
     float *h1 = smem;
     float *dz = h1 + TP * H1S;    // [TP][H2S]
     float *xbuf = dz + TP * H2S;  // 2 x ([3][TP] transformed, [3][TP] original): double-buffered per tile parity
-    float *w2l = xbuf + 12 * TP;  // NT == 0: W2^T fragments of k-blocks [0, K128_LDS_KB), K128_LDS_FLOATS
+    float *w2l = xbuf + 12 * TP;  // W2^T fragments resident for the whole kernel (k128_lds / k128_bf_lds), K128_LDS_FLOATS
     const Lane L;
     wg_priority();
     if constexpr (NT == 0) k128_fill_lds(w2l, E.w2tp, L.tid);   // read after the first tile's barriers
+    else k128_bf_fill_lds<NT>(w2l, E.w2tx, L.tid);
     const int b = blockIdx.x / S, s = blockIdx.x - b * S;
     int t0, t1; tile_range(s, S, T, t0, t1);
     const float *xb = x + (size_t)b * 3 * N;
@@ -1142,7 +1142,7 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
             f32x16 unused;
             if constexpr (NT == 0) k128_stream<1>(dz, E.w2tp, cb1, pb1, L, acc, unused);
 #endif
-            else k128_bf<NT>(dz, E.w2tx, cb1, pb1, L, acc);
+            else k128_bf_lds<NT>(dz, w2l, E.w2tx, cb1, pb1, L, acc);
             if (tile + 1 < t1) { store_points(tile + 1); fetch_tile(tile + 1); }
             TM(5)
             // g1 = dh1 masked by ReLU(bn1) (rows past N: dz == 0 -> 0); c1 = sum g1, c2 = sum g1 zhat1, R = sum g1 x^T,
@@ -1836,7 +1836,7 @@ int pngpd_trunk_bwd_e_bf(const float *x, int B, int N, const float *trans,
     TrainChan P = make_chan(w1, b1, s1c, t1c, nullptr, nullptr, nullptr);
     BwdEParams E; E.is1 = is1; E.nm1 = nm1; E.is2 = is2; E.nm2 = nm2; E.a1m = a1m; E.a2m = a2m; E.dsc2 = dsc2;
     E.w2tp = nullptr; E.w2tx = (const u16 *)w2tx;
-    const size_t lds = BWD_E_LDS_FLOATS * sizeof(float);
+    const size_t lds = (BWD_E_LDS_FLOATS + K128_LDS_FLOATS) * sizeof(float);
     const dim3 grid((unsigned)B * S);
     return nterms == 1 ? launch_bwd_e<true, 1>(grid, lds, (hipStream_t)stream, x, N, trans, P, E, T, S, z2t, g2t, pc, pR, pW2)
                        : launch_bwd_e<true, 3>(grid, lds, (hipStream_t)stream, x, N, trans, P, E, T, S, z2t, g2t, pc, pR, pW2);
