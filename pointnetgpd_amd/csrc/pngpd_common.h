@@ -163,3 +163,30 @@ static inline int pngpd_launch_status() {
 #define TM_END
 #define TM_END_TO(arr)
 #endif
+
+// pass A of the training trunk: one cloud's input moments in fp64, mom[b] = {sx,sy,sz, sxx,sxy,sxz, syy,syz,szz}; one
+// 256-thread workgroup per cloud.  A device function because two launches carry it: cloud_moments_kernel
+// (pngpd_cloud_moments) and, in the fused forward, the tail workgroups of the weight re-layout launch (train_pack_kernel).
+__device__ __forceinline__ void cloud_moments_body(const float *__restrict__ x, int N, int b, double *__restrict__ mom) {
+    __shared__ double red[4][9];
+    const int tid = threadIdx.x;
+    const float *xb = x + (size_t)b * 3 * N;
+    double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int n = tid; n < N; n += 256) {
+        double x0 = xb[n], x1 = xb[N + n], x2 = xb[2 * N + n];
+        a[0] += x0; a[1] += x1; a[2] += x2;
+        a[3] += x0 * x0; a[4] += x0 * x1; a[5] += x0 * x2;
+        a[6] += x1 * x1; a[7] += x1 * x2; a[8] += x2 * x2;
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) a[i] += __shfl_xor(a[i], m);
+    }
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) red[tid >> 6][i] = a[i];
+    }
+    __syncthreads();
+    if (tid < 9) mom[(size_t)b * 9 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}

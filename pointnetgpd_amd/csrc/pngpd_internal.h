@@ -21,7 +21,9 @@ int pngpd_reduce_fin_launch(RFArgs &A, int nseg, void *stream);
 
 #define PACK_MAX_JOBS 6
 struct PackJob { const float *W; const float *sgn_src; void *out; int C, K, transpose, src_packed, fmt; };
-struct PackArgs { PackJob job[PACK_MAX_JOBS]; int first[PACK_MAX_JOBS + 1]; };
+// mom_x != NULL: mom_B more workgroups behind the pack jobs compute the per-cloud input moments (pass A) of x (B,3,N)
+// in the same launch — the two are independent and both precede bn1's finalize in the fused forward.
+struct PackArgs { PackJob job[PACK_MAX_JOBS]; int first[PACK_MAX_JOBS + 1]; const float *mom_x; double *mom; int mom_N, mom_B; };
 int pngpd_train_pack_launch(PackArgs &A, int njobs, void *stream);
 
 // The VALU order of pngpd_trunk_pool_refine that reproduces v_mfma_f32_32x32x2_f32 bit for bit (probed on the device:

@@ -45,27 +45,7 @@ static inline bool splits_ok(int S, int T) { return S >= 1 && S <= T; }
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cloud_moments_kernel(const float *__restrict__ x, int N,
                                                             double *__restrict__ mom) {
-    __shared__ double red[4][9];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const float *xb = x + (size_t)b * 3 * N;
-    double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int n = tid; n < N; n += 256) {
-        double x0 = xb[n], x1 = xb[N + n], x2 = xb[2 * N + n];
-        a[0] += x0; a[1] += x1; a[2] += x2;
-        a[3] += x0 * x0; a[4] += x0 * x1; a[5] += x0 * x2;
-        a[6] += x1 * x1; a[7] += x1 * x2; a[8] += x2 * x2;
-    }
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) a[i] += __shfl_xor(a[i], m);
-    }
-    if ((tid & 63) == 0) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) red[tid >> 6][i] = a[i];
-    }
-    __syncthreads();
-    if (tid < 9) mom[(size_t)b * 9 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    cloud_moments_body(x, N, (int)blockIdx.x, mom);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -660,7 +660,11 @@ int pngpd_reduce_fin_launch(RFArgs &A, int nseg, void *stream) {
 //   128x128 matrix pngpd_a_cvec_finalize writes), rows scaled by sign(sgn_src[c]) (+1 for >= 0: the sign fold of W3),
 //   written MFMA_B-packed fp32 (fmt 0, pngpd_fold_conv_bn's layout) or as split_pack_bf16 fragments (fmt 1).
 // ---------------------------------------------------------------------------------------
-__global__ void train_pack_kernel(PackArgs A) {
+__global__ __launch_bounds__(256) void train_pack_kernel(PackArgs A) {
+    if ((int)blockIdx.x >= A.first[PACK_MAX_JOBS]) {     // pass A rides behind the pack jobs (workgroup-uniform branch)
+        cloud_moments_body(A.mom_x, A.mom_N, (int)blockIdx.x - A.first[PACK_MAX_JOBS], A.mom);
+        return;
+    }
     int g = 0;
 #pragma unroll
     for (int i = 1; i < PACK_MAX_JOBS; ++i) g += ((int)blockIdx.x >= A.first[i]) ? 1 : 0;
@@ -701,6 +705,10 @@ int pngpd_train_pack_launch(PackArgs &A, int njobs, void *stream) {
         total += (j.C * j.K + 255) / 256;
     }
     A.first[PACK_MAX_JOBS] = total;
+    if (A.mom_x) {
+        if (!A.mom || A.mom_N <= 0 || A.mom_B <= 0) return PNGPD_ERR_INVALID_ARG;
+        total += A.mom_B;
+    }
     hipLaunchKernelGGL(train_pack_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, A);
     return pngpd_launch_status();
 }

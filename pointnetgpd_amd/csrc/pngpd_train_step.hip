@@ -150,14 +150,10 @@ int pngpd_trunk_train_fwd(const pngpd_trunk_train_t *a, void *stream) {
     if (!carve_save(cs, d, s) || !carve_fwd(cf, d, f)) return PNGPD_ERR_WORKSPACE;
     const int B = d.B, N = d.N, S = d.S;
     const float *x = a->x, *T = a->trans;
-    // ---- pass A + BN1 (closed form from the per-cloud moments)
-    CHK(pngpd_cloud_moments(x, B, N, s.mom, stream));
-    CHK(pngpd_bn1_finalize(s.mom, T, B, N, a->w1, a->b1, a->g1, a->be1, a->eps, a->momentum, a->rm1, a->rv1,
-                           a->nbt1, s.chan1, s.stats1, stream));
-    const float *s1c = s.chan1, *t1c = s.chan1 + 64;
-    // ---- every weight re-layout of the step in one launch
+    // ---- pass A (per-cloud moments) and every weight re-layout of the step in ONE launch: the two are independent
     {
-        PackArgs P; int n = 0;
+        PackArgs P{}; int n = 0;
+        P.mom_x = x; P.mom = s.mom; P.mom_N = N; P.mom_B = B;
         const bool need_f32_side = d.nt_side == 0;
         const bool refine = d.nt && a->refine;
         if (need_f32_side || refine) P.job[n++] = PackJob{a->w2, nullptr, s.w2p, 128, 64, 0, 0, 0};
@@ -172,6 +168,10 @@ int pngpd_trunk_train_fwd(const pngpd_trunk_train_t *a, void *stream) {
         }
         CHK(pngpd_train_pack_launch(P, n, stream));
     }
+    // ---- BN1 (closed form from the per-cloud moments)
+    CHK(pngpd_bn1_finalize(s.mom, T, B, N, a->w1, a->b1, a->g1, a->be1, a->eps, a->momentum, a->rm1, a->rv1,
+                           a->nbt1, s.chan1, s.stats1, stream));
+    const float *s1c = s.chan1, *t1c = s.chan1 + 64;
     // ---- pass B (z2 = W2 h1 once, stored for passes C / D / E) + BN2
     const bool store_z2 = d.nt_side ? true : (d.nt == 0 || a->need_bwd);
     if (d.nt_side)
@@ -243,7 +243,7 @@ int pngpd_trunk_train_bwd(const pngpd_trunk_train_t *a, void *stream) {
     CHK(pngpd_a_cvec_finalize(s.sh, B, N, a->w3, a->g3, s.stats3, w.m12, a->eps, w.Ap, w.cvec, stream));
     // ---- arg-extremum gather (sparse term of dW3) and pass D
     if (nt) {
-        PackArgs P;
+        PackArgs P{};
         P.job[0] = PackJob{w.Ap, nullptr, w.Ax, 128, 128, 0, 1, 1};
         CHK(pngpd_train_pack_launch(P, 1, stream));
         CHK(pngpd_trunk_bwd_gather_bf(x, B, N, T, a->w1, a->b1, s1c, t1c, s.w2x, nt, s2c, t2c, a->idx, w.coef, d.cpr,
