@@ -33,3 +33,17 @@ int pngpd_train_pack_launch(PackArgs &A, int njobs, void *stream);
 // pngpd_fc_bwd with the bias gradient written as an exact zero (zero_db != 0): layers that feed a train-mode BatchNorm.
 int pngpd_fc_bwd_impl(const float *g, const float *x, const float *W, int B, int K, int Nout,
                       float *dW, float *dx, float *db, int zero_db, void *stream);
+
+// Passes of the trunk backward with an optional TAIL: independent finalize work carried as extra workgroups of the same
+// launch (pngpd_glue_bodies.h).  tail == NULL: exactly the public entries.
+struct DW3Args;
+struct ACvecArgs;
+int pngpd_bwd_gather_impl(const float *x, int B, int N, const float *trans, const float *w1, const float *b1,
+                          const float *s1c, const float *t1c, const float *w2p, const void *w2x, int nterms,
+                          const float *s2c, const float *t2c, const int *idx, const float *coef,
+                          int clouds_per_range, float *Gp, const ACvecArgs *tail, void *stream);
+int pngpd_bwd_e_impl(const float *x, int B, int N, const float *trans, const float *w1, const float *b1,
+                     const float *s1c, const float *t1c, const float *w2p, const float *is1, const float *nm1,
+                     const float *is2, const float *nm2, const float *a1m, const float *a2m, const float *dsc2,
+                     const float *w2tp, const void *w2tx, int nterms, const float *z2t, const float *g2t, int S,
+                     float *pc, float *pR, float *pW2, const DW3Args *tail, void *stream);

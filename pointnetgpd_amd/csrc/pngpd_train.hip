@@ -15,6 +15,8 @@
 // across passes):   h1 = relu(z1*s1c + t1c),  zhat1 = z1*is1 + nm1,   z1 = W1 x' + b1
 //                   h2 = relu(z2*s2c + t2c),  zhat2 = z2*is2 + nm2,   z2 = W2 h1   (no bias)
 #include "pngpd_tile.h"
+#include "pngpd_glue_bodies.h"
+#include "pngpd_internal.h"
 
 #ifdef PNGPD_TIMING
 __device__ unsigned long long pngpd_tm[16];
@@ -340,8 +342,12 @@ template <int NT>
 __global__ __launch_bounds__(256, 4) void trunk_bwd_gather_kernel(   // 4 workgroups per CU: <= 128 VGPRs (129 costs 25 %)
     const float *__restrict__ x, int B, int N, const float *__restrict__ trans, TrainChan P,
     const int *__restrict__ idx, const float *__restrict__ coef, int clouds_per_range,
-    float *__restrict__ Gp) {
+    float *__restrict__ Gp, const ACvecArgs AT, int n_main) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if ((int)blockIdx.x >= n_main) {   // tail workgroups (fused backward): A / cvec for pass D, row blockIdx.x - n_main
+        a_cvec_finalize_body<256>(AT, (int)blockIdx.x - n_main, (double *)smem);
+        return;
+    }
     float *h1 = smem;
     float *xcf = h1 + TP * H1S;   // 2 x ([3][TP] points, [TP] coef): double-buffered by cloud parity
     const Lane L;
@@ -964,9 +970,13 @@ template <bool LOADZ, int NT>   // LOADZ: z2 read back from z2t instead of recom
 __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
     const float *__restrict__ x, int N, const float *__restrict__ trans, TrainChan P, BwdEParams E,
     int T, int S, const f32x4 *__restrict__ z2t, const f32x4 *__restrict__ g2t, float *__restrict__ pc,
-    float *__restrict__ pR, float *__restrict__ pW2) {
+    float *__restrict__ pR, float *__restrict__ pW2, const DW3Args WT, int n_main) {
     static_assert(NT == 0 || LOADZ, "the bf16 variants read z2 back");
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if ((int)blockIdx.x >= n_main) {   // tail workgroups (fused backward): dW3's finalize, block blockIdx.x - n_main
+        dw3_finalize_body<2>(WT, (int)blockIdx.x - n_main, (double *)smem);
+        return;
+    }
     float *h1 = smem;
     float *dz = h1 + TP * H1S;    // [TP][H2S]
     float *xbuf = dz + TP * H2S;  // 2 x ([3][TP] transformed, [3][TP] original): double-buffered per tile parity
@@ -1576,10 +1586,10 @@ static int bn2_stats_impl(const float *x, int B, int N, const float *trans, cons
     return pngpd_launch_status();
 }
 
-static int bwd_gather_impl(const float *x, int B, int N, const float *trans, const float *w1, const float *b1,
+int pngpd_bwd_gather_impl(const float *x, int B, int N, const float *trans, const float *w1, const float *b1,
                            const float *s1c, const float *t1c, const float *w2p, const void *w2x, int nterms,
                            const float *s2c, const float *t2c, const int *idx, const float *coef,
-                           int clouds_per_range, float *Gp, void *stream) {
+                           int clouds_per_range, float *Gp, const ACvecArgs *tail, void *stream) {
     if (!x || !w1 || !b1 || !s1c || !t1c || !(nterms ? w2x : (const void *)w2p) || !s2c || !t2c || !idx || !coef ||
         !Gp || B <= 0 || N <= 0 || clouds_per_range <= 0 || (nterms != 0 && nterms != 1 && nterms != 3))
         return PNGPD_ERR_INVALID_ARG;
@@ -1590,14 +1600,17 @@ static int bwd_gather_impl(const float *x, int B, int N, const float *trans, con
                    : nterms == 1 ? (const void *)trunk_bwd_gather_kernel<1> : (const void *)trunk_bwd_gather_kernel<3>;
     int st = pngpd_allow_lds(fn, lds);
     if (st != PNGPD_OK) return st;
-    const dim3 grid((unsigned)R * 16);
+    const int n_main = R * 16;
+    const dim3 grid((unsigned)(n_main + (tail ? 128 : 0)));   // + one workgroup per row of A
+    const ACvecArgs AT = tail ? *tail : ACvecArgs{};
+    static_assert((TP * H1S + 8 * TP) * sizeof(float) >= ACVEC_LDS_DOUBLES * sizeof(double), "tail LDS");
     hipStream_t sm = (hipStream_t)stream;
     if (nterms == 0)
-        hipLaunchKernelGGL(trunk_bwd_gather_kernel<0>, grid, dim3(256), lds, sm, x, B, N, trans, P, idx, coef, clouds_per_range, Gp);
+        hipLaunchKernelGGL(trunk_bwd_gather_kernel<0>, grid, dim3(256), lds, sm, x, B, N, trans, P, idx, coef, clouds_per_range, Gp, AT, n_main);
     else if (nterms == 1)
-        hipLaunchKernelGGL(trunk_bwd_gather_kernel<1>, grid, dim3(256), lds, sm, x, B, N, trans, P, idx, coef, clouds_per_range, Gp);
+        hipLaunchKernelGGL(trunk_bwd_gather_kernel<1>, grid, dim3(256), lds, sm, x, B, N, trans, P, idx, coef, clouds_per_range, Gp, AT, n_main);
     else
-        hipLaunchKernelGGL(trunk_bwd_gather_kernel<3>, grid, dim3(256), lds, sm, x, B, N, trans, P, idx, coef, clouds_per_range, Gp);
+        hipLaunchKernelGGL(trunk_bwd_gather_kernel<3>, grid, dim3(256), lds, sm, x, B, N, trans, P, idx, coef, clouds_per_range, Gp, AT, n_main);
     return pngpd_launch_status();
 }
 
@@ -1615,11 +1628,15 @@ static int launch_bwd_d(dim3 grid, size_t lds, hipStream_t sm, const float *x, i
 template <bool LOADZ, int NT>
 static int launch_bwd_e(dim3 grid, size_t lds, hipStream_t sm, const float *x, int N, const float *trans,
                         const TrainChan &P, const BwdEParams &E, int T, int S, const float *z2t, const float *g2t,
-                        float *pc, float *pR, float *pW2) {
+                        float *pc, float *pR, float *pW2, const DW3Args *tail) {
     int st = pngpd_allow_lds((const void *)trunk_bwd_e_kernel<LOADZ, NT>, lds);
     if (st != PNGPD_OK) return st;
+    static_assert((BWD_E_LDS_FLOATS + K128_LDS_FLOATS) * sizeof(float) >= DW3_LDS_DOUBLES * sizeof(double), "tail LDS");
+    const int n_main = (int)grid.x;
+    if (tail) grid.x += 1024 / DW3_CPB;
     hipLaunchKernelGGL((trunk_bwd_e_kernel<LOADZ, NT>), grid, dim3(256), lds, sm,
-                       x, N, trans, P, E, T, S, (const f32x4 *)z2t, (const f32x4 *)g2t, pc, pR, pW2);
+                       x, N, trans, P, E, T, S, (const f32x4 *)z2t, (const f32x4 *)g2t, pc, pR, pW2,
+                       tail ? *tail : DW3Args{}, n_main);
     return pngpd_launch_status();
 }
 
@@ -1701,8 +1718,8 @@ int pngpd_trunk_bwd_gather(const float *x, int B, int N, const float *trans,
                            const float *w1, const float *b1, const float *s1c, const float *t1c,
                            const float *w2p, const float *s2c, const float *t2c,
                            const int *idx, const float *coef, int clouds_per_range, float *Gp, void *stream) {
-    return bwd_gather_impl(x, B, N, trans, w1, b1, s1c, t1c, w2p, nullptr, 0, s2c, t2c, idx, coef, clouds_per_range,
-                           Gp, stream);
+    return pngpd_bwd_gather_impl(x, B, N, trans, w1, b1, s1c, t1c, w2p, nullptr, 0, s2c, t2c, idx, coef, clouds_per_range,
+                           Gp, nullptr, stream);
 }
 
 int pngpd_trunk_bwd_gather_bf(const float *x, int B, int N, const float *trans,
@@ -1710,8 +1727,8 @@ int pngpd_trunk_bwd_gather_bf(const float *x, int B, int N, const float *trans,
                               const void *w2x, int nterms, const float *s2c, const float *t2c,
                               const int *idx, const float *coef, int clouds_per_range, float *Gp, void *stream) {
     if (nterms != 1 && nterms != 3) return PNGPD_ERR_INVALID_ARG;
-    return bwd_gather_impl(x, B, N, trans, w1, b1, s1c, t1c, nullptr, w2x, nterms, s2c, t2c, idx, coef,
-                           clouds_per_range, Gp, stream);
+    return pngpd_bwd_gather_impl(x, B, N, trans, w1, b1, s1c, t1c, nullptr, w2x, nterms, s2c, t2c, idx, coef,
+                           clouds_per_range, Gp, nullptr, stream);
 }
 
 int pngpd_trunk_pool_refine(const float *x, int B, int N, const float *trans,
@@ -1788,18 +1805,9 @@ int pngpd_trunk_bwd_e(const float *x, int B, int N, const float *trans,
                       const float *w2p, const float *is1, const float *nm1, const float *is2, const float *nm2,
                       const float *a1m, const float *a2m, const float *dsc2, const float *w2tp,
                       const float *z2t, const float *g2t, int S, float *pc, float *pR, float *pW2, void *stream) {
-    if (!x || !w1 || !b1 || !s1c || !t1c || !w2p || !is1 || !nm1 || !is2 || !nm2 || !a1m || !a2m || !dsc2 ||
-        !w2tp || !g2t || !pc || !pR || !pW2 || B <= 0 || N <= 0)
-        return PNGPD_ERR_INVALID_ARG;
-    const int T = (N + TP - 1) / TP;
-    if (!splits_ok(S, T)) return PNGPD_ERR_INVALID_ARG;
-    TrainChan P = make_chan(w1, b1, s1c, t1c, w2p, nullptr, nullptr);
-    BwdEParams E; E.is1 = is1; E.nm1 = nm1; E.is2 = is2; E.nm2 = nm2; E.a1m = a1m; E.a2m = a2m; E.dsc2 = dsc2;
-    E.w2tp = w2tp; E.w2tx = nullptr;
-    const size_t lds = (BWD_E_LDS_FLOATS + K128_LDS_FLOATS) * sizeof(float);   // 79 KB: two workgroups per CU still fit
-    const dim3 grid((unsigned)B * S);
-    return z2t ? launch_bwd_e<true, 0>(grid, lds, (hipStream_t)stream, x, N, trans, P, E, T, S, z2t, g2t, pc, pR, pW2)
-               : launch_bwd_e<false, 0>(grid, lds, (hipStream_t)stream, x, N, trans, P, E, T, S, nullptr, g2t, pc, pR, pW2);
+    if (!w2p || !w2tp) return PNGPD_ERR_INVALID_ARG;
+    return pngpd_bwd_e_impl(x, B, N, trans, w1, b1, s1c, t1c, w2p, is1, nm1, is2, nm2, a1m, a2m, dsc2, w2tp, nullptr, 0,
+                            z2t, g2t, S, pc, pR, pW2, nullptr, stream);
 }
 
 int pngpd_trunk_bwd_e_bf(const float *x, int B, int N, const float *trans,
@@ -1807,22 +1815,37 @@ int pngpd_trunk_bwd_e_bf(const float *x, int B, int N, const float *trans,
                          const float *is1, const float *nm1, const float *is2, const float *nm2,
                          const float *a1m, const float *a2m, const float *dsc2, const void *w2tx, int nterms,
                          const void *z2tv, const void *g2tv, int S, float *pc, float *pR, float *pW2, void *stream) {
-    const float *z2t = (const float *)z2tv, *g2t = (const float *)g2tv;
-    if (!x || !w1 || !b1 || !s1c || !t1c || !is1 || !nm1 || !is2 || !nm2 || !a1m || !a2m || !dsc2 || !w2tx || !z2t ||
-        !g2t || !pc || !pR || !pW2 || B <= 0 || N <= 0 || (nterms != 1 && nterms != 3))
-        return PNGPD_ERR_INVALID_ARG;
-    const int T = (N + TP - 1) / TP;
-    if (!splits_ok(S, T)) return PNGPD_ERR_INVALID_ARG;
-    TrainChan P = make_chan(w1, b1, s1c, t1c, nullptr, nullptr, nullptr);
-    BwdEParams E; E.is1 = is1; E.nm1 = nm1; E.is2 = is2; E.nm2 = nm2; E.a1m = a1m; E.a2m = a2m; E.dsc2 = dsc2;
-    E.w2tp = nullptr; E.w2tx = (const u16 *)w2tx;
-    const size_t lds = (BWD_E_LDS_FLOATS + K128_LDS_FLOATS) * sizeof(float);
-    const dim3 grid((unsigned)B * S);
-    return nterms == 1 ? launch_bwd_e<true, 1>(grid, lds, (hipStream_t)stream, x, N, trans, P, E, T, S, z2t, g2t, pc, pR, pW2)
-                       : launch_bwd_e<true, 3>(grid, lds, (hipStream_t)stream, x, N, trans, P, E, T, S, z2t, g2t, pc, pR, pW2);
+    if (!w2tx || !z2tv || (nterms != 1 && nterms != 3)) return PNGPD_ERR_INVALID_ARG;
+    return pngpd_bwd_e_impl(x, B, N, trans, w1, b1, s1c, t1c, nullptr, is1, nm1, is2, nm2, a1m, a2m, dsc2, nullptr, w2tx,
+                            nterms, (const float *)z2tv, (const float *)g2tv, S, pc, pR, pW2, nullptr, stream);
 }
 
 }  // extern "C"
+
+// Pass E behind both C entries (nterms 0: fp32, w2p / w2tp; 1 / 3: bf16 / bf16x3, w2tx, z2t required), optionally with
+// dW3's finalize as tail workgroups (tail != NULL: the fused backward, pngpd_train_step.hip).
+int pngpd_bwd_e_impl(const float *x, int B, int N, const float *trans, const float *w1, const float *b1,
+                     const float *s1c, const float *t1c, const float *w2p, const float *is1, const float *nm1,
+                     const float *is2, const float *nm2, const float *a1m, const float *a2m, const float *dsc2,
+                     const float *w2tp, const void *w2tx, int nterms, const float *z2t, const float *g2t, int S,
+                     float *pc, float *pR, float *pW2, const DW3Args *tail, void *stream) {
+    if (!x || !w1 || !b1 || !s1c || !t1c || !is1 || !nm1 || !is2 || !nm2 || !a1m || !a2m || !dsc2 || !g2t || !pc ||
+        !pR || !pW2 || B <= 0 || N <= 0 || (nterms != 0 && nterms != 1 && nterms != 3))
+        return PNGPD_ERR_INVALID_ARG;
+    if (nterms ? (!w2tx || !z2t) : (!w2p || !w2tp)) return PNGPD_ERR_INVALID_ARG;
+    const int T = (N + TP - 1) / TP;
+    if (!splits_ok(S, T)) return PNGPD_ERR_INVALID_ARG;
+    TrainChan P = make_chan(w1, b1, s1c, t1c, w2p, nullptr, nullptr);
+    BwdEParams E; E.is1 = is1; E.nm1 = nm1; E.is2 = is2; E.nm2 = nm2; E.a1m = a1m; E.a2m = a2m; E.dsc2 = dsc2;
+    E.w2tp = w2tp; E.w2tx = (const u16 *)w2tx;
+    const size_t lds = (BWD_E_LDS_FLOATS + K128_LDS_FLOATS) * sizeof(float);   // 79 KB: two workgroups per CU still fit
+    const dim3 grid((unsigned)B * S);
+    hipStream_t sm = (hipStream_t)stream;
+    if (nterms == 1) return launch_bwd_e<true, 1>(grid, lds, sm, x, N, trans, P, E, T, S, z2t, g2t, pc, pR, pW2, tail);
+    if (nterms == 3) return launch_bwd_e<true, 3>(grid, lds, sm, x, N, trans, P, E, T, S, z2t, g2t, pc, pR, pW2, tail);
+    return z2t ? launch_bwd_e<true, 0>(grid, lds, sm, x, N, trans, P, E, T, S, z2t, g2t, pc, pR, pW2, tail)
+               : launch_bwd_e<false, 0>(grid, lds, sm, x, N, trans, P, E, T, S, nullptr, g2t, pc, pR, pW2, tail);
+}
 
 int pngpd_fc_bwd_impl(const float *g, const float *x, const float *W, int B, int K, int Nout,
                       float *dW, float *dx, float *db, int zero_db, void *stream) {

@@ -6,6 +6,7 @@
 // to replace ~500 launch-bound framework ops per step by ~40 kernels on the same stream.
 #include "pngpd_common.h"
 #include "pngpd_internal.h"
+#include "pngpd_glue_bodies.h"
 
 #define NT 256
 
@@ -304,130 +305,16 @@ __device__ __forceinline__ double s2_at(const double *__restrict__ S2c, int k, i
     return v;
 }
 
-// ---------------------------------------------------------------------------------------
-// dW3[c][j] = G[c][j] - s3 (m1 sh[j] + (m2/sig3) (W3 Sc)[c][j]),  Sc = S2 - sh sh^T / M
-// block = DW3_CPB channels c.  A thread walks column j of S2 block-wise (the storage orientation
-// of a 32x32 block is decided once per block, not per element) and every element it fetches serves all DW3_CPB
-// channels of the block (one channel per block with a per-element s2_at() was 46 us for 17 M fp64 FMAs).
-// ---------------------------------------------------------------------------------------
-#define DW3_CPB 4
-// 512 threads = 4 row blocks a (k = 32 a + i) x 128 columns j: every thread walks ONE 32x32 block of S2 (32 dependent
-// loads instead of 128 — the kernel is a latency chain at two waves per CU otherwise: 31 us -> 10 us), the four partial
-// dot products of a column meet in LDS in fixed order.
-#define DW3_KQ (PNGPD_ASAN ? 1 : 4)   // k-quarters walked concurrently (sanitizer build: 128-thread workgroups)
-// Sum over the 64 lanes of a wave (butterfly: every lane gets the same, order-fixed total).
-__device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
-    return v;
+// dw3_finalize_kernel / a_cvec_finalize_kernel: bodies in pngpd_glue_bodies.h (pass E and the gather pass carry the
+// same bodies as tail workgroups in the fused backward)
+__global__ __launch_bounds__(128 * DW3_KQ) void dw3_finalize_kernel(const DW3Args A) {
+    __shared__ double lds[DW3_LDS_DOUBLES];
+    dw3_finalize_body<DW3_KQ>(A, (int)blockIdx.x, lds);
 }
 
-__global__ __launch_bounds__(128 * DW3_KQ) void dw3_finalize_kernel(
-    const double *__restrict__ G, const double *__restrict__ S2c, const double *__restrict__ sh, double M,
-    const float *__restrict__ w3, const float *__restrict__ g3, const double *__restrict__ stats,
-    const double *__restrict__ m12, double eps, float *__restrict__ dW3) {
-    // The kernel is a latency chain (256 workgroups, a few KB each): one barrier before the walk and one after it, the
-    // 128-long dot products w3 . sh by wave shuffles beside the walk instead of a seven-barrier tree in front of it, and
-    // all 32 (64) loads of a thread's S2 block in flight at once.  14 -> 9 us.
-    __shared__ double wrow[DW3_CPB][128];
-    __shared__ double rsum[DW3_CPB][2];
-    __shared__ double part[4][DW3_CPB][128];
-    const int c0 = blockIdx.x * DW3_CPB, j = threadIdx.x & 127, aq = threadIdx.x >> 7;
-    const double shj = sh[j];
-    for (int u = aq; u < DW3_CPB; u += DW3_KQ) {
-        const double w = (double)w3[(size_t)(c0 + u) * 128 + j];
-        wrow[u][j] = w;
-        const double t = wave_sum_f64(w * shj);
-        if ((threadIdx.x & 63) == 0) rsum[u][j >> 6] = t;
-    }
-    double gq[DW3_CPB];
-    if (aq == 0) {
-#pragma unroll
-        for (int u = 0; u < DW3_CPB; ++u) gq[u] = G[(size_t)(c0 + u) * 128 + j];
-    }
-    __syncthreads();
-    const int bb = j >> 5, jj = j & 31;
-    for (int a = aq; a < 4; a += DW3_KQ) {          // rows k = 32 a + i of column j: block (a, bb) of S2
-        double dot[DW3_CPB];
-#pragma unroll
-        for (int u = 0; u < DW3_CPB; ++u) dot[u] = 0.0;
-        const int d = (bb - a) & 3;
-        const bool tr = d == 3 || (d == 2 && a >= 2);          // stored as the transposed block (bb, a)
-        const int ra = tr ? bb : a, q = tr ? ((a - bb) & 3) : d;
-        const double *p0 = S2c + (size_t)(ra * 3 + q) * 1024;
-        const double *p1 = S2c + (size_t)((q == 2 ? ra + 2 : ra) * 3 + 2) * 1024;   // q == 2: the other half of the points
-        double v[32];
-#pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            // stored element (row, col) at ((row&3) + 4 (row>>3)) * 64 + ((row>>2)&1) * 32 + col
-            const int row = tr ? jj : i, col = tr ? i : jj;
-            const int e = ((row & 3) + 4 * (row >> 3)) * 64 + ((row >> 2) & 1) * 32 + col;
-            v[i] = p0[e];
-            if (q == 2) v[i] += p1[e];
-        }
-#pragma unroll
-        for (int i = 0; i < 32; ++i)
-#pragma unroll
-            for (int u = 0; u < DW3_CPB; ++u) dot[u] = fma(wrow[u][a * 32 + i], v[i], dot[u]);
-#pragma unroll
-        for (int u = 0; u < DW3_CPB; ++u) part[a][u][j] = dot[u];
-    }
-    __syncthreads();
-    if (aq == 0) {
-#pragma unroll
-        for (int u = 0; u < DW3_CPB; ++u) {
-            const int c = c0 + u;
-            const double w3sc = ((part[0][u][j] + part[1][u][j]) + (part[2][u][j] + part[3][u][j])) -
-                                (rsum[u][0] + rsum[u][1]) * shj / M;
-            const double sig = sqrt(stats[1024 + c] + eps);
-            const double s3 = (double)g3[c] / sig;
-            dW3[(size_t)c * 128 + j] = (float)(gq[u] - s3 * (m12[c] * shj + (m12[1024 + c] / sig) * w3sc));
-        }
-    }
-}
-
-// A = W3^T diag(g3 m2/sig3^2) W3 (written MFMA_B-packed, fp32), cvec = A mh - W3^T (s3 m1).
-// block = row i of A; 512 threads = 128 columns j x 4 quarters of the channel range.  The per-channel
-// coefficient (one fp64 divide + sqrt each) is computed ONCE per block into LDS, so the contraction loop is one
-// coalesced weight load + one LDS broadcast + one FMA per channel, 16 loads in flight.
-__global__ __launch_bounds__(512) void a_cvec_finalize_kernel(
-    const float *__restrict__ w3, const float *__restrict__ g3, const double *__restrict__ stats,
-    const double *__restrict__ m12, const double *__restrict__ sh, double M, double eps,
-    float *__restrict__ Ap, float *__restrict__ cvec) {
-    __shared__ double tco[1024];     // w3[c][i] * g3[c] m2[c] / var[c]
-    __shared__ double part[4][128];
-    __shared__ double ured[512];
-    __shared__ double red[128];
-    const int tid = threadIdx.x, i = blockIdx.x, j = tid & 127, q = tid >> 7;
-    double u = 0.0;
-    for (int c = tid; c < 1024; c += 512) {
-        const double var = stats[1024 + c] + eps;
-        const double wi = (double)w3[(size_t)c * 128 + i];
-        tco[c] = wi * ((double)g3[c] * m12[1024 + c] / var);
-        u += wi * ((double)g3[c] / sqrt(var)) * m12[c];
-    }
-    ured[tid] = u;
-    __syncthreads();
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    const float *wj = w3 + (size_t)(q * 256) * 128 + j;
-    const double *tq = tco + q * 256;
-#pragma unroll 4
-    for (int c = 0; c < 256; c += 4) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] += tq[c + e] * (double)wj[(size_t)(c + e) * 128];
-    }
-    part[q][j] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-    for (int s = 256; s > 0; s >>= 1) { __syncthreads(); if (tid < s) ured[tid] += ured[tid + s]; }
-    __syncthreads();
-    if (q == 0) {
-        const double a = part[0][j] + part[1][j] + part[2][j] + part[3][j];
-        const int cb = i >> 5, jj = i & 31, kb = j >> 3, h = (j >> 2) & 1, t = j & 3;   // MFMA_B packing of (i, j)
-        Ap[(((cb * 16 + kb) * 64) + h * 32 + jj) * 4 + t] = (float)a;
-        red[j] = a * (sh[j] / M);
-    }
-    __syncthreads();
-    for (int s = 64; s > 0; s >>= 1) { if (q == 0 && j < s) red[j] += red[j + s]; __syncthreads(); }
-    if (tid == 0) cvec[i] = (float)(red[0] - ured[0]);
+__global__ __launch_bounds__(512) void a_cvec_finalize_kernel(const ACvecArgs A) {
+    __shared__ double lds[ACVEC_LDS_DOUBLES];
+    a_cvec_finalize_body<512>(A, (int)blockIdx.x, lds);
 }
 
 // a12 (128,2) f64 = sum g2, sum g2*zhat2  ->  dg2 = a2, dbe2 = a1 and the pass-E vectors
@@ -841,8 +728,8 @@ int pngpd_reduce_partials4(const float *in0, int outer0, int R0, int n0, double 
 int pngpd_a_cvec_finalize(const double *sh, int B, int N, const float *w3, const float *g3, const double *stats,
                           const double *m12, float eps, float *Ap, float *cvec, void *stream) {
     if (!sh || !w3 || !g3 || !stats || !m12 || !Ap || !cvec || B <= 0 || N <= 0) return PNGPD_ERR_INVALID_ARG;
-    LAUNCH(a_cvec_finalize_kernel, dim3(128), dim3(512), w3, g3, stats, m12, sh, (double)B * N, (double)eps, Ap,
-           cvec);
+    const ACvecArgs A{w3, g3, stats, m12, sh, (double)B * N, (double)eps, Ap, cvec};
+    LAUNCH(a_cvec_finalize_kernel, dim3(128), dim3(512), A);
 }
 
 int pngpd_dw3_finalize(const double *G, const double *S2c, const double *sh, int B, int N, const float *w3,
@@ -850,8 +737,8 @@ int pngpd_dw3_finalize(const double *G, const double *S2c, const double *sh, int
                        void *stream) {
     if (!G || !S2c || !sh || !w3 || !g3 || !stats || !m12 || !dW3 || B <= 0 || N <= 0)
         return PNGPD_ERR_INVALID_ARG;
-    LAUNCH(dw3_finalize_kernel, dim3(1024 / DW3_CPB), dim3(128 * DW3_KQ), G, S2c, sh, (double)B * N, w3, g3, stats, m12,
-           (double)eps, dW3);
+    const DW3Args A{G, S2c, sh, (double)B * N, w3, g3, stats, m12, (double)eps, dW3};
+    LAUNCH(dw3_finalize_kernel, dim3(1024 / DW3_CPB), dim3(128 * DW3_KQ), A);
 }
 
 int pngpd_bwd_e_prep(const double *a12, int B, int N, const float *g2, const double *stats2, float eps,

@@ -6,6 +6,7 @@
 // tests compare the two bit for bit), so that an eager training step of the reference's own recipe (main_1v.py:72-76,
 // batch 64 x 750 points) costs eight foreign-function calls instead of ~140.
 #include "pngpd_internal.h"
+#include "pngpd_glue_bodies.h"
 
 namespace {
 
@@ -240,19 +241,20 @@ int pngpd_trunk_train_bwd(const pngpd_trunk_train_t *a, void *stream) {
     // ---- BN3 affine grads, sparse-term weights, dense-correction scalars, pass-D operands
     CHK(pngpd_bn3_bwd_prep(a->dp, a->pooled, a->zhat, B, N, a->g3, s.stats3, a->eps, a->relu_last, w.coef, a->dg3,
                            a->dbe3, w.m12, stream));
-    CHK(pngpd_a_cvec_finalize(s.sh, B, N, a->w3, a->g3, s.stats3, w.m12, a->eps, w.Ap, w.cvec, stream));
-    // ---- arg-extremum gather (sparse term of dW3) and pass D
+    // ---- arg-extremum gather (sparse term of dW3) with A / cvec's finalize as tail workgroups of the same launch (the
+    //      two are independent; pass D, one launch later, is their first reader), then pass D
+    const ACvecArgs AT{a->w3, a->g3, s.stats3, w.m12, s.sh, (double)B * N, (double)a->eps, w.Ap, w.cvec};
     if (nt) {
+        CHK(pngpd_bwd_gather_impl(x, B, N, T, a->w1, a->b1, s1c, t1c, nullptr, s.w2x, nt, s2c, t2c, a->idx, w.coef, d.cpr,
+                                  w.Gp, &AT, stream));
         PackArgs P{};
         P.job[0] = PackJob{w.Ap, nullptr, w.Ax, 128, 128, 0, 1, 1};
         CHK(pngpd_train_pack_launch(P, 1, stream));
-        CHK(pngpd_trunk_bwd_gather_bf(x, B, N, T, a->w1, a->b1, s1c, t1c, s.w2x, nt, s2c, t2c, a->idx, w.coef, d.cpr,
-                                      w.Gp, stream));
         CHK(pngpd_trunk_bwd_d_bf(x, B, N, s2c, t2c, is2, nm2, w.Ax, nt, w.cvec, a->w3, a->idx, w.coef, s.z2t, S, w.g2t,
                                  w.pa, w.ps2, stream));
     } else {
-        CHK(pngpd_trunk_bwd_gather(x, B, N, T, a->w1, a->b1, s1c, t1c, s.w2p, s2c, t2c, a->idx, w.coef, d.cpr, w.Gp,
-                                   stream));
+        CHK(pngpd_bwd_gather_impl(x, B, N, T, a->w1, a->b1, s1c, t1c, s.w2p, nullptr, 0, s2c, t2c, a->idx, w.coef, d.cpr,
+                                  w.Gp, &AT, stream));
         CHK(pngpd_trunk_bwd_d(x, B, N, T, a->w1, a->b1, s1c, t1c, s.w2p, s2c, t2c, is2, nm2, w.Ap, w.cvec, a->w3,
                               a->idx, w.coef, s.z2t, S, w.g2t, w.pa, w.ps2, stream));
     }
@@ -265,14 +267,15 @@ int pngpd_trunk_train_bwd(const pngpd_trunk_train_t *a, void *stream) {
         A.seg[0] = g; A.seg[1] = e; A.seg[2] = q;
         CHK(pngpd_reduce_fin_launch(A, 3, stream));
     }
-    CHK(pngpd_dw3_finalize(w.G, w.S2c, s.sh, B, N, a->w3, a->g3, s.stats3, w.m12, a->eps, a->dW3, stream));
-    // ---- pass E (also contracts dW2 = sum_points dz2 h1^T on the MFMA)
+    // ---- pass E (also contracts dW2 = sum_points dz2 h1^T on the MFMA), with dW3's finalize as tail workgroups: it
+    //      reads only what the reduction above wrote, and nothing in this entry reads dW3
+    const DW3Args WT{w.G, w.S2c, s.sh, (double)B * N, a->w3, a->g3, s.stats3, w.m12, (double)a->eps, a->dW3};
     if (nt)
-        CHK(pngpd_trunk_bwd_e_bf(x, B, N, T, a->w1, a->b1, s1c, t1c, is1, nm1, is2, nm2, w.evec, w.evec + 128,
-                                 w.evec + 256, s.w2tx, nt, s.z2t, w.g2t, S, w.pc, w.pR, w.pW2, stream));
+        CHK(pngpd_bwd_e_impl(x, B, N, T, a->w1, a->b1, s1c, t1c, nullptr, is1, nm1, is2, nm2, w.evec, w.evec + 128,
+                             w.evec + 256, nullptr, s.w2tx, nt, s.z2t, w.g2t, S, w.pc, w.pR, w.pW2, &WT, stream));
     else
-        CHK(pngpd_trunk_bwd_e(x, B, N, T, a->w1, a->b1, s1c, t1c, s.w2p, is1, nm1, is2, nm2, w.evec, w.evec + 128,
-                              w.evec + 256, s.w2tp, s.z2t, w.g2t, S, w.pc, w.pR, w.pW2, stream));
+        CHK(pngpd_bwd_e_impl(x, B, N, T, a->w1, a->b1, s1c, t1c, s.w2p, is1, nm1, is2, nm2, w.evec, w.evec + 128,
+                             w.evec + 256, s.w2tp, nullptr, 0, s.z2t, w.g2t, S, w.pc, w.pR, w.pW2, &WT, stream));
     {
         RFArgs A; A.M = (double)B * N; A.eps = (double)a->eps; A.momentum = 0.0;
         RFSeg g{}; g.in = w.pW2; g.out = a->dW2; g.outer = 1; g.R = d.blk; g.n = 128 * 64; g.kind = RF_F32;
