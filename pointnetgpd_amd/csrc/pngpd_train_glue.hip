@@ -77,9 +77,23 @@ __global__ __launch_bounds__(NT) void bn1_finalize_kernel(
                 for (int j = 0; j < 3; ++j) a[3 + i * 3 + j] += S[i][j];
         }
     }
+    // the twelve sums together: wave trees by shuffles, then the NT/64 wave partials through LDS in block_sum's order —
+    // two barriers instead of twenty-four
+#pragma unroll
     for (int i = 0; i < 12; ++i) {
-        const double r = block_sum(a[i], red);
-        if (tid == 0) tot[i] = r;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) a[i] += __shfl_xor(a[i], m);
+    }
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) red[(tid >> 6) * 12 + i] = a[i];
+    }
+    __syncthreads();
+    if (tid < 12) {
+        double r = 0.0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) r += red[w * 12 + tid];
+        tot[tid] = r;
     }
     __syncthreads();
     double mx[3], Cx[3][3];
