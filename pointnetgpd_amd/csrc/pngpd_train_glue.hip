@@ -350,12 +350,11 @@ __global__ __launch_bounds__(128) void bwd_e_prep_kernel(
 
 // dW1[c][j] = s1 (Rp[c][j] - c1 mx[j] - (c2/sig1) (W1 Cx)[c][j]),  Rp = sum_b Rb[b] T_b  (or sum_b Rb[b])
 // block = channel c, NT threads over b.   Rb f64 (B,64,3).
-__global__ __launch_bounds__(NT) void dw1_finalize_kernel(
-    const double *__restrict__ Rb, const float *__restrict__ trans, int B, const double *__restrict__ c12 /*(64,2)*/,
+__device__ __forceinline__ void dw1_finalize_body(
+    int c, const double *__restrict__ Rb, const float *__restrict__ trans, int B, const double *__restrict__ c12 /*(64,2)*/,
     const double *__restrict__ stats1, const float *__restrict__ w1, const float *__restrict__ g1, double eps,
-    float *__restrict__ dW1, float *__restrict__ dg1, float *__restrict__ dbe1) {
-    __shared__ double red[NT];
-    const int c = blockIdx.x, tid = threadIdx.x;
+    float *__restrict__ dW1, float *__restrict__ dg1, float *__restrict__ dbe1, double *red /* [NT] */) {
+    const int tid = threadIdx.x;
     double r[3] = {0.0, 0.0, 0.0};
     for (int b = tid; b < B; b += NT) {
         const double *rb = Rb + ((size_t)b * 64 + c) * 3;
@@ -385,44 +384,63 @@ __global__ __launch_bounds__(NT) void dw1_finalize_kernel(
 }
 
 // dT_b = Y_b W1,  Y_b[i][c] = s1 (Rb[b][c][i] - m_b[i] c1/M - term3 c2/M),
-//   term3 = ((S_b T_b)[i][:] . W1[c] + m_b[i] (b1 - mu1)) / sig1.     block = cloud b, 64 threads = c
-__global__ __launch_bounds__(64) void dtrans_finalize_kernel(
-    const double *__restrict__ Rb, const float *__restrict__ trans, const double *__restrict__ mom, double M,
-    const double *__restrict__ c12, const double *__restrict__ stats1, const float *__restrict__ w1,
-    const float *__restrict__ b1, const float *__restrict__ g1, double eps, float *__restrict__ dT) {
-    __shared__ double red[9][64];
-    const int b = blockIdx.x, c = threadIdx.x;
-    const double *m = mom + (size_t)b * 9;
-    const double mb[3] = {m[0], m[1], m[2]};
-    const double S[3][3] = {{m[3], m[4], m[5]}, {m[4], m[6], m[7]}, {m[5], m[7], m[8]}};
-    double T[3][3];
+//   term3 = ((S_b T_b)[i][:] . W1[c] + m_b[i] (b1 - mu1)) / sig1.     64 threads = c per cloud, NT/64 clouds per workgroup
+__device__ __forceinline__ void dtrans_finalize_body(
+    int blk, int B, const double *__restrict__ Rb, const float *__restrict__ trans, const double *__restrict__ mom,
+    double M, const double *__restrict__ c12, const double *__restrict__ stats1, const float *__restrict__ w1,
+    const float *__restrict__ b1, const float *__restrict__ g1, double eps, float *__restrict__ dT,
+    double *lds /* [NT/64][9][64] */) {
+    const int cl = threadIdx.x >> 6, c = threadIdx.x & 63;
+    const int b = blk * (NT / 64) + cl;
+    const bool live = b < B;
+    double (*red)[64] = (double (*)[64])(lds + (size_t)cl * 9 * 64);
+    if (live) {
+        const double *m = mom + (size_t)b * 9;
+        const double mb[3] = {m[0], m[1], m[2]};
+        const double S[3][3] = {{m[3], m[4], m[5]}, {m[4], m[6], m[7]}, {m[5], m[7], m[8]}};
+        double T[3][3];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) T[i / 3][i % 3] = (double)trans[(size_t)b * 9 + i];
-    const double w[3] = {(double)w1[c * 3], (double)w1[c * 3 + 1], (double)w1[c * 3 + 2]};
-    const double sig = sqrt(stats1[76 + c] + eps);
-    const double s1 = (double)g1[c] / sig;
-    const double c1 = c12[c * 2] / M, c2 = c12[c * 2 + 1] / M;
-    const double bmu = (double)b1[c] - stats1[12 + c];
-    const double *rb = Rb + ((size_t)b * 64 + c) * 3;
-    double Y[3];
+        for (int i = 0; i < 9; ++i) T[i / 3][i % 3] = (double)trans[(size_t)b * 9 + i];
+        const double w[3] = {(double)w1[c * 3], (double)w1[c * 3 + 1], (double)w1[c * 3 + 2]};
+        const double sig = sqrt(stats1[76 + c] + eps);
+        const double s1 = (double)g1[c] / sig;
+        const double c1 = c12[c * 2] / M, c2 = c12[c * 2 + 1] / M;
+        const double bmu = (double)b1[c] - stats1[12 + c];
+        const double *rb = Rb + ((size_t)b * 64 + c) * 3;
+        double Y[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        double st = 0.0;   // (S T)[i][:] . w
+        for (int i = 0; i < 3; ++i) {
+            double st = 0.0;   // (S T)[i][:] . w
 #pragma unroll
-        for (int j = 0; j < 3; ++j) st += (S[i][0] * T[0][j] + S[i][1] * T[1][j] + S[i][2] * T[2][j]) * w[j];
-        const double term3 = (st + mb[i] * bmu) / sig;
-        Y[i] = s1 * (rb[i] - mb[i] * c1 - term3 * c2);
+            for (int j = 0; j < 3; ++j) st += (S[i][0] * T[0][j] + S[i][1] * T[1][j] + S[i][2] * T[2][j]) * w[j];
+            const double term3 = (st + mb[i] * bmu) / sig;
+            Y[i] = s1 * (rb[i] - mb[i] * c1 - term3 * c2);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) red[i * 3 + j][c] = Y[i] * w[j];
     }
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) red[i * 3 + j][c] = Y[i] * w[j];
     __syncthreads();
-    if (c < 9) {
+    if (live && c < 9) {
         double s = 0.0;
         for (int k = 0; k < 64; ++k) s += red[c][k];
         dT[(size_t)b * 9 + c] = (float)s;
     }
+}
+
+// Both finalizes of pass E's sums in ONE launch (they are independent): blocks [0, 64) = dW1 / dg1 / dbe1 per channel,
+// the rest (dT != NULL) = dT for NT/64 clouds each.
+__global__ __launch_bounds__(NT) void dw1_dtrans_finalize_kernel(
+    const double *__restrict__ Rb, const float *__restrict__ trans, const double *__restrict__ mom, int B, double M,
+    const double *__restrict__ c12, const double *__restrict__ stats1, const float *__restrict__ w1,
+    const float *__restrict__ b1, const float *__restrict__ g1, double eps, float *__restrict__ dW1,
+    float *__restrict__ dg1, float *__restrict__ dbe1, float *__restrict__ dT) {
+    __shared__ double lds[(NT / 64) * 9 * 64];
+    if (blockIdx.x < 64)
+        dw1_finalize_body((int)blockIdx.x, Rb, trans, B, c12, stats1, w1, g1, eps, dW1, dg1, dbe1, lds);
+    else
+        dtrans_finalize_body((int)blockIdx.x - 64, B, Rb, trans, mom, M, c12, stats1, w1, b1, g1, eps, dT, lds);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -767,12 +785,9 @@ int pngpd_dw1_finalize(const double *Rb, const float *trans, const double *mom, 
     if (!Rb || !mom || !c12 || !stats1 || !w1 || !b1 || !g1 || !dW1 || !dg1 || !dbe1 || B <= 0 || N <= 0)
         return PNGPD_ERR_INVALID_ARG;
     if (dT && !trans) return PNGPD_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(dw1_finalize_kernel, dim3(64), dim3(NT), 0, (hipStream_t)stream, Rb, trans, B, c12, stats1,
-                       w1, g1, (double)eps, dW1, dg1, dbe1);
-    int st = pngpd_launch_status();
-    if (st != PNGPD_OK || !dT) return st;
-    LAUNCH(dtrans_finalize_kernel, dim3(B), dim3(64), Rb, trans, mom, (double)B * N, c12, stats1, w1, b1, g1,
-           (double)eps, dT);
+    const int nblk = 64 + (dT ? (B + NT / 64 - 1) / (NT / 64) : 0);
+    LAUNCH(dw1_dtrans_finalize_kernel, dim3(nblk), dim3(NT), Rb, trans, mom, B, (double)B * N, c12, stats1, w1, b1, g1,
+           (double)eps, dW1, dg1, dbe1, dT);
 }
 
 int pngpd_adam_flat(float *p, const float *g, float *m, float *v, long long n, float lr, const float *lr_dev,
