@@ -141,7 +141,7 @@ static int run() {
         const void *cl = f64 ? (const void *)dpc64 : (const void *)dpc32;
         PN_OK(pngpd_crop_count_compact(cl, f64, P, dfr, G, MAXK, dcnt, didx, st));
         for (int mode = 0; mode < 2; ++mode)
-            PN_OK(pngpd_crop_resample(cl, f64, P, dfr, nullptr, nullptr, 0, G, dcnt, didx, MAXK, N, mode, 20, 77ull + mode,
+            PN_OK(pngpd_crop_resample(cl, f64, P, dfr, nullptr, nullptr, 0, G, dcnt, didx, MAXK, N, mode, 20, 77ull + mode, 0ll, nullptr,
                                       nullptr, dout, dvalid, st));
         if (report(f64 ? "crop_f64" : "crop_f32")) return 2;
     }
@@ -156,7 +156,7 @@ static int run() {
         }
         int *dsel;
         if (upload(sel, &dsel)) return 2;
-        PN_OK(pngpd_crop_resample(dpc32, 0, P, dfr, nullptr, nullptr, 0, G, dcnt, didx, MAXK, N, 1, 20, 0ull, dsel, dout,
+        PN_OK(pngpd_crop_resample(dpc32, 0, P, dfr, nullptr, nullptr, 0, G, dcnt, didx, MAXK, N, 1, 20, 0ull, 0ll, nullptr, dsel, dout,
                                   dvalid, st));
         if (report("crop_sel")) return 2;
     }
@@ -169,7 +169,7 @@ static int run() {
         int *drng;
         if (upload(rng, &drng)) return 2;
         PN_OK(pngpd_crop_count_compact_ranges(dpc64, 1, P, dfr, drng, G, MAXK, dcnt, didx, st));
-        PN_OK(pngpd_crop_resample(dpc64, 1, P, dfr, drng, nullptr, 0, G, dcnt, didx, MAXK, N, 0, 50, 5ull, nullptr, dout,
+        PN_OK(pngpd_crop_resample(dpc64, 1, P, dfr, drng, nullptr, 0, G, dcnt, didx, MAXK, N, 0, 50, 5ull, 0ll, nullptr, nullptr, dout,
                                   dvalid, st));
         if (report("crop_ranges")) return 2;
     }
@@ -181,7 +181,7 @@ static int run() {
         int *dgat;
         if (upload(gat, &dgat)) return 2;
         PN_OK(pngpd_crop_count_compact_gather(dpc64, 1, P, dfr, dgat, Pg, G, MAXK, dcnt, didx, st));
-        PN_OK(pngpd_crop_resample(dpc64, 1, P, dfr, nullptr, dgat, Pg, G, dcnt, didx, MAXK, N, 0, 50, 9ull, nullptr, dout,
+        PN_OK(pngpd_crop_resample(dpc64, 1, P, dfr, nullptr, dgat, Pg, G, dcnt, didx, MAXK, N, 0, 50, 9ull, 0ll, nullptr, nullptr, dout,
                                   dvalid, st));
         if (report("crop_gather")) return 2;
     }

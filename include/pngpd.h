@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PNGPD_ABI_VERSION 4
+#define PNGPD_ABI_VERSION 5
 
 enum {
     PNGPD_OK = 0,
@@ -437,11 +437,40 @@ int pngpd_crop_count_compact_gather(const void *arena, int cloud_is_f64, int P, 
  * (G,2) or gather (G,Pg) when the count pass used them (else NULL).  sel (G,N) int32 ranks in [0, min(count,
  * max_keep)) injects the draw (tests; list-based, no re-scan); otherwise a device RNG keyed by seed; a
  * without-replacement draw is a uniform random N-subset written in ascending point-index order — the scorer is
- * invariant to the column order.  Invalid grasps are zero-filled.  Dynamic LDS: max(max_keep, N) * 4 bytes.   */
+ * invariant to the column order.  Invalid grasps are zero-filled.  Dynamic LDS: max(max_keep, N) * 4 bytes.
+ * The draw of grasp g is keyed by (seed, g_base + g) and nothing else: g_base = the GLOBAL index of this call's
+ * first grasp, so a candidate draws the same points whichever shard (GPU) or scoring batch it is handed to —
+ * kinect2grasp.py:454-497 scores every candidate independently of the others.  rows (G) int32 or NULL: destination
+ * row of grasp g in `out` (pngpd_batch_keep_rows; < 0 = dropped, nothing written); valid stays indexed by g.   */
 int pngpd_crop_resample(const void *cloud, int cloud_is_f64, int P, const double *frames, const int *ranges,
                         const int *gather, int Pg, int G, const int *counts, const int *idx, int max_keep, int N,
-                        int mode, int min_points, unsigned long long seed, const int *sel, float *out,
-                        unsigned char *valid, void *stream);
+                        int mode, int min_points, unsigned long long seed, long long g_base, const int *rows,
+                        const int *sel, float *out, unsigned char *valid, void *stream);
+/* my_collate (main_1v.py:48-50) without a host round trip: sample g of a training batch is kept iff counts[g] >=
+ * min_points (dataset.py:71-72) and labels[g] >= 0 (-1 = the reference's label None, dataset.py:446-453).
+ * rows (G) int32 = its row in the compacted batch or -1; labels_out[0..n) = the kept labels in order (int64, what
+ * F.nll_loss takes, main_1v.py:74); *n_keep (device int32) = n.  One workgroup, any G.                          */
+int pngpd_batch_keep_rows(const int *counts, const long long *labels, int G, int min_points, int *rows,
+                          long long *labels_out, int *n_keep, void *stream);
+/* The per-sample cloud of the full-view datasets, dataset.py:252-254: `pc[np.random.choice(len(pc), size=Pg)]` over
+ * the stack of the k_views view files drawn for sample g.  spans (G,k_views,2) int32 = [start, len] of each drawn
+ * view in the arena; gather (G,Pg) int32 = Pg uniform rows of the stacked length, arena-absolute, keyed by
+ * (seed, g_base + g, draw) — independent of how the epoch is cut into batches.  k_views <= 64.                */
+int pngpd_stack_gather_lists(const int *spans, int k_views, int Pg, int G, unsigned long long seed, long long g_base,
+                             int *gather, void *stream);
+/* One training batch of the HBM-resident data layer in ONE call (what 32 DataLoader workers produce per step in
+ * main_1v.py:120-128 through Dataset.__getitem__, dataset.py:420-458 / :244-282, and my_collate, main_1v.py:48-50):
+ * [full-view only: pngpd_stack_gather_lists] -> crop count/compact -> pngpd_batch_keep_rows -> pngpd_crop_resample
+ * (mode 0) writing straight into the compacted rows.  frames (n_items,18) fp64 and labels (n_items) int64 are
+ * per-DATASET tables resident in HBM; item (G) int32 = this batch's rows of them (an epoch's permutation slice).
+ * k_views == 0: one-view datasets, spans (G,2) = the arena range of the view drawn for each sample;
+ * k_views  > 0: full-view datasets, spans (G,k_views,2), gather_ws (G,Pg) int32 scratch.
+ * Scratch: counts (G), idx (G,max_keep), rows (G), valid (G).  Outputs: out (>= kept,3,N) fp32, labels_out (G)
+ * int64 (first kept entries), *n_keep (device int32).  Draws keyed by (seed, g_base + g).                      */
+int pngpd_train_batch(const void *arena, int arena_is_f64, int P, const double *frames, const long long *labels,
+                      const int *item, const int *spans, int k_views, int Pg, int *gather_ws, int G, int max_keep,
+                      int N, int min_points, unsigned long long seed, long long g_base, int *counts, int *idx,
+                      int *rows, unsigned char *valid, float *out, long long *labels_out, int *n_keep, void *stream);
 
 /* =======================================================================================
  * GPG grasp-candidate sampler, device half (upstream of the crop at inference) —

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PNGPD_LIB") or os.path.join(_HERE, "libpngpd.so")   # PNGPD_LIB: A/B builds only
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 _load_error = None
@@ -141,7 +141,14 @@ SIGNATURES = {
                                                        ctypes.c_int, ctypes.c_int, c_void, c_void, c_void]),
     "pngpd_crop_resample": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, c_void, c_void, ctypes.c_int,
                                            ctypes.c_int, c_void, c_void, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                           ctypes.c_int, ctypes.c_ulonglong, c_void, c_void, c_void, c_void]),
+                                           ctypes.c_int, ctypes.c_ulonglong, ctypes.c_longlong, c_void, c_void, c_void,
+                                           c_void, c_void]),
+    "pngpd_batch_keep_rows": (ctypes.c_int, [c_void, c_void, ctypes.c_int, ctypes.c_int, c_void, c_void, c_void, c_void]),
+    "pngpd_stack_gather_lists": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_ulonglong,
+                                                ctypes.c_longlong, c_void, c_void]),
+    "pngpd_train_batch": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, c_void, c_void, c_void, ctypes.c_int,
+                                         ctypes.c_int, c_void, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_ulonglong, ctypes.c_longlong] + [c_void] * 8),
     # ---- GPG sampler (device half)
     "pngpd_gpg_normal_moments": (ctypes.c_int, [c_void, ctypes.c_int, c_void, ctypes.c_int, c_void, ctypes.c_int,
                                                 ctypes.c_double, ctypes.c_int, c_void, c_void, c_void]),

@@ -148,8 +148,13 @@ def crop_count_compact_gather(arena, frames, gather, max_keep=4096):
 
 
 def crop_resample(cloud, frames, counts, idx, num_points, mode=MODE_INFER, min_points=MIN_POINTS_TO_NET,
-                  seed=0, sel=None, ranges=None, gather=None):
+                  seed=0, sel=None, ranges=None, gather=None, g_base=0, rows=None, out=None):
     """-> out (G,3,num_points) fp32 in the hand frame, valid (G) bool.
+
+    The draw of grasp g depends on ``(seed, g_base + g)`` only: pass the GLOBAL index of ``frames[0]`` as ``g_base``
+    and a candidate draws the same points in every sharding / batching of the candidate list.
+    ``rows`` (G) int32 (``batch_keep_rows``): grasp g is written to ``out[rows[g]]``, nothing when ``rows[g] < 0``;
+    ``out`` may then be a caller-owned (>= kept, 3, N) buffer.
 
     ``ranges`` / ``gather``: the same per-grasp cloud description the count pass was given
     (``crop_count_compact_ranges`` / ``_gather``).  They matter only for grasps holding MORE than ``max_keep`` in-box
@@ -158,8 +163,16 @@ def crop_resample(cloud, frames, counts, idx, num_points, mode=MODE_INFER, min_p
     lib = _lib.load()
     cloud, frames = cloud.contiguous(), frames.contiguous()
     G, max_keep = idx.shape
-    out = torch.empty(G, 3, num_points, device=cloud.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(G, 3, num_points, device=cloud.device, dtype=torch.float32)
+    elif (not out.is_cuda or out.dtype != torch.float32 or not out.is_contiguous() or out.dim() != 3
+          or tuple(out.shape[1:]) != (3, num_points) or out.shape[0] < (G if rows is None else 1)):
+        raise RuntimeError("out: expected a contiguous CUDA (rows,3,N) float32 tensor")
     valid = torch.empty(G, device=cloud.device, dtype=torch.uint8)
+    if rows is not None:
+        if not rows.is_cuda or rows.dtype != torch.int32 or tuple(rows.shape) != (G,):
+            raise RuntimeError("rows: expected a CUDA (G,) int32 tensor")
+        rows = rows.contiguous()
     if sel is not None:
         if not sel.is_cuda or sel.dtype != torch.int32 or tuple(sel.shape) != (G, num_points):
             raise RuntimeError("sel: expected a CUDA (G,N) int32 tensor")
@@ -178,9 +191,29 @@ def crop_resample(cloud, frames, counts, idx, num_points, mode=MODE_INFER, min_p
         _lib.check(lib.pngpd_crop_resample(_p(cloud), int(cloud.dtype == torch.float64), cloud.shape[0], _p(frames),
                                            _p(ranges), _p(gather), int(Pg), G, _p(counts), _p(idx), int(max_keep),
                                            int(num_points), int(mode), int(min_points),
-                                           ctypes.c_ulonglong(int(seed) & (2 ** 64 - 1)), _p(sel), _p(out),
+                                           ctypes.c_ulonglong(int(seed) & (2 ** 64 - 1)),
+                                           ctypes.c_longlong(int(g_base)), _p(rows), _p(sel), _p(out),
                                            _p(valid), _stream(cloud)), "crop_resample")
     return out, valid.bool()
+
+
+def batch_keep_rows(counts, labels, min_points):
+    """counts (G) int32 CUDA, labels (G) int64 CUDA (-1 = the reference's ``None``) -> rows (G) int32 (row in the
+    compacted batch, -1 = dropped), labels_out (G) int64 (first n entries valid), n_keep () int32 CUDA — ``my_collate``
+    (main_1v.py:48-50) with the kept count left on the device."""
+    lib = _lib.load()
+    G = counts.shape[0]
+    if not counts.is_cuda or counts.dtype != torch.int32 or not labels.is_cuda or labels.dtype != torch.int64 \
+            or tuple(labels.shape) != (G,):
+        raise RuntimeError("batch_keep_rows: counts (G) int32 and labels (G) int64 CUDA tensors expected")
+    counts, labels = counts.contiguous(), labels.contiguous()
+    rows = torch.empty(G, device=counts.device, dtype=torch.int32)
+    labels_out = torch.empty(G, device=counts.device, dtype=torch.int64)
+    n_keep = torch.empty((), device=counts.device, dtype=torch.int32)
+    with _lib.device_guard(counts.device):
+        _lib.check(lib.pngpd_batch_keep_rows(_p(counts), _p(labels), G, int(min_points), _p(rows), _p(labels_out),
+                                             _p(n_keep), _stream(counts)), "batch_keep_rows")
+    return rows, labels_out, n_keep
 
 
 def crop_grasps(cloud, frames, num_points, mode=MODE_INFER, min_points=None, seed=0, max_keep=4096, sel=None):

@@ -59,11 +59,12 @@ __device__ __forceinline__ void to_frame(const Frame &F, double x, double y, dou
 template <bool F64>
 __global__ __launch_bounds__(256) void crop_count_compact_kernel(
     const void *__restrict__ cloud, int P, const double *__restrict__ frames, const int *__restrict__ ranges,
-    const int *__restrict__ gather, int Pg, int max_keep, int *__restrict__ counts, int *__restrict__ idx) {
+    const int *__restrict__ gather, int Pg, int max_keep, int *__restrict__ counts, int *__restrict__ idx,
+    const int *__restrict__ item) {
     __shared__ int wcnt[4];
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     Frame F;
-    load_frame(frames + (size_t)g * 18, F);
+    load_frame(frames + (size_t)(item ? item[g] : g) * 18, F);   // item: frames is a per-dataset table, g's row = item[g]
     int running = 0;
     int *out = idx + (size_t)g * max_keep;
     const int p_begin = (!gather && ranges) ? ranges[2 * g] : 0;
@@ -136,7 +137,8 @@ __global__ __launch_bounds__(256) void crop_resample_kernel(
     const void *__restrict__ cloud, int P, const double *__restrict__ frames, const int *__restrict__ ranges,
     const int *__restrict__ gather, int Pg, const int *__restrict__ counts,
     const int *__restrict__ idx, int max_keep, int N, int mode, int min_points, unsigned long long seed,
-    const int *__restrict__ sel, float *__restrict__ out, unsigned char *__restrict__ valid) {
+    long long g_base, const int *__restrict__ rows, const int *__restrict__ sel, float *__restrict__ out,
+    unsigned char *__restrict__ valid, const int *__restrict__ item) {
     extern __shared__ unsigned keys[];   // [max(max_keep, N)]: keys of the without-replacement draw / rebuilt list
     __shared__ int shi[4];
     __shared__ int wsel[4], wtie[4];
@@ -145,15 +147,20 @@ __global__ __launch_bounds__(256) void crop_resample_kernel(
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cnt = counts[g];
     int m = cnt < max_keep ? cnt : max_keep;
-    float *o = out + (size_t)g * 3 * N;
+    // the draw of a grasp is keyed by its GLOBAL index: a candidate scores the same whichever shard / scoring batch
+    // it lands in (kinect2grasp.py:454-497 scores every candidate independently of the others)
+    const unsigned long long gkey = (unsigned long long)(g_base + (long long)g) << 32;
+    const int row = rows ? rows[g] : g;       // rows: destination row of the compacted batch, < 0 = dropped
     const bool ok = cnt >= min_points && m > 0;
     if (tid == 0) valid[g] = ok ? 1 : 0;
+    if (row < 0) return;
+    float *o = out + (size_t)row * 3 * N;
     if (!ok) {
         for (int i = tid; i < 3 * N; i += 256) o[i] = 0.f;
         return;
     }
     Frame F;
-    load_frame(frames + (size_t)g * 18, F);
+    load_frame(frames + (size_t)(item ? item[g] : g) * 18, F);
     const int *gi = idx + (size_t)g * max_keep;
     if (cnt > max_keep && !sel) {
         // ---- overflow: scan the grasp's own cloud (same order and test as crop_count_compact_kernel)
@@ -161,7 +168,7 @@ __global__ __launch_bounds__(256) void crop_resample_kernel(
         const int n = gather ? Pg : (ranges ? ranges[2 * g + 1] : P);
         const int *gl = gather ? gather + (size_t)g * Pg : nullptr;
         auto key_of = [&](int rank) {
-            return (unsigned)(mix64(seed ^ mix64(((unsigned long long)g << 32) | (unsigned)rank)) >> 32);
+            return (unsigned)(mix64(seed ^ mix64(gkey | (unsigned)rank)) >> 32);
         };
         // scan(f): f(in, rank, p) for every candidate point, rank = number of in-box points before it
         auto scan = [&](auto f) {
@@ -193,7 +200,7 @@ __global__ __launch_bounds__(256) void crop_resample_kernel(
             scan([&](bool in, int rank, int p) { if (in) list[rank] = p; });
             __syncthreads();
             for (int nn = tid; nn < N; nn += 256) {
-                const int r = (int)(mix64(seed ^ mix64(((unsigned long long)g << 32) | (unsigned)nn)) % (unsigned long long)cnt);
+                const int r = (int)(mix64(seed ^ mix64(gkey | (unsigned)nn)) % (unsigned long long)cnt);
                 double x, y, z, a, b, c;
                 load_point<F64>(cloud, list[r], x, y, z);
                 to_frame(F, x, y, z, a, b, c);
@@ -260,7 +267,7 @@ __global__ __launch_bounds__(256) void crop_resample_kernel(
     const bool without = (mode == 0) ? (m > N) : (m >= N);
     if (!sel && without) {
         for (int i = tid; i < m; i += 256)
-            keys[i] = (unsigned)(mix64(seed ^ mix64(((unsigned long long)g << 32) | (unsigned)i)) >> 32);
+            keys[i] = (unsigned)(mix64(seed ^ mix64(gkey | (unsigned)i)) >> 32);
         __syncthreads();
         auto count_le = [&](unsigned T) {
             int c = 0;
@@ -311,13 +318,78 @@ __global__ __launch_bounds__(256) void crop_resample_kernel(
             r = sel[(size_t)g * N + n];
             r = r < 0 ? 0 : (r >= m ? m - 1 : r);
         } else {
-            r = (int)(mix64(seed ^ mix64(((unsigned long long)g << 32) | (unsigned)n)) % (unsigned long long)m);
+            r = (int)(mix64(seed ^ mix64(gkey | (unsigned)n)) % (unsigned long long)m);
         }
         double x, y, z, a, b, c;
         load_point<F64>(cloud, gi[r], x, y, z);
         to_frame(F, x, y, z, a, b, c);
         o[n] = (float)a; o[N + n] = (float)b; o[2 * N + n] = (float)c;
     }
+}
+
+// my_collate (main_1v.py:48-50) on the device: sample g of a training batch is kept iff its crop holds at least
+// min_points points (dataset.py:71-72) and it carries a label (dataset.py:446-453: None between the thresholds).
+// One workgroup: an ordered prefix over keep[] gives each kept sample its row in the compacted batch (rows[g], -1 =
+// dropped; pngpd_crop_resample then writes straight to that row), compacts the labels, and leaves the kept count in
+// device memory — the host learns it from a pinned copy one batch later, never by stalling on this one.
+__global__ __launch_bounds__(1024) void batch_keep_rows_kernel(const int *__restrict__ counts,
+                                                               const long long *__restrict__ labels, int G,
+                                                               int min_points, int *__restrict__ rows,
+                                                               long long *__restrict__ labels_out,
+                                                               int *__restrict__ n_keep,
+                                                               const int *__restrict__ item) {
+    __shared__ int wcnt[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int running = 0;
+    for (int base = 0; base < G; base += 1024) {
+        const int g = base + tid;
+        const long long lab = g < G ? labels[item ? item[g] : g] : -1;
+        const bool keep = g < G && counts[g] >= min_points && counts[g] > 0 && lab >= 0;
+        const unsigned long long mask = __ballot(keep);
+        __syncthreads();
+        if (lane == 0) wcnt[wave] = __popcll(mask);
+        __syncthreads();
+        int woff = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const int c = wcnt[w]; if (w < wave) woff += c; total += c; }
+        if (g < G) {
+            const int r = running + woff + __popcll(mask & ((1ull << lane) - 1ull));
+            rows[g] = keep ? r : -1;
+            if (keep) labels_out[r] = lab;
+        }
+        running += total;
+    }
+    if (tid == 0) *n_keep = running;
+}
+
+// The per-sample cloud of the full-view datasets (dataset.py:252-254): ``pc[np.random.choice(len(pc), size=Pg)]`` of
+// the stack of the k view files drawn for the sample == Pg uniform rows of the stacked length L, each mapped to the
+// arena through the sample's (start, len) spans.  One thread per drawn row, a counter hash of (seed, global sample
+// index, draw) as the generator; (hash * L) >> 64 is the unbiased-to-2^-64 uniform integer in [0, L).
+__global__ __launch_bounds__(256) void stack_gather_lists_kernel(const int *__restrict__ spans, int k, int Pg,
+                                                                 unsigned long long seed, long long g_base,
+                                                                 int *__restrict__ gather) {
+    __shared__ long long cum[65];
+    __shared__ int start[64];
+    const int g = blockIdx.y, tid = threadIdx.x;
+    if (tid == 0) {
+        long long acc = 0;
+        for (int v = 0; v < k; ++v) {
+            cum[v] = acc;
+            start[v] = spans[((size_t)g * k + v) * 2];
+            acc += spans[((size_t)g * k + v) * 2 + 1];
+        }
+        cum[k] = acc;
+    }
+    __syncthreads();
+    const int j = blockIdx.x * 256 + tid;
+    if (j >= Pg) return;
+    const unsigned long long L = (unsigned long long)cum[k];
+    const unsigned long long h = mix64(seed ^ mix64(((unsigned long long)(g_base + g) << 32) | (unsigned)j));
+    const long long r = (long long)__umul64hi(h, L);
+    int v = 0;
+    while (v + 1 < k && cum[v + 1] <= r) ++v;
+    gather[(size_t)g * Pg + j] = start[v] + (int)(r - cum[v]);
 }
 
 extern "C" {
@@ -327,10 +399,10 @@ int pngpd_crop_count_compact(const void *cloud, int cloud_is_f64, int P, const d
     if (!cloud || !frames || !counts || !idx || P <= 0 || G <= 0 || max_keep <= 0) return PNGPD_ERR_INVALID_ARG;
     if (cloud_is_f64)
         hipLaunchKernelGGL(crop_count_compact_kernel<true>, dim3(G), dim3(256), 0, (hipStream_t)stream,
-                           cloud, P, frames, (const int *)nullptr, (const int *)nullptr, 0, max_keep, counts, idx);
+                           cloud, P, frames, (const int *)nullptr, (const int *)nullptr, 0, max_keep, counts, idx, (const int *)nullptr);
     else
         hipLaunchKernelGGL(crop_count_compact_kernel<false>, dim3(G), dim3(256), 0, (hipStream_t)stream,
-                           cloud, P, frames, (const int *)nullptr, (const int *)nullptr, 0, max_keep, counts, idx);
+                           cloud, P, frames, (const int *)nullptr, (const int *)nullptr, 0, max_keep, counts, idx, (const int *)nullptr);
     return pngpd_launch_status();
 }
 
@@ -340,10 +412,10 @@ int pngpd_crop_count_compact_ranges(const void *arena, int cloud_is_f64, int P, 
         return PNGPD_ERR_INVALID_ARG;
     if (cloud_is_f64)
         hipLaunchKernelGGL(crop_count_compact_kernel<true>, dim3(G), dim3(256), 0, (hipStream_t)stream,
-                           arena, P, frames, ranges, (const int *)nullptr, 0, max_keep, counts, idx);
+                           arena, P, frames, ranges, (const int *)nullptr, 0, max_keep, counts, idx, (const int *)nullptr);
     else
         hipLaunchKernelGGL(crop_count_compact_kernel<false>, dim3(G), dim3(256), 0, (hipStream_t)stream,
-                           arena, P, frames, ranges, (const int *)nullptr, 0, max_keep, counts, idx);
+                           arena, P, frames, ranges, (const int *)nullptr, 0, max_keep, counts, idx, (const int *)nullptr);
     return pngpd_launch_status();
 }
 
@@ -354,17 +426,17 @@ int pngpd_crop_count_compact_gather(const void *arena, int cloud_is_f64, int P, 
         return PNGPD_ERR_INVALID_ARG;
     if (cloud_is_f64)
         hipLaunchKernelGGL(crop_count_compact_kernel<true>, dim3(G), dim3(256), 0, (hipStream_t)stream,
-                           arena, P, frames, (const int *)nullptr, gather, Pg, max_keep, counts, idx);
+                           arena, P, frames, (const int *)nullptr, gather, Pg, max_keep, counts, idx, (const int *)nullptr);
     else
         hipLaunchKernelGGL(crop_count_compact_kernel<false>, dim3(G), dim3(256), 0, (hipStream_t)stream,
-                           arena, P, frames, (const int *)nullptr, gather, Pg, max_keep, counts, idx);
+                           arena, P, frames, (const int *)nullptr, gather, Pg, max_keep, counts, idx, (const int *)nullptr);
     return pngpd_launch_status();
 }
 
 int pngpd_crop_resample(const void *cloud, int cloud_is_f64, int P, const double *frames, const int *ranges,
                         const int *gather, int Pg, int G, const int *counts, const int *idx, int max_keep, int N,
-                        int mode, int min_points, unsigned long long seed, const int *sel, float *out,
-                        unsigned char *valid, void *stream) {
+                        int mode, int min_points, unsigned long long seed, long long g_base, const int *rows,
+                        const int *sel, float *out, unsigned char *valid, void *stream) {
     if (!cloud || !frames || !counts || !idx || !out || !valid || P <= 0 || G <= 0 || max_keep <= 0 || N <= 0 ||
         (mode != 0 && mode != 1) || (gather && Pg <= 0))
         return PNGPD_ERR_INVALID_ARG;
@@ -374,14 +446,74 @@ int pngpd_crop_resample(const void *cloud, int cloud_is_f64, int P, const double
         const int st = pngpd_allow_lds((const void *)crop_resample_kernel<true>, lds);
         if (st != PNGPD_OK) return st;
         hipLaunchKernelGGL(crop_resample_kernel<true>, dim3(G), dim3(256), lds, (hipStream_t)stream,
-                           cloud, P, frames, ranges, gather, Pg, counts, idx, max_keep, N, mode, min_points, seed, sel,
-                           out, valid);
+                           cloud, P, frames, ranges, gather, Pg, counts, idx, max_keep, N, mode, min_points, seed, g_base,
+                           rows, sel, out, valid, (const int *)nullptr);
     } else {
         const int st = pngpd_allow_lds((const void *)crop_resample_kernel<false>, lds);
         if (st != PNGPD_OK) return st;
         hipLaunchKernelGGL(crop_resample_kernel<false>, dim3(G), dim3(256), lds, (hipStream_t)stream,
-                           cloud, P, frames, ranges, gather, Pg, counts, idx, max_keep, N, mode, min_points, seed, sel,
-                           out, valid);
+                           cloud, P, frames, ranges, gather, Pg, counts, idx, max_keep, N, mode, min_points, seed, g_base,
+                           rows, sel, out, valid, (const int *)nullptr);
+    }
+    return pngpd_launch_status();
+}
+
+int pngpd_batch_keep_rows(const int *counts, const long long *labels, int G, int min_points, int *rows,
+                          long long *labels_out, int *n_keep, void *stream) {
+    if (!counts || !labels || !rows || !labels_out || !n_keep || G <= 0) return PNGPD_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(batch_keep_rows_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, labels, G,
+                       min_points, rows, labels_out, n_keep, (const int *)nullptr);
+    return pngpd_launch_status();
+}
+
+int pngpd_stack_gather_lists(const int *spans, int k_views, int Pg, int G, unsigned long long seed, long long g_base,
+                             int *gather, void *stream) {
+    if (!spans || !gather || k_views <= 0 || k_views > 64 || Pg <= 0 || G <= 0) return PNGPD_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(stack_gather_lists_kernel, dim3((Pg + 255) / 256, G), dim3(256), 0, (hipStream_t)stream, spans,
+                       k_views, Pg, seed, g_base, gather);
+    return pngpd_launch_status();
+}
+
+int pngpd_train_batch(const void *arena, int arena_is_f64, int P, const double *frames, const long long *labels,
+                      const int *item, const int *spans, int k_views, int Pg, int *gather_ws, int G, int max_keep,
+                      int N, int min_points, unsigned long long seed, long long g_base, int *counts, int *idx,
+                      int *rows, unsigned char *valid, float *out, long long *labels_out, int *n_keep, void *stream) {
+    if (!arena || !frames || !labels || !spans || !counts || !idx || !rows || !valid || !out || !labels_out ||
+        !n_keep || P <= 0 || G <= 0 || max_keep <= 0 || N <= 0 || k_views < 0 || (k_views > 0 && (!gather_ws || Pg <= 0)))
+        return PNGPD_ERR_INVALID_ARG;
+    const size_t lds = (size_t)(max_keep > N ? max_keep : N) * sizeof(int);
+    if (lds > 150 * 1024) return PNGPD_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int *ranges = k_views ? nullptr : spans;
+    const int *gather = k_views ? gather_ws : nullptr;
+    if (k_views) {
+        const int rc = pngpd_stack_gather_lists(spans, k_views, Pg, G, seed ^ 0x5bd1e995a3c59ac3ull, g_base, gather_ws, stream);
+        if (rc != PNGPD_OK) return rc;
+    }
+    if (arena_is_f64)
+        hipLaunchKernelGGL(crop_count_compact_kernel<true>, dim3(G), dim3(256), 0, st, arena, P, frames, ranges, gather,
+                           k_views ? Pg : 0, max_keep, counts, idx, item);
+    else
+        hipLaunchKernelGGL(crop_count_compact_kernel<false>, dim3(G), dim3(256), 0, st, arena, P, frames, ranges, gather,
+                           k_views ? Pg : 0, max_keep, counts, idx, item);
+    int rc = pngpd_launch_status();
+    if (rc != PNGPD_OK) return rc;
+    hipLaunchKernelGGL(batch_keep_rows_kernel, dim3(1), dim3(1024), 0, st, counts, labels, G, min_points, rows,
+                       labels_out, n_keep, item);
+    rc = pngpd_launch_status();
+    if (rc != PNGPD_OK) return rc;
+    if (arena_is_f64) {
+        rc = pngpd_allow_lds((const void *)crop_resample_kernel<true>, lds);
+        if (rc != PNGPD_OK) return rc;
+        hipLaunchKernelGGL(crop_resample_kernel<true>, dim3(G), dim3(256), lds, st, arena, P, frames, ranges, gather,
+                           k_views ? Pg : 0, counts, idx, max_keep, N, 0, min_points, seed, g_base, rows,
+                           (const int *)nullptr, out, valid, item);
+    } else {
+        rc = pngpd_allow_lds((const void *)crop_resample_kernel<false>, lds);
+        if (rc != PNGPD_OK) return rc;
+        hipLaunchKernelGGL(crop_resample_kernel<false>, dim3(G), dim3(256), lds, st, arena, P, frames, ranges, gather,
+                           k_views ? Pg : 0, counts, idx, max_keep, N, 0, min_points, seed, g_base, rows,
+                           (const int *)nullptr, out, valid, item);
     }
     return pngpd_launch_status();
 }

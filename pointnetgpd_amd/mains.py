@@ -76,8 +76,9 @@ def build_parser():
                    help="single-GPU --cuda training: replay full-size batches from a captured HIP graph "
                         "(train.GraphedTrainStep); ragged batches (my_collate dropped samples) run eagerly")
     p.add_argument("--device-data", action="store_true",
-                   help="single-GPU --cuda: keep every cloud resident in HBM and crop/resample "
-                        "training batches on the GPU (device_loader.DeviceGraspLoader) instead of DataLoader workers")
+                   help="--cuda: keep every cloud resident in HBM and crop/resample training batches on the GPU, "
+                        "prefetched on a side stream under the step (device_loader.DeviceGraspLoader) instead of "
+                        "DataLoader workers; under torchrun every rank walks its share of the epoch")
     p.add_argument("--precision", choices=["fp32", "bf16x3", "bf16"], default="fp32",
                    help="--cuda: arithmetic of the trunk contractions. fp32 = exact (default); bf16x3 = 3-term split "
                         "bf16 products on the bf16 matrix cores (meets the fp32 parity bars); bf16 = plain bf16 "
@@ -155,7 +156,7 @@ def per_rank_batch(batch_size, world):
     return batch_size // world
 
 
-def _make_loaders(cfg, args, world=1):
+def _make_loaders(cfg, args, world=1, rank=0, local_rank=0):
     from .model import dataset as ds
     args.rank_batch = per_rank_batch(args.batch_size, world)
     common = dict(batch_size=args.rank_batch, num_workers=args.num_workers, pin_memory=True, shuffle=True,
@@ -177,11 +178,12 @@ def _make_loaders(cfg, args, world=1):
         common_tr = dict(common, shuffle=False, sampler=sampler)
     else:
         common_tr = common
-    if getattr(args, "device_data", False) and args.cuda and sampler is None and not args.synthetic:
+    if getattr(args, "device_data", False) and args.cuda and not args.synthetic:
+        # HBM-resident data layer: under torchrun every rank walks its strided share of the epoch's permutation
         from .device_loader import DeviceGraspLoader
-        dev = torch.device("cuda", args.gpu if args.gpu != -1 else 0)
+        dev = torch.device("cuda", local_rank if world > 1 else (args.gpu if args.gpu != -1 else 0))
         train_loader = DeviceGraspLoader(tr, args.rank_batch, dev, shuffle=True, seed=args.seed or 0,
-                                         max_keep=16384 if cfg["fullview"] else 8192)
+                                         max_keep=16384 if cfg["fullview"] else 8192, rank=rank, world=world)
         return train_loader, torch.utils.data.DataLoader(te, **common), train_loader   # set_epoch() like a sampler
     return (torch.utils.data.DataLoader(tr, **common_tr), torch.utils.data.DataLoader(te, **common), sampler)
 
@@ -240,7 +242,7 @@ def run(variant, argv=None):
     else:
         np.random.seed(args.seed); torch.manual_seed(args.seed)
     logger = _ScalarLog(os.path.join(args.log_dir, args.tag)) if rank == 0 else None
-    train_loader, test_loader, sampler = _make_loaders(cfg, args, world)
+    train_loader, test_loader, sampler = _make_loaders(cfg, args, world, rank, local_rank)
 
     device = torch.device("cpu")
     if args.cuda:

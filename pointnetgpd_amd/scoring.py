@@ -54,9 +54,14 @@ class GraspScorer:
         self.best_class = 2 if k == 3 else 1          # kinect2grasp.py:484-487
 
     @torch.no_grad()
-    def score(self, scene_cloud, grasps):
+    def score(self, scene_cloud, grasps, g_base=0):
         """-> dict(pred (G,) int64 voted class, score (G,) fp32, counts (G,) int32, valid (G,) bool,
-        good (G,) bool, order: indices of the good grasps sorted by score descending)."""
+        good (G,) bool, order: indices of the good grasps sorted by score descending).
+
+        ``g_base``: index of ``grasps[0]`` in the scene's full candidate list.  The resampling of candidate i is
+        drawn from ``(seed, rep, g_base + i)`` alone, so its votes and score are the same bit for bit whether the list
+        is scored whole, in slices on 8 GPUs, or with another ``batch`` — as in the reference, where every candidate
+        is scored on its own (kinect2grasp.py:454-497)."""
         dev = next(self.model.parameters()).device
         cloud = torch.as_tensor(scene_cloud).to(dev)
         if cloud.dtype not in (torch.float32, torch.float64):
@@ -76,7 +81,7 @@ class GraspScorer:
                 e = min(G, s + self.batch)
                 pts, v = crop.crop_resample(cloud, frames[s:e], counts[s:e], idx[s:e], self.num_points,
                                             crop.MODE_INFER, self.min_points,
-                                            seed=self.seed + 1000003 * rep + s)
+                                            seed=self.seed * 1000003 + rep, g_base=int(g_base) + s)
                 logp, _ = self.model(pts)
                 probs[rep, s:e] = logp.softmax(1)
                 if rep == 0:
@@ -150,7 +155,13 @@ def score_scene_distributed(score_fn, scene_cloud, grasps, group=None):
     s, e = shard_grasps(G, rank, world)
     per = (G + world - 1) // world
     if e > s:
-        res = score_fn(scene_cloud, grasps[s:e])
+        # hand the slice its global offset when the scorer takes one (GraspScorer.score): sharded == unsharded scores
+        import inspect
+        try:
+            takes_base = "g_base" in inspect.signature(score_fn).parameters
+        except (TypeError, ValueError):
+            takes_base = False
+        res = score_fn(scene_cloud, grasps[s:e], g_base=s) if takes_base else score_fn(scene_cloud, grasps[s:e])
         dev = res["score"].device
         local = torch.stack([res["pred"].float(), res["score"].float(), res["counts"].float(),
                              res["valid"].float()], dim=1)

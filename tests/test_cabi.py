@@ -106,9 +106,9 @@ def test_argument_validation_of_every_family():
     assert lib.pngpd_hand_box_counts_indexed(p, 0, 130, p, 3, p, 5, p, 3, p, None) == UNSUP
     # crop
     assert lib.pngpd_crop_count_compact(p, 0, 10, p, 0, 16, p, p, None) == INV                     # G == 0
-    assert lib.pngpd_crop_resample(p, 0, 10, p, None, None, 0, 1, p, p, 16, 8, 2, 20, 0, None, p, p, None) == INV   # mode
-    assert lib.pngpd_crop_resample(p, 0, 10, p, None, p, 0, 1, p, p, 16, 8, 1, 20, 0, None, p, p, None) == INV      # gather, Pg 0
-    assert lib.pngpd_crop_resample(p, 0, 10, p, None, None, 0, 1, p, p, 1 << 20, 8, 1, 20, 0, None, p, p, None) == UNSUP  # LDS
+    assert lib.pngpd_crop_resample(p, 0, 10, p, None, None, 0, 1, p, p, 16, 8, 2, 20, 0, 0, None, None, p, p, None) == INV   # mode
+    assert lib.pngpd_crop_resample(p, 0, 10, p, None, p, 0, 1, p, p, 16, 8, 1, 20, 0, 0, None, None, p, p, None) == INV      # gather, Pg 0
+    assert lib.pngpd_crop_resample(p, 0, 10, p, None, None, 0, 1, p, p, 1 << 20, 8, 1, 20, 0, 0, None, None, p, p, None) == UNSUP  # LDS
     # training passes
     assert lib.pngpd_trunk_bn2_stats(p, 4, 100, None, p, p, p, p, p, 0, p, None, None) == INV         # S < 1
     assert lib.pngpd_trunk_bn2_stats(p, 4, 100, None, p, p, p, p, p, 3, p, None, None) == INV         # S > ceil(N/64)

@@ -126,7 +126,8 @@ def test_scorer_end_to_end(cuda_device):
     probs = res["probs"][0].cpu().numpy()
     for s in range(0, 40, 16):
         e = min(40, s + 16)
-        pts, v = crop.crop_resample(cloud, frames[s:e], counts[s:e], idx[s:e], N, crop.MODE_INFER, 20, seed=5 + s)
+        pts, v = crop.crop_resample(cloud, frames[s:e], counts[s:e], idx[s:e], N, crop.MODE_INFER, 20,
+                                    seed=5 * 1000003, g_base=s)
         with torch.no_grad():
             lp_ref, _ = po.forward_torch(sd, pts.cpu())
         np.testing.assert_allclose(probs[s:e], lp_ref.softmax(1).numpy(), atol=1e-3)
@@ -141,10 +142,10 @@ def test_scorer_end_to_end(cuda_device):
     assert (np.diff(score[order]) <= 1e-7).all()
     # test_network (main_test.py:59-69) on one cloud agrees with the batched path
     g0 = int(np.nonzero(valid)[0][0])
-    s0 = (g0 // 16) * 16
-    pts, _ = crop.crop_resample(cloud, frames[s0:s0 + 16], counts[s0:s0 + 16], idx[s0:s0 + 16], N,
-                                crop.MODE_INFER, 20, seed=5 + s0)
-    p1, pr1 = test_network(mg, pts[g0 - s0].cpu().numpy().T)
+    # the draw of candidate g0 depends on (seed, global index) only: resample it ALONE, as the reference's loop does
+    pts, _ = crop.crop_resample(cloud, frames[g0:g0 + 1], counts[g0:g0 + 1], idx[g0:g0 + 1], N,
+                                crop.MODE_INFER, 20, seed=5 * 1000003, g_base=g0)
+    p1, pr1 = test_network(mg, pts[0].cpu().numpy().T)
     assert int(p1) == int(pred[g0])
     np.testing.assert_allclose(pr1[0], probs[g0], atol=1e-5)
 

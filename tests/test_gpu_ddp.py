@@ -190,15 +190,15 @@ def _score_worker(rank, world, port, out_dir):
     torch.save({k: v.cpu() for k, v in res.items()}, os.path.join(out_dir, f"s{rank}.pt"))
     if rank == 0:                                            # single-process answer for the same candidates
         one = scorer.score(pc.astype(np.float32), grasps)
-        torch.save({k: one[k].cpu() for k in ("pred", "counts", "valid")}, os.path.join(out_dir, "one.pt"))
+        torch.save({k: one[k].cpu() for k in ("pred", "score", "counts", "valid")}, os.path.join(out_dir, "one.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_sharded_scene_scoring_two_ranks_hip(tmp_path, cuda_device):
     """BASELINE config 5's sharding with the REAL scorer (crop + resample + PointNet kernels) on two ranks: every
-    rank ends with the same all-gathered result, and counts / validity / predictions equal the single-process run
-    (scores differ only through the per-slice resampling seeds, so they are not compared)."""
+    rank ends with the same all-gathered result, and counts / validity / predictions / SCORES equal the single-process
+    run bit for bit (the resampling of a candidate is keyed by its global index, not by its place in a shard)."""
     world, port = 2, _free_port()
     mp.start_processes(_score_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
     r0, r1, one = torch.load(tmp_path / "s0.pt"), torch.load(tmp_path / "s1.pt"), torch.load(tmp_path / "one.pt")
@@ -206,6 +206,7 @@ def test_sharded_scene_scoring_two_ranks_hip(tmp_path, cuda_device):
         assert torch.equal(r0[k], r1[k]), k
     assert r0["counts"].shape[0] == 37
     assert torch.equal(r0["counts"], one["counts"]) and torch.equal(r0["valid"], one["valid"])
+    assert torch.equal(r0["score"], one["score"]) and torch.equal(r0["pred"], one["pred"])
     sc = r0["score"][r0["order"]]
     assert (sc[:-1] >= sc[1:]).all()
 

@@ -151,3 +151,60 @@ def test_cli_with_device_data(tmp_path, monkeypatch, cuda_device):
     r = mains.run("1v", args)
     assert np.isfinite(r["test_loss"]) and 0.0 <= r["train_acc"] <= 1.0
     assert (tmp_path / "m" / "dd_1.model").exists()
+
+
+@pytest.mark.parametrize("fullview", [False, True])
+def test_overlapped_and_serial_loaders_yield_identical_batches(fullview, tmp_path, monkeypatch, cuda_device):
+    """The side-stream schedule (batches produced ``prefetch`` ahead, under a busy consumer stream) and the serial one
+    run the same launches with the same keys: every batch is bit-identical, whatever the prefetch depth, and the draws
+    of a sample depend on its position in the epoch, not on the batch size."""
+    from pointnetgpd_amd.device_loader import DeviceGraspLoader
+    from pointnetgpd_amd.model import dataset as ds_mod
+    root = synth_dataset.build(str(tmp_path / "tree"), grasps_per_obj=40)
+    monkeypatch.setenv("PointNetGPD_FOLDER", root)
+    if fullview:
+        ds = ds_mod.PointGraspMultiClassDataset(obj_points_num=4000, grasp_points_num=100, pc_file_used_num=3,
+                                                grasp_amount_per_file=40, thresh_good=0.5, thresh_bad=1.2, tag="train")
+        ds.min_point_limit = 225                   # drops some samples -> ragged batches
+    else:
+        ds = ds_mod.PointGraspOneViewDataset(grasp_points_num=64, grasp_amount_per_file=40, thresh_good=0.45,
+                                             thresh_bad=1.2, tag="train")     # label None between the thresholds
+    serial = [(d.clone(), t.clone()) for d, t in DeviceGraspLoader(ds, 16, cuda_device, seed=7, prefetch=0)]
+    assert len(serial) == 8 and any(d.shape[0] < 16 for d, _ in serial) and sum(d.shape[0] for d, _ in serial) > 0
+    busy = torch.randn(2048, 2048, device=cuda_device)
+    for depth in (1, 2, 4):
+        got = []
+        for d, t in DeviceGraspLoader(ds, 16, cuda_device, seed=7, prefetch=depth):
+            for _ in range(3):
+                busy = torch.tanh(busy @ busy * 1e-3)          # the consumer's stream is busy while the next batches are made
+            got.append((d.clone(), t.clone()))
+        assert len(got) == len(serial)
+        for (d0, t0), (d1, t1) in zip(serial, got):
+            assert d0.shape == d1.shape and torch.equal(d0, d1) and torch.equal(t0, t1)
+    # batch size 8: the same samples, two batches for one
+    half = [(d.clone(), t.clone()) for d, t in DeviceGraspLoader(ds, 8, cuda_device, seed=7, prefetch=2)]
+    for i, (d0, t0) in enumerate(serial):
+        pair = half[2 * i:2 * i + 2]                            # 120 items: the last 16-batch holds 8 = one 8-batch
+        d1 = torch.cat([p[0] for p in pair]); t1 = torch.cat([p[1] for p in pair])
+        assert torch.equal(d0, d1) and torch.equal(t0, t1)
+
+
+def test_device_loader_rank_shards_cover_the_epoch(tmp_path, monkeypatch, cuda_device):
+    """One process per GPU: the ranks' strided shares of one epoch's permutation are disjoint up to the wrap-around
+    padding and cover every item (DistributedSampler's contract, main_1v.py:120-128 under torchrun)."""
+    from pointnetgpd_amd.device_loader import DeviceGraspLoader
+    from pointnetgpd_amd.model import dataset as ds_mod
+    root = synth_dataset.build(str(tmp_path / "tree"), grasps_per_obj=13)
+    monkeypatch.setenv("PointNetGPD_FOLDER", root)
+    ds = ds_mod.PointGraspOneViewDataset(grasp_points_num=64, grasp_amount_per_file=13, thresh_good=0.6, thresh_bad=0.6,
+                                         tag="train")
+    seen = []
+    for rank in range(4):
+        loader = DeviceGraspLoader(ds, 4, cuda_device, seed=2, rank=rank, world=4)
+        assert len(loader) == 3                     # 39 items -> 10 per rank (1 wrapped) -> 3 batches
+        mine = []
+        for _ in loader:
+            mine += loader.last_meta["items"].tolist()
+        assert len(mine) == 10
+        seen += mine
+    assert sorted(set(seen)) == list(range(39)) and len(seen) == 40
