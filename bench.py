@@ -583,17 +583,18 @@ def main():
                                             early_bucket_at_world_1=True)
 
             def train_step():
+                # mains.py's loop: output + F.nll_loss in one call (PointNetCls.forward_loss, main_1v.py:73-74), the
+                # loss and its backward inside the FC head's own foreign calls
                 opt.zero_grad()
-                lp, _ = tmodel(xt)
                 if averager is not None:
                     # data-parallel (mains.py): summed loss, gradient + sample-count all-reduce in two buckets over
                     # the flat gradient buffer, the optimizer divides by the global count
-                    loss = F.nll_loss(lp, yt, reduction="sum")
+                    loss, lp, _ = tmodel.forward_loss(xt, yt, "sum")
                     total = averager.backward(loss, bt)
                     opt.step(grad_div=total)
-                    return loss / bt
-                loss = F.nll_loss(lp, yt)
-                loss.backward()
+                    return loss.detach() / bt
+                loss, lp, _ = tmodel.forward_loss(xt, yt)
+                _train.loss_backward(loss)
                 opt.step()
                 return loss
             train_step.model, train_step.x = tmodel, xt

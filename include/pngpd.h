@@ -266,6 +266,13 @@ int pngpd_bn1d_bwd(const float *dy, const float *z, const float *y, int B, int C
                    float *dz, float *dgamma, float *dbeta, void *stream);
 /* backward of F.log_softmax (pointnet.py:194): dlogits = g - exp(logp) * rowsum(g) */
 int pngpd_log_softmax_bwd(const float *g, const float *logp, int B, int K, float *dlogits, void *stream);
+/* F.nll_loss (main_1v.py:74; test(): :101 with reduction="sum") on log-probabilities, and its backward fused with
+ * log_softmax's (SURVEY.md 8b `pngpd_logsoftmax_nll_fwd/bwd`):
+ *   fwd: *loss = -sum_b logp[b][target[b]]  (/ B when mean)                      — one workgroup, fp64 accumulation
+ *   bwd: G = (g ? g : 0) + onehot(target) * -(*gloss [/ B]);  dlogits = G - exp(logp) * rowsum(G)                   */
+int pngpd_nll_fwd(const float *logp, const long long *target, int B, int K, int mean, float *loss, void *stream);
+int pngpd_nll_log_softmax_bwd(const float *g, const float *gloss, const long long *target, const float *logp, int B,
+                              int K, int mean, float *dlogits, void *stream);
 
 /* ---- finalize kernels: the parameter-sized fp64 algebra between the passes (pngpd_train_glue.hip) ----
  * stats1 f64[140] = mx[3], Cx[9], mu1[64], var1[64];  stats2 f64[256] = mu2r[128], var2[128];
@@ -379,6 +386,15 @@ typedef struct pngpd_head_train {
                               BatchNorm: exactly zero in exact arithmetic) are written as exact zeros               */
     void *save;    size_t save_bytes;
     void *scratch; size_t scratch_bytes;   /* backward only */
+    /* F.nll_loss(output, target) of main_1v.py:74 inside the same two calls (PNGPD_EPI_LOG_SOFTMAX only; all NULL / 0
+     * = no loss).  forward: *loss = -sum_b out[b][target[b]] (/ B when loss_mean).  backward: the upstream of `out` is
+     * gout (may be NULL when only the loss is differentiated) PLUS the loss path -(*gloss [/ B]) at [b][target[b]]
+     * — F.nll_loss's backward — so dlogits = gloss' (softmax - onehot) in one launch and no ATen kernel is left in a
+     * training step.  target values outside [0,k) contribute nothing (F.nll_loss asserts there).                      */
+    const long long *target;   /* (B) int64 class indices                                                            */
+    float *loss;               /* () fp32                                                                            */
+    const float *gloss;        /* () fp32 device scalar dL/dloss (backward)                                          */
+    int loss_mean;             /* 1: reduction="mean" (main_1v.py:74), 0: "sum" (the per-rank sum of the DDP step)   */
 } pngpd_head_train_t;
 
 /* Diagnostic, used by bench.py's roofline block: a stream of independent matrix instructions and nothing else on every

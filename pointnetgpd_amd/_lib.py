@@ -39,7 +39,8 @@ class HeadTrainArgs(ctypes.Structure):
                 [(n, _P) for n in ("W1", "b1", "g1", "be1", "W2", "b2", "g2", "be2", "W3", "b3",
                                    "rm1", "rv1", "nbt1", "rm2", "rv2", "nbt2", "out", "gout", "dinp",
                                    "dW1", "db1", "dg1", "dbe1", "dW2", "db2", "dg2", "dbe2", "dW3", "db3")] +
-                [("save", _P), ("save_bytes", _Z), ("scratch", _P), ("scratch_bytes", _Z)])
+                [("save", _P), ("save_bytes", _Z), ("scratch", _P), ("scratch_bytes", _Z),
+                 ("target", _P), ("loss", _P), ("gloss", _P), ("loss_mean", _I)])
 
 
 # name -> (restype, argtypes); mirrors include/pngpd.h one-to-one (checked by tests).
@@ -96,6 +97,9 @@ SIGNATURES = {
     "pngpd_bn1d_bwd": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, c_f32p,
                                       ctypes.c_float, ctypes.c_int, c_f32p, c_f32p, c_f32p, c_void]),
     "pngpd_log_softmax_bwd": (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, c_f32p, c_void]),
+    "pngpd_nll_fwd": (ctypes.c_int, [c_f32p, c_void, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, c_void]),
+    "pngpd_nll_log_softmax_bwd": (ctypes.c_int, [c_f32p, c_f32p, c_void, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                 c_f32p, c_void]),
     # ---- finalize kernels
     "pngpd_bn1_finalize": (ctypes.c_int, [c_void, c_void, ctypes.c_int, ctypes.c_int] + [c_void] * 4 +
                            [ctypes.c_float, ctypes.c_float] + [c_void] * 5 + [c_void]),

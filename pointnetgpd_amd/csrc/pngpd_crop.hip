@@ -61,7 +61,11 @@ __global__ __launch_bounds__(256) void crop_count_compact_kernel(
     const void *__restrict__ cloud, int P, const double *__restrict__ frames, const int *__restrict__ ranges,
     const int *__restrict__ gather, int Pg, int max_keep, int *__restrict__ counts, int *__restrict__ idx,
     const int *__restrict__ item) {
-    __shared__ int wcnt[4];
+    // UNR blocks of 256 points per trip: the UNR loads of a thread are independent, so a trip costs ONE memory latency
+    // and one barrier pair instead of UNR of each (a training batch is 64 workgroups on 256 CUs — latency-, not
+    // throughput-bound); positions stay in ascending point order (block-major, then wave, then lane)
+    constexpr int UNR = 4;
+    __shared__ int wcnt[UNR][4];
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     Frame F;
     load_frame(frames + (size_t)(item ? item[g] : g) * 18, F);   // item: frames is a per-dataset table, g's row = item[g]
@@ -70,28 +74,44 @@ __global__ __launch_bounds__(256) void crop_count_compact_kernel(
     const int p_begin = (!gather && ranges) ? ranges[2 * g] : 0;
     const int n = gather ? Pg : (ranges ? ranges[2 * g + 1] : P);
     const int *gi = gather ? gather + (size_t)g * Pg : nullptr;
-    for (int base = 0; base < n; base += 256) {
-        const int i = base + tid;
-        bool in = false;
-        int p = 0;
-        if (i < n) {
-            p = gi ? gi[i] : p_begin + i;
-            double x, y, z, a, b, c;
-            load_point<F64>(cloud, p, x, y, z);
-            to_frame(F, x, y, z, a, b, c);
-            in = (a > F.lo[0]) && (a < F.hi[0]) && (b > F.lo[1]) && (b < F.hi[1]) && (c > F.lo[2]) && (c < F.hi[2]);
-        }
-        const unsigned long long mask = __ballot(in);
-        if (lane == 0) wcnt[wave] = __popcll(mask);
-        __syncthreads();
-        int woff = 0, total = 0;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int base = 0; base < n; base += 256 * UNR) {
+        bool in[UNR];
+        int p[UNR];
+        unsigned long long mask[UNR];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) { const int c = wcnt[w]; if (w < wave) woff += c; total += c; }
-        if (in) {
-            const int pos = running + woff + __popcll(mask & ((1ull << lane) - 1ull));
-            if (pos < max_keep) out[pos] = p;
+        for (int j = 0; j < UNR; ++j) {
+            const int i = base + j * 256 + tid;
+            p[j] = i < n ? (gi ? gi[i] : p_begin + i) : 0;
         }
-        running += total;
+#pragma unroll
+        for (int j = 0; j < UNR; ++j) {
+            const int i = base + j * 256 + tid;
+            in[j] = false;
+            if (i < n) {
+                double x, y, z, a, b, c;
+                load_point<F64>(cloud, p[j], x, y, z);
+                to_frame(F, x, y, z, a, b, c);
+                in[j] = (a > F.lo[0]) && (a < F.hi[0]) && (b > F.lo[1]) && (b < F.hi[1]) && (c > F.lo[2]) && (c < F.hi[2]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < UNR; ++j) {
+            mask[j] = __ballot(in[j]);
+            if (lane == 0) wcnt[j][wave] = __popcll(mask[j]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < UNR; ++j) {
+            int woff = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { const int c = wcnt[j][w]; if (w < wave) woff += c; total += c; }
+            if (in[j]) {
+                const int pos = running + woff + __popcll(mask[j] & below);
+                if (pos < max_keep) out[pos] = p[j];
+            }
+            running += total;
+        }
         __syncthreads();
     }
     if (tid == 0) counts[g] = running;

@@ -1403,6 +1403,49 @@ __global__ void log_softmax_bwd_kernel(const float *__restrict__ g, const float 
     for (int k = 0; k < K; ++k) dlogits[(size_t)b * K + k] = g[(size_t)b * K + k] - expf(logp[(size_t)b * K + k]) * s;
 }
 
+// F.nll_loss(logp, target) (main_1v.py:74): one workgroup, fp64 accumulation in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void nll_fwd_kernel(const float *__restrict__ logp, const long long *__restrict__ target,
+                                                      int B, int K, int mean, float *__restrict__ loss) {
+    __shared__ double sh[4];
+    double acc = 0.0;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const long long t = target[b];
+        if (t >= 0 && t < K) acc -= (double)logp[(size_t)b * K + t];
+    }
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) acc += __shfl_xor(acc, k);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double tot = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+        *loss = (float)(mean ? tot / (double)B : tot);
+    }
+}
+
+// Backward of log_softmax with F.nll_loss's backward folded into its upstream: the loss path contributes
+// -(gloss / B) (ATen's own expression, a division) at the target column; an explicit upstream g on the log-probabilities
+// is added when present.  Same per-element expression as log_softmax_bwd_kernel, so the two-launch form (ATen's
+// nll_loss_backward, then log_softmax_bwd) and this one agree bit for bit.
+__global__ void nll_log_softmax_bwd_kernel(const float *__restrict__ g, const float *__restrict__ gloss,
+                                           const long long *__restrict__ target, const float *__restrict__ logp,
+                                           int B, int K, int mean, float *__restrict__ dlogits) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const long long t = target[b];
+    const float gl = mean ? -(*gloss / (float)B) : -*gloss;
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) {
+        float gk = g ? g[(size_t)b * K + k] : 0.f;
+        if (k == t) gk = g ? gk + gl : gl;
+        s += gk;
+    }
+    for (int k = 0; k < K; ++k) {
+        float gk = g ? g[(size_t)b * K + k] : 0.f;
+        if (k == t) gk = g ? gk + gl : gl;
+        dlogits[(size_t)b * K + k] = gk - expf(logp[(size_t)b * K + k]) * s;
+    }
+}
+
 
 // ---------------------------------------------------------------------------------------
 // Backward of a Linear layer y = x W^T + b (pointnet.py:35-37,191-193) in ONE launch, operands read in place
@@ -1895,6 +1938,20 @@ int pngpd_bn1d_bwd(const float *dy, const float *z, const float *y, int B, int C
     else
         hipLaunchKernelGGL(bn1d_bwd_kernel<false>, grid, dim3(BN1D_CW * BN1D_RL), 0, (hipStream_t)stream,
                            dy, z, y, B, C, gamma, mean, var, eps, relu, dz, dgamma, dbeta);
+    return pngpd_launch_status();
+}
+
+int pngpd_nll_fwd(const float *logp, const long long *target, int B, int K, int mean, float *loss, void *stream) {
+    if (!logp || !target || !loss || B <= 0 || K <= 0) return PNGPD_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(nll_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logp, target, B, K, mean, loss);
+    return pngpd_launch_status();
+}
+
+int pngpd_nll_log_softmax_bwd(const float *g, const float *gloss, const long long *target, const float *logp, int B,
+                              int K, int mean, float *dlogits, void *stream) {
+    if (!gloss || !target || !logp || !dlogits || B <= 0 || K <= 0) return PNGPD_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(nll_log_softmax_bwd_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, g, gloss,
+                       target, logp, B, K, mean, dlogits);
     return pngpd_launch_status();
 }
 

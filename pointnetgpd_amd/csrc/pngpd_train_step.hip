@@ -341,18 +341,27 @@ int pngpd_head_train_fwd(const pngpd_head_train_t *a, void *stream) {
     CHK(pngpd_fc_fwd(s.y1, a->B, a->H1, a->W2, a->b2, a->H2, PNGPD_EPI_NONE, s.z2, stream));
     CHK(pngpd_bn1d_fwd_train(s.z2, a->B, a->H2, a->g2, a->be2, a->eps, 1, s.y2, s.mean2, s.var2, a->momentum, a->rm2,
                              a->rv2, a->nbt2, stream));
-    return pngpd_fc_fwd(s.y2, a->B, a->H2, a->W3, a->b3, a->k, a->epilogue, a->out, stream);
+    CHK(pngpd_fc_fwd(s.y2, a->B, a->H2, a->W3, a->b3, a->k, a->epilogue, a->out, stream));
+    if (a->target) {   // F.nll_loss(output, target), main_1v.py:74
+        if (a->epilogue != PNGPD_EPI_LOG_SOFTMAX || !a->loss) return PNGPD_ERR_INVALID_ARG;
+        return pngpd_nll_fwd(a->out, a->target, a->B, a->k, a->loss_mean, a->loss, stream);
+    }
+    return PNGPD_OK;
 }
 
 int pngpd_head_train_bwd(const pngpd_head_train_t *a, void *stream) {
-    if (!head_ok(a) || !a->gout || !a->scratch || !a->dW1 || !a->db1 || !a->dg1 || !a->dbe1 || !a->dW2 || !a->db2 ||
+    if (!head_ok(a) || (!a->gout && !(a->target && a->gloss)) || !a->scratch || !a->dW1 || !a->db1 || !a->dg1 || !a->dbe1 || !a->dW2 || !a->db2 ||
         !a->dg2 || !a->dbe2 || !a->dW3 || !a->db3)
         return PNGPD_ERR_INVALID_ARG;
     Carve c(a->save, a->save_bytes), cw(a->scratch, a->scratch_bytes);
     HeadSave s; HeadScratch w;
     if (!carve_head_save(c, a, s) || !carve_head_scratch(cw, a, w)) return PNGPD_ERR_WORKSPACE;
     const float *g = a->gout;
-    if (a->epilogue == PNGPD_EPI_LOG_SOFTMAX) {
+    if (a->target && a->gloss) {
+        if (a->epilogue != PNGPD_EPI_LOG_SOFTMAX) return PNGPD_ERR_INVALID_ARG;
+        CHK(pngpd_nll_log_softmax_bwd(a->gout, a->gloss, a->target, a->out, a->B, a->k, a->loss_mean, w.dl, stream));
+        g = w.dl;
+    } else if (a->epilogue == PNGPD_EPI_LOG_SOFTMAX) {
         CHK(pngpd_log_softmax_bwd(a->gout, a->out, a->B, a->k, w.dl, stream));
         g = w.dl;
     }

@@ -140,7 +140,11 @@ class GradAverager:
                 self._count.fill_(float(n_local))
                 self._active, self._early_sent = True, False
                 try:
-                    loss_sum.backward()
+                    if loss_sum.is_cuda:
+                        from .train import loss_backward
+                        loss_backward(loss_sum)       # cached unit root gradient: no ones_like fill per step
+                    else:
+                        loss_sum.backward()
                 finally:
                     self._active = False
                 if self._early is not None and not self._early_sent:

@@ -293,6 +293,18 @@ def run(variant, argv=None):
     if not recreate:
         new_optimizer()
 
+    if args.cuda and hasattr(model, "forward_loss"):
+        # HIP path: F.nll_loss and its backward run inside the FC head's own foreign calls (no ATen kernel in a step)
+        from .train import loss_backward
+        forward_loss = model.forward_loss
+    else:
+        def forward_loss(data, target, reduction):
+            output, trans = model(data)
+            return F.nll_loss(output, target, reduction=reduction), output, trans
+
+        def loss_backward(loss):
+            loss.backward()
+
     def train(epoch):
         if recreate:
             new_optimizer()
@@ -326,8 +338,7 @@ def run(variant, argv=None):
                 optimizer.zero_grad()
                 loss_sum = None
                 if runnable:
-                    output, _ = model(data)
-                    loss_sum = F.nll_loss(output, target, reduction="sum")
+                    loss_sum, output, _ = forward_loss(data, target, "sum")
                     loss = loss_sum.detach() / n_local
                 total = averager.backward(loss_sum, n_local)
                 if total is not None:
@@ -346,9 +357,8 @@ def run(variant, argv=None):
                 loss, output = state["graph"](data, target)
             else:
                 optimizer.zero_grad()
-                output, _ = model(data)
-                loss = F.nll_loss(output, target)
-                loss.backward()
+                loss, output, _ = forward_loss(data, target, "mean")      # main_1v.py:73-74
+                loss_backward(loss)                                       # :75
                 optimizer.step()
             if output is not None:
                 pred = output.data.max(1, keepdim=True)[1]

@@ -324,6 +324,19 @@ class PointNetCls(_HipModule):
         g = F.relu(self.bn2(self.fc2(g)))
         return F.log_softmax(self.fc3(g), dim=-1), trans
 
+    def forward_loss(self, x, target, reduction="mean"):
+        """``output, trans = model(x); loss = F.nll_loss(output, target, reduction=reduction)`` (main_1v.py:73-74) as
+        one call -> (loss, output, trans).  On the HIP training path the loss and its backward run inside the FC head's
+        own foreign calls (``pngpd_head_train_fwd/_bwd`` with ``target``): no ATen kernel is left in a training step.
+        Everywhere else (CPU, eval) it is literally the two reference lines."""
+        if x.is_cuda and self.training:
+            g, trans = self.feat(x)
+            output, loss = train.head_train(self.fc1, self.bn1, self.fc2, self.bn2, self.fc3, g, ops.EPI_LOG_SOFTMAX,
+                                            target=target, reduction=reduction)
+            return loss, output, trans
+        output, trans = self(x)
+        return F.nll_loss(output, target, reduction=reduction), output, trans
+
 
 # ---------------------------------------------------------------------------------------
 # import-compatibility classes (plain ATen; out of the hot path, see module docstring)

@@ -449,3 +449,23 @@ def log_softmax_bwd(g, logp):
     out = torch.empty_like(logp)
     _call("pngpd_log_softmax_bwd", logp, _f32(g, "g", (B, K)), logp, B, K, out)
     return out
+
+
+def nll_fwd(logp, target, mean=True):
+    """F.nll_loss(logp, target, reduction='mean'|'sum') (main_1v.py:74, :101) -> 0-dim fp32 tensor."""
+    B, K = logp.shape
+    if not target.is_cuda or target.dtype != torch.int64 or tuple(target.shape) != (B,):
+        raise RuntimeError("nll_fwd: target must be a CUDA int64 tensor of shape (B,)")
+    loss = torch.empty((), device=logp.device, dtype=torch.float32)
+    _call("pngpd_nll_fwd", logp, _f32(logp, "logp", (B, K)), target.contiguous(), B, K, int(bool(mean)), loss)
+    return loss
+
+
+def nll_log_softmax_bwd(g, gloss, target, logp, mean=True):
+    """Backward of ``F.nll_loss(F.log_softmax(z), target)`` w.r.t. z in one launch: upstream ``g`` (B,K) on the
+    log-probabilities (or None) plus ``gloss`` (0-dim fp32) on the loss."""
+    B, K = logp.shape
+    out = torch.empty_like(logp)
+    _call("pngpd_nll_log_softmax_bwd", logp, None if g is None else _f32(g, "g", (B, K)), gloss.contiguous(),
+          target.contiguous(), logp, B, K, int(bool(mean)), out)
+    return out

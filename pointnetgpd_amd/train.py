@@ -472,7 +472,8 @@ class FusedHeadFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, inp, W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, epilogue, eps, momentum, bufs1, bufs2,
-                grad_outs):
+                grad_outs, target=None, loss_mean=True):
+        ctx.set_materialize_grads(False)      # an output nobody differentiates arrives as None, not as a zero fill
         inp = inp.contiguous()
         dev = inp.device
         P = [t.detach().contiguous() for t in (W1, b1, g1, be1, W2, b2, g2, be2, W3, b3)]
@@ -495,20 +496,41 @@ class FusedHeadFn(torch.autograd.Function):
         a.save, a.save_bytes = save.data_ptr(), sizes[0]
         out = torch.empty(a.B, a.k, device=dev, dtype=torch.float32)
         a.out = out.data_ptr()
+        loss = None
+        if target is not None:
+            if int(epilogue) != ops.EPI_LOG_SOFTMAX:
+                raise RuntimeError("head_train: a target needs the log_softmax tail")
+            if not target.is_cuda or target.dtype != torch.int64 or tuple(target.shape) != (a.B,):
+                raise RuntimeError("head_train: target must be a CUDA int64 tensor of shape (B,)")
+            target = target.contiguous()
+            loss = torch.empty((), device=dev, dtype=torch.float32)
+            a.target, a.loss, a.loss_mean = target.data_ptr(), loss.data_ptr(), int(bool(loss_mean))
         _ccall("pngpd_head_train_fwd", a, dev)
         _bump(bufs1); _bump(bufs2)
         ctx.args, ctx.save_buf, ctx.grad_outs, ctx.sizes = a, save, grad_outs, sizes
+        ctx.target = target
         ctx.save_for_backward(inp, out, *P)
-        return out
+        if loss is None:
+            return out
+        return out, loss
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_loss=None):
         saved = ctx.saved_tensors
         inp, P = saved[0], saved[2:]
         dev = inp.device
         a = ctx.args
-        g = g.contiguous()
-        a.gout = g.data_ptr()
+        if g is None and g_loss is None:
+            raise RuntimeError("head_train backward: neither the log-probabilities nor the loss carry a gradient")
+        g = g.contiguous() if g is not None else None
+        a.gout = _dp(g)
+        if g_loss is not None:
+            g_loss = g_loss.to(torch.float32).contiguous()
+            a.gloss = g_loss.data_ptr()
+        else:
+            a.gloss = None
+            if ctx.target is not None:
+                a.target = None               # the loss took no part in this backward: plain log_softmax upstream
         shapes = [tuple(t.shape) for t in P]
         if ctx.grad_outs is not None:
             outs, views = ctx.grad_outs.views, None
@@ -527,7 +549,9 @@ class FusedHeadFn(torch.autograd.Function):
         if views is None:
             ctx.grad_outs.mark_written()
         grads = (None,) * 10 if views is None else tuple(views)
-        return (dinp,) + grads + (None,) * 6
+        if ctx.target is not None:
+            a.target = ctx.target.data_ptr()
+        return (dinp,) + grads + (None,) * 8
 
 
 def _bufs(bn):
@@ -570,17 +594,33 @@ def fc_epilogue_train(lin, inp, epilogue):
     return LinearEpiFn.apply(inp, lin.weight, lin.bias, epilogue)
 
 
-def head_train(fc1, bn1, fc2, bn2, fc3, inp, epilogue):
-    """relu(bn1(fc1(inp))) -> relu(bn2(fc2(.))) -> fc3 + tail, train mode (pointnet.py:35-43, :191-194)."""
+def head_train(fc1, bn1, fc2, bn2, fc3, inp, epilogue, target=None, reduction="mean"):
+    """relu(bn1(fc1(inp))) -> relu(bn2(fc2(.))) -> fc3 + tail, train mode (pointnet.py:35-43, :191-194).
+    ``target`` (B,) int64: also returns ``F.nll_loss(out, target, reduction=reduction)`` (main_1v.py:74) -> (out, loss);
+    in fused sequencing the loss and its backward run inside the head's own two foreign calls."""
+    if reduction not in ("mean", "sum"):
+        raise ValueError("reduction must be 'mean' or 'sum'")
     if _use_fused():
         mom = bn1.momentum if bn1.momentum is not None else 0.1
         params = (fc1.weight, fc1.bias, bn1.weight, bn1.bias, fc2.weight, fc2.bias, bn2.weight, bn2.bias,
                   fc3.weight, fc3.bias)
         return FusedHeadFn.apply(inp, *params, int(epilogue), float(bn1.eps), float(mom), _bufs(bn1), _bufs(bn2),
-                                 _grad_outs(params))
+                                 _grad_outs(params), target, reduction == "mean")
     g = fc_bn_relu_train(fc1, bn1, inp)
     g = fc_bn_relu_train(fc2, bn2, g)
-    return fc_epilogue_train(fc3, g, epilogue)
+    out = fc_epilogue_train(fc3, g, epilogue)
+    if target is None:
+        return out
+    return out, torch.nn.functional.nll_loss(out, target, reduction=reduction)
+
+
+def loss_backward(loss):
+    """``loss.backward()`` (main_1v.py:75) with a cached unit gradient: autograd's own root gradient is a
+    ``ones_like`` = one fill launch per step."""
+    if loss.is_cuda and loss.dim() == 0 and loss.dtype == torch.float32:
+        loss.backward(gradient=_pm_one(loss.device)[0])
+    else:
+        loss.backward()
 
 
 class GraphedTrainStep:
@@ -629,9 +669,13 @@ class GraphedTrainStep:
 
         def one_step():
             optimizer.zero_grad(set_to_none=True)
-            logp, _ = self.model(self.x)
-            loss = F.nll_loss(logp, self.y)
-            loss.backward()
+            if hasattr(self.model, "forward_loss"):
+                loss, logp, _ = self.model.forward_loss(self.x, self.y)
+                loss_backward(loss)
+            else:
+                logp, _ = self.model(self.x)
+                loss = F.nll_loss(logp, self.y)
+                loss.backward()
             optimizer.step()
             return loss, logp
 

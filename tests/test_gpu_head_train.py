@@ -193,3 +193,85 @@ def test_log_softmax_bwd_kernel_vs_fp64(B, k, cuda_device):
     f = lambda t: t.detach().float().to(cuda_device).contiguous()
     got = ops.log_softmax_bwd(f(g), f(logp))
     assert rel_max(got, logits.grad) <= 1e-5
+
+
+@pytest.mark.parametrize("B,k", [(2, 2), (33, 3), (64, 2), (1024, 2), (1024, 3), (4096, 3)])
+@pytest.mark.parametrize("mean", [True, False])
+def test_nll_kernels_vs_fp64(B, k, mean, cuda_device):
+    """pngpd_nll_fwd / pngpd_nll_log_softmax_bwd (SURVEY 8b's logsoftmax_nll pair) against F.nll_loss over
+    F.log_softmax in fp64 (main_1v.py:74-75): the loss, and d loss / d logits with and without an extra upstream
+    gradient on the log-probabilities — isolated gate at 1e-6."""
+    import torch.nn.functional as F
+    from pointnetgpd_amd import ops
+    gen = torch.Generator().manual_seed(B * 31 + k)
+    logits = (torch.randn(B, k, generator=gen, dtype=torch.float64) * 3).requires_grad_(True)
+    target = torch.randint(0, k, (B,), generator=gen)
+    g = torch.randn(B, k, generator=gen, dtype=torch.float64)
+    gl = 0.7
+    red = "mean" if mean else "sum"
+    logp = torch.log_softmax(logits, -1)
+    loss = F.nll_loss(logp, target, reduction=red)
+    (loss * gl).backward(retain_graph=True)
+    d_loss_only = logits.grad.clone()
+    logits.grad = None
+    (loss * gl + (logp * g).sum()).backward()
+    d_both = logits.grad.clone()
+    f = lambda t: t.detach().float().to(cuda_device).contiguous()
+    lp, tg = f(logp), target.to(cuda_device)
+    got = ops.nll_fwd(lp, tg, mean)
+    assert abs(got.item() - loss.item()) <= 1e-6 * max(1.0, abs(loss.item()))
+    gloss = torch.tensor(gl, device=cuda_device)
+    d1 = ops.nll_log_softmax_bwd(None, gloss, tg, lp, mean)
+    d2 = ops.nll_log_softmax_bwd(f(g), gloss, tg, lp, mean)
+    assert rel_max(d1, d_loss_only) <= 1e-6 and rel_max(d2, d_both) <= 1e-5
+    # the two-launch form it replaces (ATen's nll_loss_backward, then pngpd_log_softmax_bwd): bit-identical
+    lp_r = lp.clone().requires_grad_(True)
+    F.nll_loss(lp_r, tg, reduction=red).backward(gradient=gloss)
+    assert torch.equal(d1, ops.log_softmax_bwd(lp_r.grad.contiguous(), lp))
+
+
+@pytest.mark.parametrize("k,reduction", [(2, "mean"), (3, "sum")])
+def test_forward_loss_equals_the_two_reference_lines(k, reduction, cuda_device):
+    """PointNetCls.forward_loss == ``output, _ = model(x); loss = F.nll_loss(output, target)`` (main_1v.py:73-74):
+    same log-probabilities and BatchNorm buffers, loss within 1e-6, and — the fused backward writes the very numbers
+    the ATen + log_softmax_bwd pair produces — bit-identical parameter gradients; likewise against pass-by-pass
+    sequencing.  No ATen kernel is launched by the fused step."""
+    import copy
+    import torch.nn.functional as F
+    from pointnetgpd_amd import train
+    from tests.helpers import build_model
+    B, N = 24, 128
+    m0 = build_model(N, k, 77, 4800).train().to(cuda_device)
+    gen = torch.Generator().manual_seed(5)
+    x = ((torch.rand(B, 3, N, generator=gen) - 0.5) * 0.08).to(cuda_device)
+    y = torch.randint(0, k, (B,), generator=gen).to(cuda_device)
+    res = {}
+    for tag in ("fused_loss", "two_lines", "passes"):
+        m = copy.deepcopy(m0)
+        train.set_sequencing("passes" if tag == "passes" else "fused")
+        try:
+            if tag == "two_lines":
+                out, _ = m(x)
+                loss = F.nll_loss(out, y, reduction=reduction)
+                loss.backward()
+            else:
+                loss, out, _ = m.forward_loss(x, y, reduction)
+                train.loss_backward(loss)
+        finally:
+            train.set_sequencing("fused")
+        res[tag] = (loss.detach().clone(), out.detach().clone(), {n: p.grad.clone() for n, p in m.named_parameters()},
+                    {n: b.clone() for n, b in m.named_buffers()})
+    l0, o0, g0, b0 = res["two_lines"]
+    for tag in ("fused_loss", "passes"):
+        l1, o1, g1, b1 = res[tag]
+        assert torch.equal(o0, o1) and abs(l0.item() - l1.item()) <= 1e-6 * max(1.0, abs(l0.item()))
+        for n in g0:
+            assert torch.equal(g0[n], g1[n]), (tag, n)
+        for n in b0:
+            assert torch.equal(b0[n], b1[n]), (tag, n)
+    # eval mode / no grad: literally the two lines
+    m = copy.deepcopy(m0).eval()
+    with torch.no_grad():
+        loss, out, _ = m.forward_loss(x, y, reduction)
+        ref = F.nll_loss(m(x)[0], y, reduction=reduction)
+    assert torch.equal(loss, ref)

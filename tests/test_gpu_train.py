@@ -300,9 +300,8 @@ def test_graphed_train_step_equals_eager(cuda_device):
         loss_g, logp_g = step(x, y)
         loss_g, logp_g = loss_g.clone(), logp_g.clone()
         opt_e.zero_grad(set_to_none=True)
-        logp_e, _ = m_e(x)
-        loss_e = F.nll_loss(logp_e, y)
-        loss_e.backward()
+        loss_e, logp_e, _ = m_e.forward_loss(x, y)            # the eager loop of mains.py (loss inside the head's calls)
+        pt.loss_backward(loss_e)
         opt_e.step()
         assert torch.equal(logp_g, logp_e.detach()) and torch.equal(loss_g, loss_e.detach()), i
     # the CLI's mixture (mains.py --hip-graph): a ragged batch runs eagerly on the SAME optimizer, then replays go on
@@ -316,8 +315,10 @@ def test_graphed_train_step_equals_eager(cuda_device):
     y = torch.randint(0, k, (B,), generator=torch.Generator().manual_seed(10)).to(cuda_device)
     loss_g, _ = step(x, y)
     opt_e.zero_grad(set_to_none=True)
+    # the reference's two lines (main_1v.py:73-75) through ATen's nll_loss: the same gradients bit for bit (the parameter
+    # comparison below), the loss VALUE to 1e-6 (fp64 accumulation in pngpd_nll_fwd vs ATen's fp32 reduction)
     loss_e = F.nll_loss(m_e(x)[0], y); loss_e.backward(); opt_e.step()
-    assert torch.equal(loss_g, loss_e.detach())
+    assert abs(loss_g.item() - loss_e.item()) <= 1e-6 * max(1.0, abs(loss_e.item()))
     sd_g, sd_e = m_g.state_dict(), m_e.state_dict()
     for n in sd_g:
         assert torch.equal(sd_g[n], sd_e[n]), n

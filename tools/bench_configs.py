@@ -67,8 +67,8 @@ def main():
 
             def step():
                 opt.zero_grad()
-                logp, _ = m(x)
-                F.nll_loss(logp, y).backward()
+                loss, _, _ = m.forward_loss(x, y)          # mains.py's step: loss inside the head's calls
+                pt.loss_backward(loss)
                 opt.step()
             ms = timeit(step, 8)
             row[f"train_{prec}_ms"] = round(ms, 3)

@@ -42,6 +42,7 @@ def measure(case, steps=150, warmup=10, dev=None, prefetch=2, root=None):
     from pointnetgpd_amd.model import dataset as ds_mod
     from pointnetgpd_amd.model.pointnet import PointNetCls
     from pointnetgpd_amd.optim import FlatAdam
+    from pointnetgpd_amd.train import loss_backward
     dev = dev or torch.device("cuda:0")
     cls, kw, B, max_keep, points, label = CASES[case]
     if root is None:
@@ -56,8 +57,8 @@ def measure(case, steps=150, warmup=10, dev=None, prefetch=2, root=None):
 
     def step(x, y):
         opt.zero_grad()
-        logp, _ = model(x)
-        F.nll_loss(logp, y).backward()
+        loss, _, _ = model.forward_loss(x, y)                  # mains.py's step (main_1v.py:72-76)
+        loss_backward(loss)
         opt.step()
 
     def batches(loader):
