@@ -290,22 +290,66 @@ def cpu_baseline(num_points, k, budget_s=7.0):
         n_crop += 1
     crop_dt = (time.perf_counter() - t0) / n_crop
     torch.set_num_threads(cores)
-    # the headline batch itself, ONE eval forward (about 8 s of CPU work)
+    # the headline batch itself: three eval forwards (about 8 s of CPU work each), median
     xb = synth_clouds(1024, num_points, 98, cpu)
     big_model = rm if ref is not None else None
     if big_model is not None:
         big_model.eval()
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        if big_model is not None:
-            big_model(xb)
-        else:
-            po.forward_torch(sd, xb)
-    big_dt = time.perf_counter() - t0
+    big = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            if big_model is not None:
+                big_model(xb)
+            else:
+                po.forward_torch(sd, xb)
+        big.append(time.perf_counter() - t0)
+    big_dt = statistics.median(big)
+    # BASELINE configs[0]'s own shape: main_1v.py's recipe (2-class, N = 750, batch 64), eval forward + training step
+    c0_n, c0_b = 750, 64
+    c0m = build_model(c0_n, 2, cpu)
+    c0sd = {kk: v.detach().clone() for kk, v in c0m.state_dict().items()}
+    c0x, c0y = synth_clouds(c0_b, c0_n, 97, cpu), (torch.arange(c0_b) % 2).long()
+    if ref is not None:
+        c0r = ref.PointNetCls(num_points=c0_n, input_chann=3, k=2)
+        c0r.load_state_dict(c0sd)
+        c0r.eval()
+
+        def c0_fwd():
+            with torch.no_grad():
+                c0r(c0x)
+        c0_eval, c0_eit = _time_loop(c0_fwd, 3.0)
+        c0r.train()
+        c0opt = torch.optim.Adam(c0r.parameters(), lr=0.005)
+
+        def c0_step():
+            c0opt.zero_grad()
+            F.nll_loss(c0r(c0x)[0], c0y).backward()
+            c0opt.step()
+    else:
+        def c0_fwd():
+            with torch.no_grad():
+                po.forward_torch(c0sd, c0x)
+        c0_eval, c0_eit = _time_loop(c0_fwd, 3.0)
+        c0w = {n: v.clone().requires_grad_(v.is_floating_point() and "running_" not in n) for n, v in c0sd.items()}
+        c0opt = torch.optim.Adam([v for v in c0w.values() if v.requires_grad], lr=0.005)
+
+        def c0_step():
+            c0opt.zero_grad()
+            F.nll_loss(po.forward_torch(c0w, c0x, training=True)[0], c0y).backward()
+            c0opt.step()
+    c0_train, c0_tit = _time_loop(c0_step, 3.0, lo=2, hi=10)
     return {"value": round(b / eval_dt, 2), "unit": "grasps/s", "cores": cores, "threads": cores, "batch": b,
             "kind": kind,
-            "headline_batch": {"value": round(1024 / big_dt, 2), "unit": "grasps/s", "batch": 1024, "iters": 1,
-                               "sample": "one eval forward at the headline batch B=1024 (same module, same threads)"},
+            "headline_batch": {"value": round(1024 / big_dt, 2), "unit": "grasps/s", "batch": 1024, "iters": 3,
+                               "seconds_each": [round(t, 2) for t in big],
+                               "sample": "median of three eval forwards at the headline batch B=1024 (same module, "
+                                         "same threads)"},
+            "configs0": {"workload": "BASELINE configs[0]: main_1v.py 2-class PointNetCls, N=750, batch=64, CPU PyTorch",
+                         "value": round(c0_b / c0_eval, 2), "unit": "grasps/s", "iters": c0_eit,
+                         "train_step": {"value": round(c0_b / c0_train, 2), "unit": "grasps/s", "iters": c0_tit,
+                                        "step": "fwd+nll_loss+bwd+Adam (main_1v.py:72-76)"},
+                         "kind": kind, "threads": cores},
             "sample": f"{what}, eval forward, fp32, B={b} N={num_points}, {eval_it} iters, {cores} threads",
             "train_step": {"value": round(b / train_dt, 2), "unit": "grasps/s", "iters": train_it,
                            "step": "fwd+nll_loss+bwd+Adam, same module and batch"},
@@ -431,6 +475,66 @@ class Timer:
                 "min_wall": min(walls), "out": out}
 
 
+def train_pass_rooflines(B, N, dev, reps=None):
+    """Per-pass rooflines of the fp32 training step's trunk kernels, timed NOW with HIP events on the launch stream:
+    each pass entry of the C ABI (the very kernels ``pngpd_trunk_train_fwd/_bwd`` sequence) on synthetic but valid
+    operands of the step's shape.  GFLOP = the matrix FLOPs the pass EXECUTES (EXEC_FLOP_PER_POINT_TRUNK x B x N,
+    DESIGN.md section 3), frac = GFLOP / time / the 157.3 TFLOP/s fp32 matrix peak.  A step runs every pass twice (STN
+    trunk + feature trunk): ``trunk_passes_ms_x2`` is what the five passes contribute to ``train.ms_per_step``."""
+    import torch
+    from pointnetgpd_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = synth_clouds(B, N, 1, dev)
+    T = (torch.eye(3)[None] + 0.1 * torch.randn(B, 3, 3, generator=g)).to(dev).contiguous()
+    r = lambda *sh: torch.randn(*sh, generator=g).to(dev)
+    w1, b1 = r(64, 3), r(64) * 0.1
+    s1c, t1c = (torch.rand(64, generator=g) + 0.5).to(dev) * 30, r(64) * 0.1
+    w2 = r(128, 64) / 8; w3 = r(1024, 128) / 11
+    w2p = ops.pack_mfma_b(w2); w3p = ops.pack_mfma_b(w3); w2tp = ops.pack_mfma_b(w2.t().contiguous())
+    s2c, t2c = (torch.rand(128, generator=g) + 0.5).to(dev), r(128) * 0.1
+    is2, nm2, is1, nm1 = s2c.clone(), t2c.clone(), s1c.clone(), t1c.clone()
+    idx = torch.randint(0, N, (B, 1024), generator=g, dtype=torch.int32).to(dev)
+    coef = r(B, 1024) * 1e-3
+    A = r(128, 128) * 1e-3; Ap = ops.pack_mfma_b(((A + A.t()) / 2).contiguous()); cvec = r(128) * 1e-3
+    ev = r(3, 128)
+    S = ops.train_splits(B, N)
+    reps = reps or (10 if B * N >= 512 * 1024 else 50)
+
+    def timeit(fn):
+        out = fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            out = fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps, out
+
+    res = {}
+    ms, (_, z2t) = timeit(lambda: ops.trunk_bn2_stats(x, T, w1, b1, s1c, t1c, w2p, S))
+    res["B bn2 stats (+ z2 store)"] = ms
+    ms, _ = timeit(lambda: ops.trunk_fwd_train(x, T, w1, b1, s1c, t1c, w2p, s2c, t2c, w3p, S, z2t))
+    res["C forward"] = ms
+    ms, _ = timeit(lambda: ops.trunk_bwd_gather(x, T, w1, b1, s1c, t1c, w2p, s2c, t2c, idx, coef))
+    res["gather"] = ms
+    ms, (g2t, _, _) = timeit(lambda: ops.trunk_bwd_d(x, T, w1, b1, s1c, t1c, w2p, s2c, t2c, is2, nm2, Ap, cvec, w3, idx, coef,
+                                                     S, z2t))
+    res["D"] = ms
+    ms, _ = timeit(lambda: ops.trunk_bwd_e(x, T, w1, b1, s1c, t1c, w2p, is1, nm1, is2, nm2, ev[0], ev[1], ev[2], w2tp, g2t, S,
+                                           z2t))
+    res["E"] = ms
+    out, tot_ms, tot_gf = {}, 0.0, 0.0
+    for name, ms in res.items():
+        gf = B * N * EXEC_FLOP_PER_POINT_TRUNK[name] / 1e9
+        tf = gf / ms
+        out[name] = {"gflop": round(gf, 2), "avg_ms": round(ms, 4), "tflops": round(tf, 2),
+                     "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
+        tot_ms += ms; tot_gf += gf
+    return {"bound": "mfma", "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "splits": S, "reps": reps,
+            "timing": "HIP events on the launch stream around `reps` launches of each pass entry, in this run",
+            "passes": out, "trunk_passes_ms_x2": round(2 * tot_ms, 4),
+            "trunk_passes_frac": round(tot_gf / tot_ms / PEAK_FP32_MFMA_TFLOPS, 4)}
+
+
 def measure_sustained_mfma(dev):
     """TFLOP/s of a bare stream of matrix instructions (pngpd_probe_mfma_rate, HIP events on the launch stream)."""
     import ctypes
@@ -473,11 +577,13 @@ def main():
     ap.add_argument("--no-train", action="store_true", help="skip the training-step legs")
     ap.add_argument("--no-fast", action="store_true", help="skip the opt-in bf16x3 legs")
     ap.add_argument("--graph", action="store_true", help="also time the train step replayed from a HIP graph")
+    ap.add_argument("--no-epoch", action="store_true", help="skip the loader + step (train.epoch) block")
     ap.add_argument("--no-config5", action="store_true",
                     help="skip the BASELINE configs[4] leg (100k candidates: crop + scoring, sharded over the ranks)")
-    ap.add_argument("--pmc", action="store_true",
-                    help="measure roofline.traffic NOW with two rocprofv3 --pmc passes over the dominant kernel "
-                         "(N = 1 only; ~15 s) instead of citing the stored figure of profiles/pmc_trunk.json")
+    ap.add_argument("--pmc", action="store_true", help="(default at N = 1 since round 5; kept for old command lines)")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do NOT measure roofline.traffic with the two rocprofv3 --pmc passes over the dominant kernel "
+                         "(N = 1 only; ~15 s); the stored figure of profiles/pmc_trunk.json is cited instead")
     ap.add_argument("--trunk-only", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.trunk_only:
@@ -687,7 +793,8 @@ def main():
             for prec, note in (("bf16x3", "every pass on bf16x3 split products (opt-in)"),
                                ("bf16", "every pass on plain bf16 operands, bf16 z2/g2 tiles (opt-in; BASELINE "
                                         "configs[2] arithmetic)")):
-                leg = {"mode": note}
+                # pool refinement (train._REFINE_POOL: 0 off / 1 matrix pipe / 2 VALU) is part of what these legs measure
+                leg = {"mode": note, "refine_pool": _train._REFINE_POOL, "fp32_side_passes": _train._FP32_SIDE_PASSES}
                 for tag, fn in (("", step), ("_diverse_clouds", step_div)):
                     # parity label first (on the leg's own weights, before the timed steps move them)
                     dl, agree = train_fwd_dlogp(fn, prec)
@@ -707,6 +814,24 @@ def main():
                                       "fp32 forward on the same weights, measured in this run; the iid box clouds of "
                                       "the headline are the adversarial case (near-identical pooled features)")
                 train_res["fast_" + prec] = leg
+
+    # ---- loader + step together (main_1v.py:59-84 fed by :120-128): the HBM-resident data layer prefetching on a side
+    #      stream under the eager HIP step, on a synthetic on-disk tree — what `main_1v.py --cuda --device-data` delivers
+    if train_res is not None and world == 1 and env_world == 0 and not args.no_epoch:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_epoch
+            root_tree = bench_epoch._tree(20000)
+            train_res["epoch"] = {
+                "what": "samples/s of DeviceGraspLoader (crop + resample of batch t+1 on a side stream) + training step "
+                        "(forward_loss + backward + FlatAdam, eager) together, next to the step alone on a resident "
+                        "batch; synthetic tree: 3 objects x 6 views x 20000 points, 6500 grasps each",
+                "cases": [bench_epoch.measure(c, steps=(60 if c != "big" else 20), warmup=5, dev=dev, root=root_tree)
+                          for c in ("one", "full", "big")]}
+            train_res["epoch"]["min_end_to_end_over_step_only"] = min(
+                c["end_to_end_over_step_only"] for c in train_res["epoch"]["cases"])
+        except Exception as e:      # noqa: BLE001  an extra block: never fail the bench over it
+            train_res["epoch"] = {"error": repr(e)}
 
     # ---- BASELINE configs[4]: 100k candidates of one scene, crop + scoring, candidates sharded over the ranks
     c5 = None
@@ -731,11 +856,23 @@ def main():
     achieved = trunk_flops / (trunk_ms * 1e-3) / 1e12
     sustained = measure_sustained_mfma(dev)     # {dtype: TFLOP/s} of a bare MFMA stream on THIS box, or {}
 
+    pass_roof = None
+    if not args.no_train:
+        try:
+            pass_roof = train_pass_rooflines(B, N, dev)
+        except Exception as e:      # noqa: BLE001  a diagnostic block: never fail the bench over it
+            pass_roof = {"error": repr(e)}
     traffic, traffic_src = None, None
-    if args.pmc and world == 1:
+    if world == 1 and env_world == 0 and not args.no_pmc:
+        # the driver's line is self-contained: two counter passes (rocprofv3 child processes of THIS run) over
+        # launches of the dominant kernel at this run's (B, N); the stored figure is only the fallback, and says why
         traffic, traffic_src = measure_traffic_pmc(B, N)
         if traffic is None:
             traffic_src = "in-run PMC measurement failed (" + traffic_src + "); falling back to the stored figure"
+    elif args.no_pmc:
+        traffic_src = "--no-pmc given"
+    elif world > 1 or env_world:
+        traffic_src = "not measured under a multi-process launch (counters are collected at N = 1)"
     try:
         if traffic is not None:
             raise StopIteration
@@ -744,7 +881,7 @@ def main():
         if B == pmc.get("B") and N == pmc.get("N"):
             traffic = pmc["traffic_bytes_per_launch"]
             traffic_src = ((traffic_src + "; " if traffic_src else "") +
-                           f"STORED rocprofv3 PMC figure (not measured in this run; pass --pmc to measure): "
+                           f"STORED rocprofv3 PMC figure (not measured in this run): "
                            f"profiles/pmc_trunk.json, taken at commit {pmc.get('commit', '?')}; 2*FETCH_SIZE + "
                            f"WRITE_SIZE, separate passes")
     except (Exception, StopIteration):
@@ -794,6 +931,9 @@ def main():
                 train_res["tflops_executed_frac_of_sustained_fp32"] = round(
                     train_res["tflops_executed"] / (world * sustained["f32"]), 4)
             res["train"] = train_res
+            if pass_roof is not None:
+                pass_roof["step_ms"] = train_res.get("ms_per_step")
+                res["roofline_train"] = pass_roof
             res["value_train"] = train_res["value"]
             res["value_train_is"] = "training-step leg (fwd + nll_loss + bwd + Adam, exact fp32), grasps/s, same batch"
         if c5 is not None:

@@ -288,7 +288,8 @@ int pngpd_bn2_finalize(const double *tot2, int B, int N, const float *b2, const 
                        float *chan2, double *stats2, void *stream);
 int pngpd_bn3_finalize(const double *tot3, int B, int N, const float *b3, const float *g3,
                        float momentum, float *rm, float *rv, long long *nbt, double *stats3, void *stream);
-/* pooled (B,1024) = [relu](g3*zhat + be3), idx (B,1024) arg-extremum point, zhat (B,1024) */
+/* pooled (B,1024) = [relu](g3*zhat + be3), idx (B,1024) arg-extremum point, zhat (B,1024).  parg == idx (in place) is
+ * allowed when S == 1 — the pool refinement's second call, which leaves idx unchanged.                              */
 int pngpd_pool_finalize(const float *pmax, const int *parg, int B, int S, const double *stats3, const float *g3,
                         const float *be3, float eps, int relu_last, float *pooled, int *idx, float *zhat,
                         void *stream);

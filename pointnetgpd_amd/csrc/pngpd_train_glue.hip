@@ -185,10 +185,12 @@ __global__ __launch_bounds__(NT) void bn3_finalize_kernel(
 }
 
 // pooled[b][c] = (relu?)(g3 * zhat + be3), zhat = sgn*(max_s pmax - mu3s)/sig3 ; idx = arg of the max
+// parg and idx carry no __restrict__: the pool refinement calls this in place (parg == idx, S == 1 — every thread reads
+// its own element before it rewrites the same value), which a restrict contract would make undefined behaviour
 __global__ __launch_bounds__(NT) void pool_finalize_kernel(
-    const float *__restrict__ pmax, const int *__restrict__ parg, int S, const double *__restrict__ stats,
+    const float *__restrict__ pmax, const int *parg, int S, const double *__restrict__ stats,
     const float *__restrict__ g3, const float *__restrict__ be3, double eps, int relu_last, int total,
-    float *__restrict__ pooled, int *__restrict__ idx, float *__restrict__ zhat) {
+    float *__restrict__ pooled, int *idx, float *__restrict__ zhat) {
     const int i = blockIdx.x * NT + threadIdx.x;
     if (i >= total) return;
     const int b = i >> 10, c = i & 1023;

@@ -234,7 +234,12 @@ def run(variant, argv=None):
     args = build_parser().parse_args(argv)
     args.cuda = args.cuda if torch.cuda.is_available else False      # sic: main_1v.py:35 never calls it
     os.makedirs(args.model_path, exist_ok=True)
-    rank, world, local_rank = ddp.init_from_env("nccl" if args.cuda else "gloo")
+    # Debug switch shared with bench.py (never set by a launcher): every rank on cuda:0 over gloo, so that the
+    # N-rank control flow of `torchrun --nproc-per-node 8 main_1v_mc.py ...` runs on a 1-GPU box (tests/test_gpu_ddp.py)
+    one_gpu_debug = os.environ.get("PNGPD_BENCH_DEBUG_ONE_GPU") == "1"
+    rank, world, local_rank = ddp.init_from_env("nccl" if (args.cuda and not one_gpu_debug) else "gloo")
+    if one_gpu_debug:
+        local_rank = 0
     if args.cuda:
         torch.cuda.manual_seed(1)
     if args.seed is None:

@@ -5,8 +5,10 @@ keys and seeded initialisation), same forward graph:
     conv1(C,20,5) -> pool1 -> conv2(20,50,5) -> pool2 -> view(-1,7200) -> relu(fc1) -> [dropout] -> fc2 -> log_softmax
 
 Dispatch: CUDA tensor in eval mode -> libpngpd (``pngpd_conv5_pool2`` x2 + ``pngpd_fc_fwd`` x2, no fallback);
-CPU tensors, and training mode (the comparator's training is not part of the hot path — DESIGN.md §6) -> the ATen
-composite the reference itself runs."""
+CPU tensors -> the ATen composite the reference itself runs.  A CUDA tensor in TRAINING mode raises, like every other
+CUDA path without a libpngpd kernel: the comparator's backward (``main_1v_gpd.py:105``) is not part of the hot path
+ and has no HIP kernels — training it on ATen / MIOpen is an explicit opt-in
+(``GPDClassifier.allow_aten_training = True``), never a silent dispatch."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -16,6 +18,8 @@ from .. import gpd_ops, ops
 
 class GPDClassifier(nn.Module):
     """Input: (batch_size, input_chann, 60, 60)"""
+
+    allow_aten_training = False      # opt-in: CUDA + train() runs the ATen / MIOpen composite (no libpngpd backward)
 
     def __init__(self, input_chann, dropout=False):
         super().__init__()
@@ -32,6 +36,11 @@ class GPDClassifier(nn.Module):
     def forward(self, x):
         if x.is_cuda and not self.training:
             return self._forward_hip(x)
+        if x.is_cuda and not self.allow_aten_training:
+            raise RuntimeError("GPDClassifier: libpngpd has no training kernels for the GPD comparator (gpd.py:5-31 under "
+                               "main_1v_gpd.py:105 is outside the hot path); a CUDA tensor in train() mode would run on "
+                               "ATen/MIOpen. Opt in with GPDClassifier.allow_aten_training = True, call .eval(), or "
+                               "train on the CPU.")
         x = self.pool1(self.conv1(x))
         x = self.pool2(self.conv2(x))
         x = x.view(-1, 7200)

@@ -93,6 +93,9 @@ def grad_group(params):
                            "(the fused backward writes the whole piece's gradients in place)")
     g = GradGroup([e[0] for e in entries], [weakref.ref(p) for p in params], [e[2] for e in entries], entries[0][1])
     _GROUPS[id(params[0])] = g
+    owner = entries[0][1]()
+    for i in g.idx:
+        owner._grouped[i] = 1     # these slices are OVERWRITTEN by a fused backward; all others accumulate via autograd
     return g
 
 
@@ -124,6 +127,7 @@ class FlatAdam(torch.optim.Optimizer):
         self._step = 0
         self._views = []
         self._written = bytearray(len(ps))    # per parameter: slice written in place by the fused backward this step
+        self._grouped = bytearray(len(ps))    # per parameter: owned by a fused piece (optim.GradGroup) — set on first use
         with torch.no_grad():
             for p, o in zip(ps, self.offsets):
                 n = p.numel()
@@ -147,27 +151,34 @@ class FlatAdam(torch.optim.Optimizer):
         return lo, hi - lo
 
     def zero_grad(self, set_to_none=True):
-        """The fused backward OVERWRITES every gradient slice, so nothing is cleared (and the views are never
-        dropped); with pass-by-pass / ATen sequencing autograd accumulates into the views, which then need zeros.
-        Slices the fused backward did NOT write in a step (a sub-module that took no part in it) are zeroed by
-        ``step()`` itself, and a slice written twice raises (``mark_written``): no stale or half-accumulated gradient
-        reaches the update."""
+        """The fused backward OVERWRITES the gradient slices of the pieces it owns (``optim.GradGroup``: the trunks and
+        FC stacks), so those are never cleared (and the views are never dropped).  Every other parameter — a plain
+        autograd parameter next to the fused pieces, e.g. a custom head on a ``PointNetfeat`` — receives its gradient by
+        autograd ACCUMULATION into the same view and is zeroed here; with pass-by-pass / ATen sequencing that is every
+        parameter (one fill of the whole buffer).  A slice written twice raises (``mark_written``)."""
         from . import train
         for p, gv in zip(self._params, self._views):
             if p.grad is not gv:
                 p.grad = gv
         self._written[:] = bytes(len(self._written))
         if train._use_fused():
-            return
+            if any(self._grouped):
+                for i, gv in enumerate(self._views):
+                    if not self._grouped[i]:
+                        gv.zero_()
+                return
+            # no fused piece has registered yet (first step, or a model without one): clear everything
         self.flat_g.zero_()
 
     def _settle_gradients(self):
         """Before the update: every parameter's gradient must be IN its slice.  A gradient autograd left elsewhere
-        (``.grad`` re-pointed or dropped by foreign code) is copied in / zeroed; in fused sequencing a slice nobody
-        wrote this step is zeroed (torch.optim.Adam would skip a ``None`` gradient; with zero gradient Adam's moments
-        still decay — the same update torch makes for a zero ``.grad``)."""
+        (``.grad`` re-pointed or dropped by foreign code) is copied in / zeroed.  Returns the indices of the parameters
+        to leave untouched this step: slices of a fused piece that took no part in this step's backward (an unused or
+        eval-mode sub-module) hold a STALE gradient — ``torch.optim.Adam`` skips a parameter whose ``.grad`` is None,
+        and so does this update (no momentum-only drift).  Plain autograd parameters always update."""
         from . import train
         fused = train._use_fused()
+        skip = []
         for i, (p, gv) in enumerate(zip(self._params, self._views)):
             g = p.grad
             if g is not gv:
@@ -176,9 +187,24 @@ class FlatAdam(torch.optim.Optimizer):
                 else:
                     gv.copy_(g)
                 p.grad = gv
-            elif fused and not self._written[i] and any(self._written):
-                gv.zero_()
+            elif fused and self._grouped[i] and not self._written[i] and any(self._written):
+                skip.append(i)
         self._written[:] = bytes(len(self._written))
+        return skip
+
+    def _update_ranges(self, skip):
+        """(offset, length) runs of the flat buffers to update = everything but the slices of ``skip``."""
+        if not skip:
+            return [(self.header, self.numel - self.header)]
+        runs, lo = [], self.header
+        for i in skip:
+            o = self.offsets[i]
+            if o > lo:
+                runs.append((lo, o - lo))
+            lo = o + (self._params[i].numel() + 63) // 64 * 64
+        if self.numel > lo:
+            runs.append((lo, self.numel - lo))
+        return runs
 
     # ---- update ----------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -195,19 +221,20 @@ class FlatAdam(torch.optim.Optimizer):
         stream = torch.cuda.current_stream(self.device).cuda_stream
         lr_dev = lr.data_ptr() if torch.is_tensor(lr) and lr.is_cuda else None
         lr_host = 0.0 if lr_dev else float(lr)
-        self._settle_gradients()
+        runs = self._update_ranges(self._settle_gradients())      # one run (one launch) unless a fused piece sat out
         self._step += 1
         with _lib.device_guard(self.device):
             if self.step_dev is not None:
                 _lib.check(lib.pngpd_adam_step_inc(self.step_dev.data_ptr(), stream), "adam_step_inc")
-            h = self.header * 4
-            _lib.check(lib.pngpd_adam_flat(self.flat_p.data_ptr() + h, self.flat_g.data_ptr() + h,
-                                           self.flat_m.data_ptr() + h, self.flat_v.data_ptr() + h,
-                                           self.numel - self.header, lr_host, lr_dev, float(b1), float(b2),
-                                           float(eps), float(self._step),
-                                           self.step_dev.data_ptr() if self.step_dev is not None else None,
-                                           float(grad_scale), grad_div.data_ptr() if grad_div is not None else None,
-                                           stream), "adam_flat")
+            for lo, n in runs:
+                h = lo * 4
+                _lib.check(lib.pngpd_adam_flat(self.flat_p.data_ptr() + h, self.flat_g.data_ptr() + h,
+                                               self.flat_m.data_ptr() + h, self.flat_v.data_ptr() + h,
+                                               n, lr_host, lr_dev, float(b1), float(b2),
+                                               float(eps), float(self._step),
+                                               self.step_dev.data_ptr() if self.step_dev is not None else None,
+                                               float(grad_scale), grad_div.data_ptr() if grad_div is not None else None,
+                                               stream), "adam_flat")
         # the kernel rewrote every parameter behind autograd's back: version-keyed caches (the eval-mode fold cache)
         # must see it
         torch.autograd.graph.increment_version(self._params)

@@ -211,24 +211,60 @@ def test_sharded_scene_scoring_two_ranks_hip(tmp_path, cuda_device):
     assert (sc[:-1] >= sc[1:]).all()
 
 
-def test_bench_self_spawns_two_ranks(cuda_device):
-    """``python bench.py --gpus 2`` from a plain shell (no torchrun): bench.py launches its own ranks.  On this 1-GPU
-    box the debug switch maps both ranks to cuda:0 over gloo; the JSON line must still report 2 ranks and carry the
-    inference and training legs."""
+@pytest.mark.parametrize("gpus", [2, 8])
+def test_bench_self_spawns_ranks(gpus, cuda_device):
+    """``python bench.py --gpus N`` from a plain shell (no torchrun): bench.py launches its own ranks.  On this 1-GPU
+    box the debug switch maps every rank to cuda:0 over gloo; the JSON line must still report N ranks and carry the
+    inference, training (weak + strong) and config-5 legs with the aggregation a real N-GPU run uses — the first real
+    8-GPU run must not die on a shape or an aggregation bug."""
+    import time
     env = dict(os.environ, PNGPD_BENCH_DEBUG_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+    t0 = time.perf_counter()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1",
                           "--batch", "64", "--num-points", "256", "--no-cpu-baseline", "--no-fast", "--min-seconds", "0"],
                          capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
+    assert time.perf_counter() - t0 < 300
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
     res = json.loads(lines[0])
-    assert res["n_gpus"] == 2 and res["collective_ranks"] == 2
+    assert res["n_gpus"] == gpus and res["collective_ranks"] == gpus
     assert res["config"]["batch_per_gpu"] == 64 and res["value"] > 0
     assert res["train"]["weak"]["value"] > 0 and res["train"]["strong"]["value"] > 0
+    assert res["train"]["weak"]["global_batch"] == 64 * gpus and res["train"]["strong"]["global_batch"] == 64
     assert "all-reduce" in res["train"]["step"]
     # BASELINE configs[4]: the 100k-candidate scene, candidates sharded over the ranks (strong scaling)
     c5 = res["config5"]
-    assert c5["candidates"] == 100000 and c5["candidates_per_gpu"] == 50000 and c5["scaling"] == "strong"
+    assert c5["candidates"] == 100000 and c5["candidates_per_gpu"] == 100000 // gpus and c5["scaling"] == "strong"
     assert c5["value"] > 0 and 0.0 < c5["valid_frac"] <= 1.0
+    assert res["roofline"]["traffic_source"].startswith("not measured under a multi-process launch") or \
+        "STORED" in res["roofline"]["traffic_source"]
+
+
+def test_cli_eight_ranks_configs2_command_on_one_gpu(tmp_path, cuda_device):
+    """BASELINE configs[2]'s command line: ``torchrun --nproc-per-node 8 main_1v_mc.py --batch-size 4096
+    --cuda --precision bf16x3`` for one epoch on synthetic clouds — 8 ranks x 512, a ragged last batch (188 per rank),
+    DistributedSampler, the flat-buffer gradient all-reduce in two buckets, eval with rank 0's statistics, rank 0's
+    checkpoint — every rank on cuda:0 over gloo (debug switch), so that the first real 8-GPU launch is boring."""
+    import time
+    env = dict(os.environ, PNGPD_BENCH_DEBUG_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "pointnetgpd_amd", "main_1v_mc.py"), "--mode", "train",
+           "--epoch", "1", "--batch-size", "4096", "--cuda", "--precision", "bf16x3", "--synthetic", str(8 * 700),
+           "--num-workers", "0", "--model-path", str(tmp_path / "m"), "--log-dir", str(tmp_path / "l"), "--seed", "1",
+           "--tag", "c2"]
+    t0 = time.perf_counter()
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
+    assert time.perf_counter() - t0 < 300
+    assert "Train done" in out.stdout and "Test done" in out.stdout and "Save model" in out.stdout
+    assert out.stdout.count("Train done") == 1                                   # rank 0 alone reports
+    ckpt = tmp_path / "m" / "c2_0.model"
+    assert ckpt.exists()
+    from pointnetgpd_amd import install_reference_aliases
+    install_reference_aliases()
+    m = torch.load(ckpt, map_location="cpu", weights_only=False)
+    assert m.fc3.out_features == 3 and int(m.feat.bn3.num_batches_tracked) == 2   # 512 + 188 per rank: two steps
+    assert all(torch.isfinite(p).all() for p in m.parameters())

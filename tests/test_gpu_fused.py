@@ -172,10 +172,11 @@ def test_flat_adam_checkpoint_round_trip_then_foreign_optimizer(cuda_device, tmp
 
 
 def test_flat_adam_partial_backward_and_double_write(cuda_device):
-    """the fused backward overwrites gradient slices.  (i) A slice written twice before step()
-    raises instead of silently keeping the last contribution; (ii) parameters that took no part in a backward get a
-    ZERO gradient in step(), not the previous step's; (iii) ``p.grad`` dropped by foreign code (``set_to_none``) falls
-    back to autograd and step() picks the gradient up."""
+    """The fused backward overwrites gradient slices.  (i) A slice written twice before step() raises instead of
+    silently keeping the last contribution; (ii) a fused piece that took no part in a backward (its slices hold the
+    PREVIOUS step's gradient) is left untouched by step() — parameters, moments — exactly as ``torch.optim.Adam`` skips
+    a parameter whose ``.grad`` is None; (iii) ``p.grad`` dropped by foreign code (``set_to_none``) falls back to
+    autograd and step() picks the gradient up."""
     from pointnetgpd_amd import optim
     from pointnetgpd_amd.optim import FlatAdam
     B, N, k = 8, 128, 2
@@ -187,19 +188,22 @@ def test_flat_adam_partial_backward_and_double_write(cuda_device):
     with pytest.raises(RuntimeError, match="written twice"):
         F.nll_loss(m(x)[0], y).backward()
     opt.zero_grad()
-    # (ii) only the feature extractor takes part: the head's slices hold the previous gradients and must be zeroed
+    # (ii) only the feature extractor takes part: the head is skipped, the feature extractor moves
     F.nll_loss(m(x)[0], y).backward(); opt.step()
-    head_before = m.fc3.weight.detach().clone()
+    head_before = {n: p.detach().clone() for n, p in m.named_parameters() if not n.startswith("feat.")}
+    mom_before = opt.state[m.fc3.weight]["exp_avg"].clone()
+    feat_before = m.feat.conv3.weight.detach().clone()
     assert m.fc3.weight.grad.abs().max().item() > 0
-    opt2_state = opt.state[m.fc3.weight]["exp_avg"].clone()
     opt.zero_grad()
     feat, _ = m.feat(x)
     feat.square().mean().backward()
     opt.step()
-    assert m.fc3.weight.grad.abs().max().item() == 0.0
-    # zero gradient: the first moment only decays
-    assert torch.allclose(opt.state[m.fc3.weight]["exp_avg"], 0.9 * opt2_state, rtol=1e-6, atol=0)
-    assert m.fc3.weight.shape == head_before.shape
+    for n, p in m.named_parameters():
+        if not n.startswith("feat."):
+            assert torch.equal(p.detach(), head_before[n]), n              # no momentum-only drift
+    assert torch.equal(opt.state[m.fc3.weight]["exp_avg"], mom_before)
+    assert (m.feat.conv3.weight.detach() - feat_before).abs().max().item() > 0
+    assert (m.feat.stn.fc3.weight.grad.abs().max().item()) > 0
     # (iii) gradients dropped by the module's own zero_grad: autograd path, then adopted by step()
     m.zero_grad(set_to_none=True)
     assert all(optim.grad_view(p) is None for p in m.parameters())
@@ -240,3 +244,44 @@ def test_struct_sizes_match_header(cuda_device):
     lib.pngpd_struct_bytes.restype = ctypes.c_size_t
     assert lib.pngpd_struct_bytes(0) == ctypes.sizeof(_lib.TrunkTrainArgs)
     assert lib.pngpd_struct_bytes(1) == ctypes.sizeof(_lib.HeadTrainArgs)
+
+
+def test_flat_adam_with_a_plain_autograd_parameter_next_to_fused_pieces(cuda_device):
+    """a parameter FlatAdam owns but no fused piece writes — a custom head on a PointNetfeat —
+    receives its gradient by autograd accumulation into its flat view.  It must train exactly like under
+    torch.optim.Adam: neither wiped before the update nor summed over steps."""
+    import copy
+    from pointnetgpd_amd.model.pointnet import PointNetfeat
+    from pointnetgpd_amd.optim import FlatAdam
+    B, N = 8, 128
+    torch.manual_seed(3)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.feat = PointNetfeat(num_points=N, input_chann=3, global_feat=True)
+            self.out = torch.nn.Linear(1024, 4)
+
+        def forward(self, x):
+            g, _ = self.feat(x)
+            return self.out(g)
+
+    a = Net().to(cuda_device).train()
+    b = copy.deepcopy(a)
+    oa, ob = FlatAdam(a.parameters(), lr=0.005), torch.optim.Adam(b.parameters(), lr=0.005, foreach=False, fused=False)
+    w0 = a.out.weight.detach().clone()
+    for i in range(4):
+        x = synth_cloud(B, N, 720 + i, "box").to(cuda_device)
+        t = torch.randn(B, 4, generator=torch.Generator().manual_seed(i)).to(cuda_device)
+        for m, o in ((a, oa), (b, ob)):
+            o.zero_grad()
+            (m(x) - t).square().mean().backward()
+            if i == 0:
+                assert m.out.weight.grad.abs().max().item() > 0
+            o.step()
+        # same gradient on both sides this step (no stale sum, no wipe): Adam's first steps are sign-like, so compare
+        # the parameters tightly
+        assert torch.allclose(a.out.weight, b.out.weight, atol=2e-5, rtol=0), i
+        assert torch.allclose(a.out.bias, b.out.bias, atol=2e-5, rtol=0), i
+    assert (a.out.weight.detach() - w0).abs().max().item() > 1e-3            # it trained
+    assert torch.allclose(a.feat.conv1.weight, b.feat.conv1.weight, atol=5e-4, rtol=0)

@@ -105,3 +105,24 @@ def test_gpd_classifier_forward(chann, cuda_device):
         got = m(xb.to(cuda_device)).cpu()
     np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=2e-5, rtol=0)
     assert (got.argmax(1) == ref.argmax(1)).all()
+
+
+def test_gpd_classifier_cuda_training_is_explicit(cuda_device):
+    """A CUDA tensor in train() mode has no libpngpd kernel (the comparator's backward is outside the hot path): it
+    raises like every other CUDA path without one, instead of silently dispatching to ATen / MIOpen; the opt-in runs
+    the reference's own composite (gpd.py:5-31 under main_1v_gpd.py:105)."""
+    from pointnetgpd_amd.model.gpd import GPDClassifier
+    torch.manual_seed(3)
+    m = GPDClassifier(3).to(cuda_device).train()
+    x = torch.rand(4, 3, 60, 60, device=cuda_device)
+    with pytest.raises(RuntimeError, match="allow_aten_training"):
+        m(x)
+    try:
+        GPDClassifier.allow_aten_training = True
+        out = m(x)
+        out.sum().backward()
+        assert out.shape == (4, 2) and m.conv1.weight.grad is not None
+    finally:
+        GPDClassifier.allow_aten_training = False
+    with torch.no_grad():
+        assert torch.allclose(m.eval()(x), out.detach(), atol=1e-4)       # eval: the HIP path, same numbers
