@@ -210,6 +210,28 @@ def hand_box_counts(cloud, poses, boxes, index=None, valid_units=None, per_unit=
     return counts
 
 
+def sweep_select(index, poses, ab, L, R, D, boxes, prm, tol=1e-9, want_masks=False):
+    """The lateral sweep + selection of all (sample point, rotation) units in one launch
+    (``pngpd_gpg_sweep_select``): index = the scene's ``CloudIndex``; poses (L*R*D,12), ab (L*R,6) from
+    ``pngpd_gpg_enumerate``; boxes (4,6); prm the sampler's parameter block.
+    -> flag, dsel, list (L*R) int32, total (1) int32 [, masks (L*R,2) int32: opening / collision bits per offset] —
+    identical to ``hand_box_counts(..., index=index)`` + ``pngpd_gpg_select``."""
+    lib = _lib.load()
+    cap = L * R
+    dev = poses.device
+    ibuf = torch.empty(3 * cap + 1, device=dev, dtype=torch.int32)
+    flag, dsel, plist, total = ibuf[:cap], ibuf[cap:2 * cap], ibuf[2 * cap:3 * cap], ibuf[3 * cap:]
+    masks = torch.empty(cap, 2, device=dev, dtype=torch.int32) if want_masks else None
+    c = index.cloud
+    with _lib.device_guard(dev):
+        _lib.check(lib.pngpd_gpg_sweep_select(_p(c), int(c.dtype == torch.float64), index.P, _p(index.spheres), index.C,
+                                              _p(poses), _p(ab), int(L), int(R), int(D), _p(boxes), _p(prm), float(tol),
+                                              _p(flag), _p(dsel), _p(plist), _p(total),
+                                              _p(masks) if masks is not None else None, _stream(c)),
+                   "gpg_sweep_select")
+    return (flag, dsel, plist, total, masks) if want_masks else (flag, dsel, plist, total)
+
+
 # ------------------------------------------------------------------------------------------------
 # the sampler
 # ------------------------------------------------------------------------------------------------
@@ -222,16 +244,20 @@ class GpgGraspSamplerPcl:
     init_bite (default: robotiq_85).  ``config`` is accepted for signature compatibility and unused, as in the
     Pcl sampler."""
 
-    def __init__(self, gripper=None, config=None, device=None, use_index=True, batch_samples=2048):
+    def __init__(self, gripper=None, config=None, device=None, use_index=True, batch_samples=2048, fused_sweep=True):
         # sphere-culled collision kernel (identical counts).  False = brute force (debugging): it cannot skip the unused
         # tail of the capacity-sized push-in buffer and is slower even on 3,000-point clouds (3.4 vs 2.6 ms per scene).
         self.use_index = bool(use_index)
+        # lateral sweep + selection per (sample point, rotation) in one launch (pngpd_gpg_sweep_select; needs the index).
+        # False = one wave per pose (pngpd_hand_box_counts_indexed) + pngpd_gpg_select: same flag / dsel, ~5x the work.
+        self.fused_sweep = bool(fused_sweep) and self.use_index
         self.batch_samples = int(batch_samples)   # sample points per device round (399 poses each; bounds host memory)
         self.gripper = gripper if gripper is not None else ROBOTIQ_85
         self.config = config
         self.device = torch.device(device) if device is not None else None
         self.last_stats = {}
         self._const_cache = {}
+        self.profile = None                       # set to {} to collect per-stage times (synchronising; diagnostics only)
 
     # -- device work for one batch of draws --------------------------------------------------
     def _constants(self, g, dev):
@@ -243,6 +269,18 @@ class GpgGraspSamplerPcl:
             prm, R, D, S = self._params(g)
             c = self._const_cache[key] = (torch.from_numpy(hand_boxes(g)).to(dev), prm, R, D, S)
         return c
+
+    def _tick(self, name, dev):
+        """Stage timing for tools/bench_gpg_scale.py: with ``self.profile`` a dict, every stage boundary synchronises and
+        adds the elapsed host time to its entry (None = start a batch).  Off (the default): no-op."""
+        if self.profile is None:
+            return
+        import time
+        torch.cuda.synchronize(dev)
+        now = time.perf_counter()
+        if name is not None:
+            self.profile[name] = self.profile.get(name, 0.0) + (now - self._t_last)
+        self._t_last = now
 
     def _pinned(self, n):
         """A pinned host staging buffer of >= n doubles.  Page-locking costs milliseconds, so the buffer is shared by all
@@ -278,6 +316,8 @@ class GpgGraspSamplerPcl:
         while the host waits for the K moment matrices and computes the local frames."""
         dev = cloud_d.device
         K = sel_pts.shape[0]
+        tick = self._tick
+        tick(None, dev)
         fw, hd = g["finger_width"], g["hand_depth"]
         r_ball = max(g["hand_outer_diameter"] - fw, hd, g["hand_height"] / 2.0)                  # :1464
         boxes_d, prm, R, D, S = self._constants(g, dev)
@@ -290,6 +330,7 @@ class GpgGraspSamplerPcl:
             scene["index"] = CloudIndex(cloud_d)          # ~0.4 ms of device work, overlapped with the host's eig below
         index = scene.get("index")
         ev.synchronize()
+        tick("moments+download", dev)
         M = M_h.numpy().reshape(K, 3, 3).copy()
         m_zero = M.sum((1, 2)) == 0                                                             # :1486
         counts = np.zeros(K, dtype=np.int64)
@@ -310,6 +351,7 @@ class GpgGraspSamplerPcl:
         minor = np.where(flip[:, None], -minor, minor)
         L = live.size
         up = np.concatenate([np.concatenate([minor, normal, major, sel_pts[live]], 1).reshape(-1), prm])
+        tick("host eig+frames", dev)
         up_d = torch.from_numpy(up).to(dev)                                                     # upload: frames + constants
         frames_d, prm_d = up_d[:L * 12], up_d[L * 12:]
         cap = L * R
@@ -318,15 +360,21 @@ class GpgGraspSamplerPcl:
         poses = torch.empty(cap * D, 12, **f64)
         ab = torch.empty(cap, 6, **f64)
         _call("pngpd_gpg_enumerate", up_d, frames_d, L, R, D, prm_d, poses, ab)
-        cnt = hand_box_counts(cloud_d, poses, boxes_d, index=index)                             # (L*R*D,4)
-        ibuf = torch.empty(3 * cap + 1, **i32)
-        flag, dsel, plist, total = ibuf[:cap], ibuf[cap:2 * cap], ibuf[2 * cap:3 * cap], ibuf[3 * cap:]
-        _call("pngpd_gpg_select", up_d, cnt, poses, ab, L, R, D, prm_d, flag, dsel, plist, total)
+        tick("upload+enumerate", dev)
+        if self.fused_sweep and index is not None:
+            flag, dsel, plist, total = sweep_select(index, poses, ab, L, R, D, boxes_d, prm_d)
+        else:
+            cnt = hand_box_counts(cloud_d, poses, boxes_d, index=index)                         # (L*R*D,4)
+            ibuf = torch.empty(3 * cap + 1, **i32)
+            flag, dsel, plist, total = ibuf[:cap], ibuf[cap:2 * cap], ibuf[2 * cap:3 * cap], ibuf[3 * cap:]
+            _call("pngpd_gpg_select", up_d, cnt, poses, ab, L, R, D, prm_d, flag, dsel, plist, total)
+        tick("sweep+select", dev)
         poses2 = torch.empty(cap * S * 2, 12, **f64)
         bm = torch.empty(2 * cap * S, 3, **f64)
         back, mod = bm[:cap * S], bm[cap * S:]
         _call("pngpd_gpg_pushin", up_d, plist, total, dsel, poses, ab, frames_d, L, R, D, S, prm_d, poses2, back, mod)
         cnt2 = hand_box_counts(cloud_d, poses2, boxes_d, index=index, valid_units=total, per_unit=2 * S)
+        tick("pushin+sweep2", dev)
         jbuf = torch.empty(3 * cap + 1, **i32)
         found, sfirst, olist, ototal = jbuf[:cap], jbuf[cap:2 * cap], jbuf[2 * cap:3 * cap], jbuf[3 * cap:]
         nres = 1 + L + cap * 15 + 1
@@ -337,6 +385,7 @@ class GpgGraspSamplerPcl:
         host_t = self._pinned(nres)
         host_t.copy_(out, non_blocking=True)                                                    # download 2: packed result
         torch.cuda.current_stream(dev).synchronize()
+        tick("finish+download", dev)
         host = host_t.numpy()
         self.last_stats["potential"] = self.last_stats.get("potential", 0) + int(host[-1])
         n = int(host[0])

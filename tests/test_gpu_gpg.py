@@ -194,3 +194,73 @@ def test_sampler_same_result_with_and_without_index(cuda_device):
     a = gpg.GpgGraspSamplerPcl(device=cuda_device, use_index=True).sample_grasps(pts, pfs, nrm, 1000, 40, sample_indices=draws, as_array=True)
     b = gpg.GpgGraspSamplerPcl(device=cuda_device, use_index=False).sample_grasps(pts, pfs, nrm, 1000, 40, sample_indices=draws, as_array=True)
     assert len(a) > 0 and np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("dtype,P,kind,L", [(np.float32, 5000, "box", 40), (np.float64, 3000, "cylinder", 24),
+                                            (np.float32, 20000, "ellipsoid", 64), (np.float64, 130, "box", 5)])
+def test_fused_sweep_select_equals_counts_then_select(dtype, P, kind, L, cuda_device):
+    """pngpd_gpg_sweep_select (one wave per (sample point, rotation): closed-form offset intervals + exact re-evaluation
+    of every near-boundary point) against the exact per-pose counts: the opening / collision bit masks of every unit are
+    the ones derived from pngpd_hand_box_counts_indexed, and flag / dsel / list / total equal pngpd_gpg_select's — with
+    the default margin, with the exact path forced everywhere (tol = 1e30), and with a margin so wide that a large
+    share of the points takes the exact path (tol = 0.2 offsets)."""
+    from pointnetgpd_amd import gpg
+    from pointnetgpd_amd.ops import _call
+    pts, nrm = go.synth_scene(kind, P, 9)
+    pts = pts.astype(dtype)
+    g = gpg._gripper_dict(gpg.ROBOTIQ_85)
+    s = gpg.GpgGraspSamplerPcl(device=cuda_device)
+    boxes_d, prm, R, D, S = s._constants(g, cuda_device)
+    rng = np.random.default_rng(P + L)
+    # local frames as the sampler builds them: orthonormal (minor, normal, major) at sample points of the cloud ...
+    q, _ = np.linalg.qr(rng.normal(size=(L, 3, 3)))
+    minor, normal = q[:, :, 0], q[:, :, 1]
+    major = np.cross(minor, normal)
+    sel = pts[rng.integers(0, P, L)].astype(np.float64)
+    if L > 8:       # ... and a few skewed ones: the closed form must not assume an orthogonal frame
+        minor[:4] = minor[:4] + 0.3 * major[:4]
+        minor[:4] /= np.linalg.norm(minor[:4], axis=1, keepdims=True)
+    frames = np.concatenate([minor, normal, major, sel], 1)
+    up = torch.from_numpy(np.concatenate([frames.reshape(-1), prm])).to(cuda_device)
+    frames_d, prm_d = up[:L * 12], up[L * 12:]
+    cap = L * R
+    poses = torch.empty(cap * D, 12, device=cuda_device, dtype=torch.float64)
+    ab = torch.empty(cap, 6, device=cuda_device, dtype=torch.float64)
+    _call("pngpd_gpg_enumerate", up, frames_d, L, R, D, prm_d, poses, ab)
+    cloud = torch.from_numpy(pts).to(cuda_device)
+    index = gpg.CloudIndex(cloud)
+    cnt = gpg.hand_box_counts(cloud, poses, boxes_d, index=index)                    # exact counts (cap*D,4)
+    ibuf = torch.empty(3 * cap + 1, device=cuda_device, dtype=torch.int32)
+    flag, dsel, plist, total = ibuf[:cap], ibuf[cap:2 * cap], ibuf[2 * cap:3 * cap], ibuf[3 * cap:]
+    _call("pngpd_gpg_select", up, cnt, poses, ab, L, R, D, prm_d, flag, dsel, plist, total)
+    c = cnt.view(cap, D, 4).cpu().numpy()
+    bit = (1 << np.arange(D, dtype=np.int64))
+    open_ref = ((c[:, :, 0] > 0) * bit).sum(1)
+    coll_ref = (((c[:, :, 1] > 0) | (c[:, :, 2] > 0) | (c[:, :, 3] > 0)) * bit).sum(1)
+    assert (open_ref > 0).any() and (coll_ref > 0).any() and int(total.item()) > 0
+    for tol in (1e-9, 1e30, 0.2):
+        f2, d2, l2, t2, masks = gpg.sweep_select(index, poses, ab, L, R, D, boxes_d, prm_d, tol=tol, want_masks=True)
+        m = masks.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+        assert np.array_equal(m[:, 0], open_ref), tol
+        assert np.array_equal(m[:, 1], coll_ref), tol
+        assert torch.equal(f2, flag) and int(t2.item()) == int(total.item()), tol
+        n = int(total.item())
+        assert torch.equal(l2[:n], plist[:n])
+        sel_units = plist[:n].long()
+        assert torch.equal(d2[sel_units], dsel[sel_units])           # dsel matters where a potential grasp exists
+        ok = (open_ref & ~coll_ref) != 0
+        assert torch.equal(d2.cpu()[torch.from_numpy(ok)], dsel.cpu()[torch.from_numpy(ok)])
+        # the production call (no masks): units whose 30-degree rule fails at every offset leave before the sweep
+        f3, d3, l3, t3 = gpg.sweep_select(index, poses, ab, L, R, D, boxes_d, prm_d, tol=tol)
+        assert torch.equal(f3, flag) and int(t3.item()) == n and torch.equal(l3[:n], plist[:n])
+        assert torch.equal(d3[sel_units], dsel[sel_units])
+
+
+def test_sampler_same_result_fused_and_per_pose_sweep(cuda_device):
+    from pointnetgpd_amd import gpg
+    pts, nrm = go.synth_scene("cylinder", 12000, 15)
+    pfs = pts[pts[:, 2] > 0.010]
+    draws = np.random.default_rng(5).integers(0, len(pfs), 300)
+    a = gpg.GpgGraspSamplerPcl(device=cuda_device, fused_sweep=True).sample_grasps(pts, pfs, nrm, 10 ** 6, 300, sample_indices=draws, as_array=True)
+    b = gpg.GpgGraspSamplerPcl(device=cuda_device, fused_sweep=False).sample_grasps(pts, pfs, nrm, 10 ** 6, 300, sample_indices=draws, as_array=True)
+    assert len(a) > 20 and np.array_equal(a, b)
