@@ -540,11 +540,13 @@ int pngpd_gpg_select(const int *counts, const double *poses, const double *ab, i
  * forces the exact path everywhere) of changing is re-evaluated with the exact per-pose arithmetic of
  * pngpd_hand_box_counts, so flag / dsel / list / total equal pngpd_hand_box_counts_indexed + pngpd_gpg_select always.
  * cloud_sorted / spheres: gpg.CloudIndex (as for pngpd_hand_box_counts_indexed); boxes (4,6): opening, left, right,
- * bottom.  masks (L*R,2) uint32 or NULL: bit d of [0] = the opening holds a point at offset d, of [1] = a collision. */
+ * bottom.  masks (L*R,2) uint32 or NULL: bit d of [0] = the opening holds a point at offset d, of [1] = a collision.
+ * stats (4) uint64 or NULL, diagnostics, ADDED to: units swept, chunks past the broad phase, chunks evaluated, points
+ * sent to the exact path.                                                                                          */
 int pngpd_gpg_sweep_select(const void *cloud_sorted, int cloud_is_f64, int P, const double *spheres, int C,
                            const double *poses, const double *ab, int L, int R, int D, const double *boxes,
                            const double *prm, double tol, int *flag, int *dsel, int *list, int *total,
-                           unsigned *masks, void *stream);
+                           unsigned *masks, unsigned long long *stats, void *stream);
 /* :1575-1612  push-in poses and their backed-off, table-corrected twins: poses2 (L*R,S,2,12), back / mod (L*R,S,3) */
 int pngpd_gpg_pushin(const int *list, const int *total, const int *dsel, const double *poses, const double *ab,
                      const double *frames, int L, int R, int D, int S, const double *prm, double *poses2, double *back,

@@ -666,17 +666,17 @@ int pngpd_gpg_finish(const int *counts2, const int *list, const int *total, cons
 int pngpd_gpg_sweep_select(const void *cloud_sorted, int cloud_is_f64, int P, const double *spheres, int C,
                            const double *poses, const double *ab, int L, int R, int D, const double *boxes,
                            const double *prm, double tol, int *flag, int *dsel, int *list, int *total,
-                           unsigned *masks, void *stream) {
+                           unsigned *masks, unsigned long long *stats, void *stream) {
     if (!cloud_sorted || !spheres || !poses || !ab || !boxes || !prm || !flag || !dsel || !list || !total || P <= 0 ||
         L <= 0 || R <= 0 || D <= 0 || D > 32 || C != (P + 63) / 64 || !(tol >= 0.0))
         return PNGPD_ERR_INVALID_ARG;
     const int LR = L * R;
     if (cloud_is_f64)
         hipLaunchKernelGGL(gpg_sweep_select_kernel<true>, dim3((LR + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                           cloud_sorted, P, spheres, C, poses, ab, LR, D, boxes, prm, tol, flag, dsel, masks);
+                           cloud_sorted, P, spheres, C, poses, ab, LR, D, boxes, prm, tol, flag, dsel, masks, stats);
     else
         hipLaunchKernelGGL(gpg_sweep_select_kernel<false>, dim3((LR + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                           cloud_sorted, P, spheres, C, poses, ab, LR, D, boxes, prm, tol, flag, dsel, masks);
+                           cloud_sorted, P, spheres, C, poses, ab, LR, D, boxes, prm, tol, flag, dsel, masks, stats);
     int st = pngpd_launch_status();
     if (st != PNGPD_OK) return st;
     hipLaunchKernelGGL(gpg_flag_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, flag, LR, list, total);

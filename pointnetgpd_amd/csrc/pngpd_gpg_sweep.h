@@ -18,6 +18,10 @@
 //     gate coordinate within a margin of a face) the point is "uncertain" and is re-evaluated for all D poses with the
 //     exact per-pose arithmetic of hand_box_counts_kernel (lane = offset) — so the masks equal the ones derived from
 //     the exact counts, always (tests compare them; `tol` = 1e30 forces the exact path everywhere);
+//   * saturation: a chunk's sphere bounds the offsets its points can reach per box (a conservative bit mask); once the
+//     masks accumulated so far already hold every bit a chunk could add — or, for the opening, the bit is dead because
+//     that offset already collides — the chunk is skipped without loading a point.  On a dense cloud the masks
+//     saturate after a few dozen chunks; skipped chunks can only set bits that are set, so the result is unchanged;
 //   * the select step (:1565-1573, gpg_select_kernel) is fused: flag / dsel leave directly — and a unit whose 30-degree
 //     rule (:1570-1573; a function of the approach axis and the pose centre only) fails at EVERY offset can never yield
 //     a potential grasp: it leaves before touching the cloud (the reference sweeps first and tests afterwards; the
@@ -61,7 +65,7 @@ __global__ __launch_bounds__(256) void gpg_sweep_select_kernel(
     const void *__restrict__ cloud, int P, const double *__restrict__ spheres, int C,
     const double *__restrict__ poses, const double *__restrict__ ab, int LR, int D,
     const double *__restrict__ boxes, const double *__restrict__ prm, double tol, int *__restrict__ flag,
-    int *__restrict__ dsel, unsigned *__restrict__ masks) {
+    int *__restrict__ dsel, unsigned *__restrict__ masks, unsigned long long *__restrict__ stats) {
     __shared__ double bx[24];                               // the four boxes: uniform reads (LDS broadcast), no registers
     if (threadIdx.x < 24) bx[threadIdx.x] = boxes[threadIdx.x];
     __syncthreads();
@@ -129,14 +133,14 @@ __global__ __launch_bounds__(256) void gpg_sweep_select_kernel(
         swlo[a] = fmin(0.0, sweep) - 1e-9; swhi[a] = fmax(0.0, sweep) + 1e-9;
         Elo[a] = lo + swlo[a]; Ehi[a] = hi + swhi[a];
     }
-    unsigned acc_open = 0u, acc_coll = 0u;                   // per lane: closed-form masks
-    unsigned ex_open = 0u, ex_coll = 0u;                     // wave-uniform: masks from the exact path
+    unsigned known_open = 0u, known_coll = 0u;               // wave-uniform: the masks accumulated so far
+    unsigned st_pass = 0u, st_proc = 0u, st_exact = 0u;      // diagnostics (stats != NULL): chunks passed / evaluated, exact trips
     const unsigned full = D >= 32 ? 0xFFFFFFFFu : ((1u << D) - 1u);
 
     for (int cbase = 0; cbase < C; cbase += 64) {
         const int c = cbase + lane;
         bool pass = false;
-        unsigned bmask = 0u;
+        unsigned bmask = 0u, poss_open = 0u, poss_coll = 0u;
         if (c < C) {
             const double4 sp = *(const double4 *)(spheres + (size_t)c * 4);
             const double dx = sp.x - f0[0], dy = sp.y - f0[1], dz = sp.z - f0[2];
@@ -155,27 +159,55 @@ __global__ __launch_bounds__(256) void gpg_sweep_select_kernel(
                 for (int b = 0; b < 4; ++b) {
                     const bool hit = gp[0] > bx[b * 6] && gm[0] < bx[b * 6 + 1] && gp[1] > bx[b * 6 + 2] &&
                                      gm[1] < bx[b * 6 + 3] && gp[2] > bx[b * 6 + 4] && gm[2] < bx[b * 6 + 5];
-                    bmask |= hit ? (1u << b) : 0u;
+                    if (!hit) continue;
+                    bmask |= 1u << b;
+                    // offsets at which a point of this sphere can be inside box b (conservative): for every interval
+                    // axis,  tau w in (g - r - hi, g + r - lo)
+                    double tl = -1.0, th = (double)D;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        if (gate[a]) continue;
+                        const double t1 = (g[a] - r - bx[b * 6 + 2 * a + 1]) * inv_w[a];
+                        const double t2 = (g[a] + r - bx[b * 6 + 2 * a]) * inv_w[a];
+                        tl = fmax(tl, fmin(t1, t2) - err[a] - 1e-6);
+                        th = fmin(th, fmax(t1, t2) + err[a] + 1e-6);
+                    }
+                    int dlo = (int)ceil(tl), dhi = (int)floor(th);      // the integers inside the (already padded) range
+                    dlo = dlo < 0 ? 0 : dlo; dhi = dhi > D - 1 ? D - 1 : dhi;
+                    const unsigned pm = dhi < dlo ? 0u : (((dhi >= 31 ? 0xFFFFFFFFu : ((2u << dhi) - 1u)) & ~((1u << dlo) - 1u)) & full);
+                    if (b == 0) poss_open |= pm; else poss_coll |= pm;
                 }
                 pass = bmask != 0u;
             }
         }
         unsigned long long work = __ballot(pass);
-        // the chunk loop is a chain of dependent loads: the NEXT surviving chunk's points are requested before the
-        // current ones are evaluated
+        st_pass += (unsigned)__popcll(work);
+        // Walk the surviving chunks; a chunk is evaluated only if it can still add a bit (see "saturation" above).  The
+        // chunk loop is a chain of dependent loads, so the next chunk's points are requested before the current ones are
+        // evaluated (with the masks known at that moment: a prefetched chunk may turn out to be unnecessary).
+        auto next_needed = [&](unsigned long long &wk) {
+            while (wk) {
+                const int b = __ffsll((long long)wk) - 1;
+                const unsigned po = (unsigned)__builtin_amdgcn_readlane((int)poss_open, b);
+                const unsigned pc = (unsigned)__builtin_amdgcn_readlane((int)poss_coll, b);
+                const unsigned dead = masks ? 0u : known_coll;      // (the debug masks want every opening bit)
+                if (slow || (po & ~known_open & ~dead) || (pc & ~known_coll)) return b;
+                wk &= wk - 1ull;
+            }
+            return -1;
+        };
         double nx = 0, ny = 0, nz = 0;
-        int nb = work ? __ffsll((long long)work) - 1 : 0;
-        if (work && (cbase + nb) * 64 + lane < P) sw_load_point<F64>(cloud, (cbase + nb) * 64 + lane, nx, ny, nz);
-        while (work) {
+        int nb = next_needed(work);
+        if (nb >= 0 && (cbase + nb) * 64 + lane < P) sw_load_point<F64>(cloud, (cbase + nb) * 64 + lane, nx, ny, nz);
+        while (nb >= 0) {
             const int b0 = nb;
-            work &= work - 1ull;
+            ++st_proc;
+            work &= work - 1ull;                            // b0 is the lowest set bit of `work`
             const unsigned bm = (unsigned)__builtin_amdgcn_readlane((int)bmask, b0);
             const bool live = (cbase + b0) * 64 + lane < P;
             const double x = nx, y = ny, z = nz;
-            if (work) {
-                nb = __ffsll((long long)work) - 1;
-                if ((cbase + nb) * 64 + lane < P) sw_load_point<F64>(cloud, (cbase + nb) * 64 + lane, nx, ny, nz);
-            }
+            nb = next_needed(work);
+            if (nb >= 0 && (cbase + nb) * 64 + lane < P) sw_load_point<F64>(cloud, (cbase + nb) * 64 + lane, nx, ny, nz);
             bool unc = live && slow;
             if (!slow) {
                 const double dx = x - f0[0], dy = y - f0[1], dz = z - f0[2];
@@ -227,13 +259,19 @@ __global__ __launch_bounds__(256) void gpg_sweep_select_kernel(
                     const unsigned m = ((dmax >= 31 ? 0xFFFFFFFFu : ((2u << dmax) - 1u)) & ~((1u << dmin) - 1u)) & full;
                     if (b == 0) m_open |= m; else m_coll |= m;
                 }
-                if (!unc) { acc_open |= m_open; acc_coll |= m_coll; }
+                if (unc) { m_open = 0u; m_coll = 0u; }
+                // fold this chunk's new bits into the wave-uniform masks (only when some lane has one)
+                if (__ballot((m_open & ~known_open) | (m_coll & ~known_coll)) != 0ull) {
+                    known_open |= sw_wave_or(m_open);
+                    known_coll |= sw_wave_or(m_coll);
+                }
             }
             // ---- exact path: lane = offset d, the very arithmetic of hand_box_counts_kernel, one uncertain point a trip
             unsigned long long todo = __ballot(unc);
             while (todo) {
                 const int src = __ffsll((long long)todo) - 1;
                 todo &= todo - 1ull;
+                ++st_exact;
                 const double px = sw_readlane(x, src), py = sw_readlane(y, src), pz = sw_readlane(z, src);
                 bool in[4] = {false, false, false, false};
                 if (lane < D) {
@@ -249,13 +287,16 @@ __global__ __launch_bounds__(256) void gpg_sweep_select_kernel(
                         in[b] = (bx[b * 6] < gx) && (bx[b * 6 + 1] > gx) && (bx[b * 6 + 2] < gy) &&
                                 (bx[b * 6 + 3] > gy) && (bx[b * 6 + 4] < gz) && (bx[b * 6 + 5] > gz);
                 }
-                ex_open |= (unsigned)__ballot(in[0]);
-                ex_coll |= (unsigned)(__ballot(in[1]) | __ballot(in[2]) | __ballot(in[3]));
+                known_open |= (unsigned)__ballot(in[0]);
+                known_coll |= (unsigned)(__ballot(in[1]) | __ballot(in[2]) | __ballot(in[3]));
             }
         }
     }
-    const unsigned open_m = (sw_wave_or(acc_open) | ex_open) & full;
-    const unsigned coll_m = (sw_wave_or(acc_coll) | ex_coll) & full;
+    const unsigned open_m = known_open & full, coll_m = known_coll & full;
+    if (stats && lane == 0) {
+        atomicAdd(&stats[0], 1ull); atomicAdd(&stats[1], (unsigned long long)st_pass);
+        atomicAdd(&stats[2], (unsigned long long)st_proc); atomicAdd(&stats[3], (unsigned long long)st_exact);
+    }
     if (lane == 0) {
         if (masks) { masks[(size_t)t * 2] = open_m; masks[(size_t)t * 2 + 1] = coll_m; }
         // gpg_select_kernel: the middle admissible offset (:1565-1567), then the 30-degree rule at it (:1570-1573)

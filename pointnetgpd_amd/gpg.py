@@ -29,7 +29,9 @@ Reference quirks reproduced on purpose (see oracle/gpg_oracle.py for the execute
 The reference reseeds numpy from the OS before every draw (:1455) and so has no reproducible stream; here the
 draws come from ``sample_indices`` (explicit), else ``numpy.random.default_rng(seed)``.
 """
+import collections
 import ctypes
+import threading
 
 import numpy as np
 import torch
@@ -47,7 +49,14 @@ MAX_NN = 100                                   # :1475
 TABLE_CLEARANCE = 0.01                         # :1599 safety_dis_above_table
 MIN_OPEN_POINTS = 10                           # :1614
 BOX_OPEN, BOX_LEFT, BOX_RIGHT, BOX_BOTTOM = 0, 1, 2, 3
-_PIN = None                                    # process-wide pinned staging buffer of the sampler's two downloads
+_TLS = threading.local()                       # per-thread pool of pinned staging buffers (two downloads per round)
+
+
+def _pin_pool():
+    pool = getattr(_TLS, "pool", None)
+    if pool is None:
+        pool = _TLS.pool = []
+    return pool
 
 
 def _gripper_dict(gripper):
@@ -210,7 +219,7 @@ def hand_box_counts(cloud, poses, boxes, index=None, valid_units=None, per_unit=
     return counts
 
 
-def sweep_select(index, poses, ab, L, R, D, boxes, prm, tol=1e-9, want_masks=False):
+def sweep_select(index, poses, ab, L, R, D, boxes, prm, tol=1e-9, want_masks=False, stats=None):
     """The lateral sweep + selection of all (sample point, rotation) units in one launch
     (``pngpd_gpg_sweep_select``): index = the scene's ``CloudIndex``; poses (L*R*D,12), ab (L*R,6) from
     ``pngpd_gpg_enumerate``; boxes (4,6); prm the sampler's parameter block.
@@ -227,7 +236,8 @@ def sweep_select(index, poses, ab, L, R, D, boxes, prm, tol=1e-9, want_masks=Fal
         _lib.check(lib.pngpd_gpg_sweep_select(_p(c), int(c.dtype == torch.float64), index.P, _p(index.spheres), index.C,
                                               _p(poses), _p(ab), int(L), int(R), int(D), _p(boxes), _p(prm), float(tol),
                                               _p(flag), _p(dsel), _p(plist), _p(total),
-                                              _p(masks) if masks is not None else None, _stream(c)),
+                                              _p(masks) if masks is not None else None,
+                                              _p(stats) if stats is not None else None, _stream(c)),
                    "gpg_sweep_select")
     return (flag, dsel, plist, total, masks) if want_masks else (flag, dsel, plist, total)
 
@@ -257,6 +267,7 @@ class GpgGraspSamplerPcl:
         self.device = torch.device(device) if device is not None else None
         self.last_stats = {}
         self._const_cache = {}
+        self.sweep_stats = None                   # a CUDA int64 (4,) tensor: pngpd_gpg_sweep_select adds its diagnostics
         self.profile = None                       # set to {} to collect per-stage times (synchronising; diagnostics only)
 
     # -- device work for one batch of draws --------------------------------------------------
@@ -283,12 +294,19 @@ class GpgGraspSamplerPcl:
         self._t_last = now
 
     def _pinned(self, n):
-        """A pinned host staging buffer of >= n doubles.  Page-locking costs milliseconds, so the buffer is shared by all
-        samplers of the process (scoring.detect_grasps builds one per scene by default) and grows geometrically."""
-        global _PIN
-        if _PIN is None or _PIN.numel() < n:
-            _PIN = torch.empty(max(2 * n, 1 << 17), dtype=torch.float64).pin_memory()
-        return _PIN[:n]
+        """A pinned host staging buffer of >= n doubles from a thread-local pool (page-locking costs milliseconds; samplers
+        are short-lived — scoring.detect_grasps builds one per scene — so the pool outlives them).  Several rounds are in
+        flight at once, each with its own buffers; ``_unpin`` hands a buffer back once its copy has been consumed."""
+        pool = _pin_pool()
+        for i, t in enumerate(pool):
+            if t.numel() >= n:
+                return pool.pop(i)
+        return torch.empty(max(n, 1 << 15), dtype=torch.float64).pin_memory()
+
+    @staticmethod
+    def _unpin(t):
+        if t is not None:
+            _pin_pool().append(t)
 
     @staticmethod
     def _params(g):
@@ -309,35 +327,48 @@ class GpgGraspSamplerPcl:
         prm[80:80 + S] = np.arange(S, dtype=np.float64)
         return prm, len(dth), len(dys), S
 
-    def _run_batch(self, g, cloud_d, normals_d, sel_pts, normals_at_ind, scene):
-        """sel_pts (K,3) sample points, normals_at_ind (K,3) -> (m_zero (K,) bool, counts (K,) grasps per draw,
-        grasps (n,5,3) rows of all draws in draw order).  ``scene``: dict holding the scene's CloudIndex (built lazily,
-        once) — the index is only needed by the sweep, so its device work is enqueued BEHIND the moments kernel and runs
-        while the host waits for the K moment matrices and computes the local frames."""
+    # -- one round of draws = three stages, so that consecutive rounds overlap (see sample_grasps) --------------------
+    def _stage_moments(self, g, cloud_d, normals_d, sel_pts, normals_at_ind):
+        """[device] r-ball / 100-NN moment matrices of the round's sample points + their download (asynchronous)."""
         dev = cloud_d.device
         K = sel_pts.shape[0]
-        tick = self._tick
-        tick(None, dev)
+        self._tick(None, dev)
         fw, hd = g["finger_width"], g["hand_depth"]
         r_ball = max(g["hand_outer_diameter"] - fw, hd, g["hand_height"] / 2.0)                  # :1464
-        boxes_d, prm, R, D, S = self._constants(g, dev)
-        M_d, _ = normal_moments(cloud_d, normals_d, torch.from_numpy(sel_pts).to(dev), r_ball, MAX_NN)
+        # uploads go through pinned staging buffers: a pageable copy would block the host until the device has drained
+        # everything queued before it — i.e. the previous round's whole chain — and serialise the pipeline
+        q_h = self._pinned(K * 3)
+        q_h[:K * 3].copy_(torch.from_numpy(np.ascontiguousarray(sel_pts).reshape(-1)))
+        q_d = torch.empty(K, 3, device=dev, dtype=torch.float64)
+        q_d.view(-1).copy_(q_h[:K * 3], non_blocking=True)
+        M_d, _ = normal_moments(cloud_d, normals_d, q_d, r_ball, MAX_NN)
         M_h = self._pinned(K * 9)
-        M_h.copy_(M_d.view(-1), non_blocking=True)                                              # download 1: K x 9 doubles
+        M_h[:K * 9].copy_(M_d.view(-1), non_blocking=True)                                      # download 1: K x 9 doubles
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
+        return dict(K=K, sel_pts=sel_pts, normals_at_ind=normals_at_ind, M_h=M_h, M_d=M_d, ev_m=ev, q_h=q_h)
+
+    def _stage_chain(self, rd, g, cloud_d, scene):
+        """[host] local frames of the round (np.linalg.eig, exactly as the reference calls it), then [device] everything
+        from the pose enumeration to the packed result and its download (asynchronous).  Fills rd["m_zero"]."""
+        dev = cloud_d.device
+        K, sel_pts, normals_at_ind = rd["K"], rd["sel_pts"], rd["normals_at_ind"]
+        tick = self._tick
+        boxes_d, prm, R, D, S = self._constants(g, dev)
         if self.use_index and scene.get("index") is None:
-            scene["index"] = CloudIndex(cloud_d)          # ~0.4 ms of device work, overlapped with the host's eig below
+            scene["index"] = CloudIndex(cloud_d)          # enqueued behind the first moments kernel; the host does not wait
         index = scene.get("index")
-        ev.synchronize()
+        rd["ev_m"].synchronize()
         tick("moments+download", dev)
-        M = M_h.numpy().reshape(K, 3, 3).copy()
+        M = rd["M_h"][:K * 9].numpy().reshape(K, 3, 3).copy()
+        self._unpin(rd.pop("M_h")); rd.pop("M_d"); self._unpin(rd.pop("q_h"))
         m_zero = M.sum((1, 2)) == 0                                                             # :1486
-        counts = np.zeros(K, dtype=np.int64)
+        rd["m_zero"] = m_zero
         live = np.nonzero(~m_zero)[0]
+        rd["live"], rd["L"] = live, live.size
         if live.size == 0:
-            return m_zero, counts, np.zeros((0, 5, 3))
-        # local frames (:1493-1512) — np.linalg.eig exactly as the reference calls it, once for the whole batch
+            return
+        # local frames (:1493-1512) — np.linalg.eig exactly as the reference calls it, once for the whole round
         eigval, eigvec = np.linalg.eig(M[live])
         eigval, eigvec = np.real(eigval), np.real(eigvec)
         ar = np.arange(live.size)
@@ -352,7 +383,11 @@ class GpgGraspSamplerPcl:
         L = live.size
         up = np.concatenate([np.concatenate([minor, normal, major, sel_pts[live]], 1).reshape(-1), prm])
         tick("host eig+frames", dev)
-        up_d = torch.from_numpy(up).to(dev)                                                     # upload: frames + constants
+        up_h = self._pinned(up.size)
+        up_h[:up.size].copy_(torch.from_numpy(up))
+        up_d = torch.empty(up.size, device=dev, dtype=torch.float64)
+        up_d.copy_(up_h[:up.size], non_blocking=True)                                           # upload: frames + constants
+        rd["up_h"] = up_h
         frames_d, prm_d = up_d[:L * 12], up_d[L * 12:]
         cap = L * R
         f64 = dict(device=dev, dtype=torch.float64)
@@ -362,7 +397,7 @@ class GpgGraspSamplerPcl:
         _call("pngpd_gpg_enumerate", up_d, frames_d, L, R, D, prm_d, poses, ab)
         tick("upload+enumerate", dev)
         if self.fused_sweep and index is not None:
-            flag, dsel, plist, total = sweep_select(index, poses, ab, L, R, D, boxes_d, prm_d)
+            flag, dsel, plist, total = sweep_select(index, poses, ab, L, R, D, boxes_d, prm_d, stats=self.sweep_stats)
         else:
             cnt = hand_box_counts(cloud_d, poses, boxes_d, index=index)                         # (L*R*D,4)
             ibuf = torch.empty(3 * cap + 1, **i32)
@@ -383,15 +418,28 @@ class GpgGraspSamplerPcl:
               sfirst, olist, ototal, out)
         out[-1:].copy_(total)               # the potential-grasp count rides in the same download (it was a third sync)
         host_t = self._pinned(nres)
-        host_t.copy_(out, non_blocking=True)                                                    # download 2: packed result
-        torch.cuda.current_stream(dev).synchronize()
-        tick("finish+download", dev)
-        host = host_t.numpy()
+        host_t[:nres].copy_(out, non_blocking=True)                                             # download 2: packed result
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        rd.update(host_t=host_t, nres=nres, out_d=out, ev_r=ev)
+
+    def _stage_collect(self, rd, dev):
+        """[host] wait for the round's packed result -> (m_zero (K,) bool, counts (K,) grasps per draw, grasps (n,5,3) rows
+        of all draws in draw order)."""
+        K, m_zero = rd["K"], rd["m_zero"]
+        counts = np.zeros(K, dtype=np.int64)
+        if rd["L"] == 0:
+            return m_zero, counts, np.zeros((0, 5, 3))
+        rd["ev_r"].synchronize()
+        self._tick("finish+download", dev)
+        L, live = rd["L"], rd["live"]
+        host = rd["host_t"][:rd["nres"]].numpy()
         self.last_stats["potential"] = self.last_stats.get("potential", 0) + int(host[-1])
         n = int(host[0])
         counts[live] = host[1:1 + L].astype(np.int64)
         # rows are packed in (live sample point, rotation) order = draw order: no per-draw regrouping needed
         grasps = host[1 + L:1 + L + n * 15].reshape(n, 5, 3).copy()
+        self._unpin(rd.pop("host_t")); rd.pop("out_d"); self._unpin(rd.pop("up_h"))
         return m_zero, counts, grasps
 
     def sample_grasps(self, point_cloud, points_for_sample, all_normal, num_grasps=20, max_num_samples=200,
@@ -419,31 +467,71 @@ class GpgGraspSamplerPcl:
             return np.zeros((0, 5, 3)) if as_array else []
         rng = np.random.default_rng(seed)
         explicit = None if sample_indices is None else np.asarray(sample_indices, dtype=np.int64).reshape(-1)
-        pos, sampled, found, done = 0, 0, 0, False
-        while not done:
-            want = min(self.batch_samples, max_num_samples - sampled)
+        # Rounds of up to ``batch_samples`` draws run as a three-stage pipeline on ONE stream, two rounds ahead:
+        #     device:  mom(0) mom(1) | chain(0) mom(2) | chain(1) mom(3) | ...
+        #     host:                    eig(0)          | eig(1) collect(0) | eig(2) collect(1) | ...
+        # The moments of round k+2 are enqueued behind chain(k), so their download is complete when the host turns to
+        # eig(k+1) — which then runs while the device works on chain(k): neither side waits for the other, where the
+        # serial schedule alternated (host eig with an idle device, then the device chain with an idle host).  Rounds are
+        # sized as if no draw of the rounds in flight had a zero moment matrix (those do not count, :1486-1489); the
+        # stop rule is applied to the rounds in order, one round behind, and a stop abandons the rounds in flight.
+        sampled, found, done = 0, 0, False
+        st = dict(pos=0, issued=0, credit=0)       # credit: draws issued but not yet known to count (or not)
+
+        def issue():
+            want = min(self.batch_samples, max_num_samples - sampled - st["credit"])
+            if want <= 0:
+                return None
             if explicit is not None:
-                draws = explicit[pos:pos + want]
+                draws = explicit[st["pos"]:st["pos"] + want]
                 if draws.size == 0:
-                    break
+                    return None
             else:
-                if self.last_stats["draws"] >= 10 * max_num_samples:
-                    break                                            # degenerate cloud: the reference would spin here
+                if st["issued"] >= 10 * max_num_samples:
+                    return None                                      # degenerate cloud: the reference would spin here
                 draws = rng.integers(0, pfs.shape[0], size=want)
-            pos += draws.size
-            m_zero, counts, grasps = self._run_batch(g, cloud_d, normals_d, pfs[draws], all_normal[draws], scene)
-            # the reference's loop over the draws (:1486-1489, :1639), without a Python iteration per draw: a draw whose
-            # M is zero consumes a draw but is not counted; stop behind the first counted draw at which num_grasps
-            # grasps have been found or max_num_samples sample points have been processed
-            live_cum = sampled + np.cumsum(~m_zero)
-            found_cum = found + np.cumsum(counts)
-            stop = np.nonzero(~m_zero & ((found_cum >= num_grasps) | (live_cum >= max_num_samples)))[0]
-            last = int(stop[0]) if stop.size else draws.size - 1
-            keep = int(found_cum[last] - found)
-            chunks.append(grasps[:keep])
-            self.last_stats["draws"] += last + 1
-            sampled, found = int(live_cum[last]), int(found_cum[last])
-            done = bool(stop.size)
+            st["pos"] += draws.size; st["issued"] += draws.size; st["credit"] += draws.size
+            rd = self._stage_moments(g, cloud_d, normals_d, pfs[draws], all_normal[draws])
+            rd["draws"] = draws
+            return rd
+
+        lookahead = 0 if self.profile is not None else 2             # the stage profile wants one round at a time
+        pending, chained = collections.deque(), collections.deque()
+        for _ in range(max(1, lookahead)):
+            rd = issue()
+            if rd is not None:
+                pending.append(rd)
+        while (pending or chained) and not done:
+            if pending:
+                rd = pending.popleft()
+                self._stage_chain(rd, g, cloud_d, scene)
+                chained.append(rd)
+            if len(chained) > (1 if pending and lookahead else 0):
+                rd = chained.popleft()
+                m_zero, counts, grasps = self._stage_collect(rd, dev)
+                # the reference's loop over the draws (:1486-1489, :1639), without a Python iteration per draw: a draw
+                # whose M is zero consumes a draw but is not counted; stop behind the first counted draw at which
+                # num_grasps grasps have been found or max_num_samples sample points have been processed
+                st["credit"] -= rd["K"]
+                live_cum = sampled + np.cumsum(~m_zero)
+                found_cum = found + np.cumsum(counts)
+                stop = np.nonzero(~m_zero & ((found_cum >= num_grasps) | (live_cum >= max_num_samples)))[0]
+                last = int(stop[0]) if stop.size else rd["K"] - 1
+                keep = int(found_cum[last] - found)
+                chunks.append(grasps[:keep])
+                self.last_stats["draws"] += last + 1
+                sampled, found = int(live_cum[last]), int(found_cum[last])
+                done = bool(stop.size)
+            if not done:
+                rd = issue()
+                if rd is not None:
+                    pending.append(rd)
+        if pending or chained:
+            # rounds in flight were abandoned by the stop rule: their copies must land before the buffers are reused
+            torch.cuda.current_stream(dev).synchronize()
+            for rd in list(pending) + list(chained):
+                for key in ("M_h", "host_t", "q_h", "up_h"):
+                    self._unpin(rd.get(key))
         out = np.concatenate(chunks, 0) if chunks else np.zeros((0, 5, 3))
         self.last_stats["sampled"] = sampled
         if as_array:
