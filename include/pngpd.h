@@ -502,6 +502,16 @@ int pngpd_train_batch(const void *arena, int arena_is_f64, int P, const double *
 int pngpd_gpg_normal_moments(const void *cloud, int cloud_is_f64, const double *normals, int P,
                              const double *queries, int K, double radius, int max_nn, double *M_out,
                              int *nsel_out, void *stream);
+/* The same selection over the spatial index of gpg.CloudIndex (Morton-sorted cloud + 64-point chunk spheres, as for
+ * pngpd_hand_box_counts_indexed): the chunk spheres bound the max_nn-th nearest distance, only the chunks that can hold
+ * a selected point are scanned (a handful on a dense cloud instead of all P points, 11 times).  order (P) int32: sorted
+ * position -> ORIGINAL index (ties at the cut go to the lower original index; normals stay in original order).
+ * Same selected set as pngpd_gpg_normal_moments and the same order of additions: M is bit-identical (LAPACK's
+ * eigenvector signs on the host can flip on a last-bit change).  max_nn <= 1024, else PNGPD_ERR_UNSUPPORTED.         */
+int pngpd_gpg_normal_moments_indexed(const void *cloud_sorted, int cloud_is_f64, const int *order,
+                                     const double *normals, int P, const double *spheres, int C,
+                                     const double *queries, int K, double radius, int max_nn, double *M_out,
+                                     int *nsel_out, void *stream);
 /* :336-393 / :405-421  For each of Q hand poses (poses (Q,12) f64 = centre, approach, binormal, minor; unit
  * axes) count the cloud points strictly inside each of num_boxes (1 or 4) boxes of the hand model, boxes
  * (num_boxes,6) f64 = x_lo, x_hi, y_lo, y_hi, z_lo, z_hi in the grasp frame -> counts (Q,num_boxes) int32.

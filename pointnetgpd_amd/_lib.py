@@ -156,6 +156,9 @@ SIGNATURES = {
     # ---- GPG sampler (device half)
     "pngpd_gpg_normal_moments": (ctypes.c_int, [c_void, ctypes.c_int, c_void, ctypes.c_int, c_void, ctypes.c_int,
                                                 ctypes.c_double, ctypes.c_int, c_void, c_void, c_void]),
+    "pngpd_gpg_normal_moments_indexed": (ctypes.c_int, [c_void, ctypes.c_int, c_void, c_void, ctypes.c_int, c_void,
+                                                        ctypes.c_int, c_void, ctypes.c_int, ctypes.c_double, ctypes.c_int,
+                                                        c_void, c_void, c_void]),
     "pngpd_hand_box_counts": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, ctypes.c_int, c_void,
                                              ctypes.c_int, c_void, c_void]),
     "pngpd_hand_box_counts_indexed_n": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, ctypes.c_int, c_void,

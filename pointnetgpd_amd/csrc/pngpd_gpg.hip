@@ -544,6 +544,7 @@ __global__ __launch_bounds__(256) void gpg_pack_kernel(const int *__restrict__ o
 }
 
 #include "pngpd_gpg_sweep.h"
+#include "pngpd_gpg_moments.h"
 
 extern "C" {
 
@@ -680,6 +681,23 @@ int pngpd_gpg_sweep_select(const void *cloud_sorted, int cloud_is_f64, int P, co
     int st = pngpd_launch_status();
     if (st != PNGPD_OK) return st;
     hipLaunchKernelGGL(gpg_flag_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, flag, LR, list, total);
+    return pngpd_launch_status();
+}
+
+int pngpd_gpg_normal_moments_indexed(const void *cloud_sorted, int cloud_is_f64, const int *order,
+                                     const double *normals, int P, const double *spheres, int C,
+                                     const double *queries, int K, double radius, int max_nn, double *M_out,
+                                     int *nsel_out, void *stream) {
+    if (!cloud_sorted || !order || !normals || !spheres || !queries || !M_out || !nsel_out || P <= 0 || K <= 0 ||
+        max_nn <= 0 || !(radius > 0) || C != (P + 63) / 64)
+        return PNGPD_ERR_INVALID_ARG;
+    if (max_nn > GPG_MAXSEL) return PNGPD_ERR_UNSUPPORTED;      // (use pngpd_gpg_normal_moments)
+    if (cloud_is_f64)
+        hipLaunchKernelGGL(gpg_normal_moments_indexed_kernel<true>, dim3(K), dim3(256), 0, (hipStream_t)stream,
+                           cloud_sorted, order, normals, P, spheres, C, queries, radius, max_nn, M_out, nsel_out);
+    else
+        hipLaunchKernelGGL(gpg_normal_moments_indexed_kernel<false>, dim3(K), dim3(256), 0, (hipStream_t)stream,
+                           cloud_sorted, order, normals, P, spheres, C, queries, radius, max_nn, M_out, nsel_out);
     return pngpd_launch_status();
 }
 

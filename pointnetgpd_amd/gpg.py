@@ -122,8 +122,10 @@ def _check_cloud(cloud):
     return cloud.contiguous()
 
 
-def normal_moments(cloud, normals, queries, radius, max_nn=MAX_NN):
-    """cloud (P,3) CUDA f32|f64, normals (P,3) CUDA f64, queries (K,3) CUDA f64 -> M (K,3,3) f64, nsel (K) int32."""
+def normal_moments(cloud, normals, queries, radius, max_nn=MAX_NN, index=None):
+    """cloud (P,3) CUDA f32|f64, normals (P,3) CUDA f64, queries (K,3) CUDA f64 -> M (K,3,3) f64, nsel (K) int32.
+    ``index`` (the cloud's ``CloudIndex``): only the chunks that can hold one of the max_nn nearest points are scanned
+    (``pngpd_gpg_normal_moments_indexed``); same selection, same order of additions: M is bit-identical."""
     lib = _lib.load()
     cloud = _check_cloud(cloud)
     if not normals.is_cuda or normals.dtype != torch.float64 or tuple(normals.shape) != tuple(cloud.shape):
@@ -135,9 +137,16 @@ def normal_moments(cloud, normals, queries, radius, max_nn=MAX_NN):
     M = torch.empty(K, 3, 3, device=cloud.device, dtype=torch.float64)
     nsel = torch.empty(K, device=cloud.device, dtype=torch.int32)
     with _lib.device_guard(cloud.device):
-        _lib.check(lib.pngpd_gpg_normal_moments(_p(cloud), int(cloud.dtype == torch.float64), _p(normals),
-                                                cloud.shape[0], _p(queries), K, float(radius), int(max_nn), _p(M),
-                                                _p(nsel), _stream(cloud)), "gpg_normal_moments")
+        if index is not None and max_nn <= 1024:
+            c = index.cloud
+            _lib.check(lib.pngpd_gpg_normal_moments_indexed(_p(c), int(c.dtype == torch.float64), _p(index.order),
+                                                            _p(normals), index.P, _p(index.spheres), index.C,
+                                                            _p(queries), K, float(radius), int(max_nn), _p(M), _p(nsel),
+                                                            _stream(c)), "gpg_normal_moments_indexed")
+        else:
+            _lib.check(lib.pngpd_gpg_normal_moments(_p(cloud), int(cloud.dtype == torch.float64), _p(normals),
+                                                    cloud.shape[0], _p(queries), K, float(radius), int(max_nn), _p(M),
+                                                    _p(nsel), _stream(cloud)), "gpg_normal_moments")
     return M, nsel
 
 
@@ -165,6 +174,7 @@ class CloudIndex:
         q = ((pts - lo) / ext * 1023.0).long().clamp_(0, 1023)
         code = _spread3(q[:, 0]) | (_spread3(q[:, 1]) << 1) | (_spread3(q[:, 2]) << 2)
         order = torch.argsort(code)
+        self.order = order.int().contiguous()              # sorted position -> original index
         self.cloud = cloud[order].contiguous()
         C = (P + 63) // 64
         sp = pts[order]
@@ -328,10 +338,13 @@ class GpgGraspSamplerPcl:
         return prm, len(dth), len(dys), S
 
     # -- one round of draws = three stages, so that consecutive rounds overlap (see sample_grasps) --------------------
-    def _stage_moments(self, g, cloud_d, normals_d, sel_pts, normals_at_ind):
+    def _stage_moments(self, g, cloud_d, normals_d, sel_pts, normals_at_ind, scene):
         """[device] r-ball / 100-NN moment matrices of the round's sample points + their download (asynchronous)."""
         dev = cloud_d.device
         K = sel_pts.shape[0]
+        if self.use_index and scene.get("index") is None:
+            scene["index"] = CloudIndex(cloud_d)          # once per scene: ~0.4 ms of device work, nobody waits for it
+        index = scene.get("index")
         self._tick(None, dev)
         fw, hd = g["finger_width"], g["hand_depth"]
         r_ball = max(g["hand_outer_diameter"] - fw, hd, g["hand_height"] / 2.0)                  # :1464
@@ -341,7 +354,7 @@ class GpgGraspSamplerPcl:
         q_h[:K * 3].copy_(torch.from_numpy(np.ascontiguousarray(sel_pts).reshape(-1)))
         q_d = torch.empty(K, 3, device=dev, dtype=torch.float64)
         q_d.view(-1).copy_(q_h[:K * 3], non_blocking=True)
-        M_d, _ = normal_moments(cloud_d, normals_d, q_d, r_ball, MAX_NN)
+        M_d, _ = normal_moments(cloud_d, normals_d, q_d, r_ball, MAX_NN, index=index)
         M_h = self._pinned(K * 9)
         M_h[:K * 9].copy_(M_d.view(-1), non_blocking=True)                                      # download 1: K x 9 doubles
         ev = torch.cuda.Event()
@@ -491,7 +504,7 @@ class GpgGraspSamplerPcl:
                     return None                                      # degenerate cloud: the reference would spin here
                 draws = rng.integers(0, pfs.shape[0], size=want)
             st["pos"] += draws.size; st["issued"] += draws.size; st["credit"] += draws.size
-            rd = self._stage_moments(g, cloud_d, normals_d, pfs[draws], all_normal[draws])
+            rd = self._stage_moments(g, cloud_d, normals_d, pfs[draws], all_normal[draws], scene)
             rd["draws"] = draws
             return rd
 

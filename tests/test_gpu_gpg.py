@@ -71,6 +71,38 @@ def test_normal_moments_vs_oracle(cuda_device):
         assert nsel[-1] == 0 and np.all(M[-1] == 0)
 
 
+@pytest.mark.parametrize("dtype,P,kind", [(np.float64, 4000, "ellipsoid"), (np.float32, 20000, "cylinder"),
+                                          (np.float32, 50, "box"), (np.float64, 130, "box")])
+def test_indexed_moments_select_the_same_points(dtype, P, kind, cuda_device):
+    """pngpd_gpg_normal_moments_indexed (chunk spheres bound the 100-NN distance; only the chunks that can hold a
+    selected point are scanned) against the whole-cloud kernel: the same number of selected points for every query and
+    radius / max_nn combination and BIT-IDENTICAL M (the additions are re-ordered into the whole-cloud kernel's order:
+    np.linalg.eig's eigenvector signs can flip on a last-bit change), duplicates / exact ties / zero normals / empty
+    balls / fewer points than max_nn included."""
+    from pointnetgpd_amd import gpg
+    pts, nrm = go.synth_scene(kind, P, 6)
+    pts = pts.astype(dtype)
+    nrm[::17] = 0.0
+    if P > 300:
+        pts[100] = pts[7]; pts[200] = pts[7]; pts[300] = pts[7]          # duplicates: zero distance + exact ties
+    rng = np.random.default_rng(P)
+    q = np.concatenate([pts[[7, min(50, P - 1), P - 1]].astype(np.float64),
+                        pts[:20].astype(np.float64) + rng.normal(scale=1e-3, size=(20, 3)),
+                        np.array([[1.0, 1.0, 1.0]])])
+    cloud, nd, qd = torch.from_numpy(pts).to(cuda_device), torch.from_numpy(nrm).to(cuda_device), torch.from_numpy(q).to(cuda_device)
+    index = gpg.CloudIndex(cloud)
+    assert torch.equal(index.cloud, cloud[index.order.long()])
+    for radius, max_nn in [(0.1925, 100), (0.01, 100), (0.004, 100), (0.1925, 7), (0.05, 1), (0.1925, 1000)]:
+        M0, n0 = gpg.normal_moments(cloud, nd, qd, radius, max_nn)
+        M1, n1 = gpg.normal_moments(cloud, nd, qd, radius, max_nn, index=index)
+        assert torch.equal(n0, n1), (radius, max_nn)
+        assert torch.equal(M0, M1), (radius, max_nn, (M0 - M1).abs().max().item())
+    # determinism: the candidate list is built in chunk order, every sum has a fixed order
+    Ma, _ = gpg.normal_moments(cloud, nd, qd, 0.1925, 100, index=index)
+    Mb, _ = gpg.normal_moments(cloud, nd, qd, 0.1925, 100, index=index)
+    assert torch.equal(Ma, Mb)
+
+
 def test_tie_break_lower_index(cuda_device):
     """Exactly equal distances at the max_nn cut: the lower indices are kept (stable sort of the stand-in)."""
     from pointnetgpd_amd import gpg
@@ -86,6 +118,11 @@ def test_tie_break_lower_index(cuda_device):
         Mr = sum(np.outer(nrm[i], nrm[i]) / (nrm[i] @ nrm[i]) for i in idx)
         assert int(nsel[0]) == max_nn
         np.testing.assert_allclose(M[0].cpu().numpy(), Mr, atol=1e-14)
+        cl = torch.from_numpy(pts).to(cuda_device)
+        Mi, ni = gpg.normal_moments(cl, torch.from_numpy(nrm).to(cuda_device), torch.from_numpy(q).to(cuda_device), 1.0,
+                                    max_nn, index=gpg.CloudIndex(cl))
+        assert int(ni[0]) == max_nn
+        np.testing.assert_allclose(Mi[0].cpu().numpy(), Mr, atol=1e-14)       # ties go to the lower ORIGINAL index
 
 
 @pytest.mark.parametrize("tag", CASES)
