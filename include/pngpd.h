@@ -561,7 +561,16 @@ int pngpd_gpg_sweep_select(const void *cloud_sorted, int cloud_is_f64, int P, co
 int pngpd_gpg_pushin(const int *list, const int *total, const int *dsel, const double *poses, const double *ab,
                      const double *frames, int L, int R, int D, int S, const double *prm, double *poses2, double *back,
                      double *mod, void *stream);
-/* :1614-1637  counts2 (L*R,S,2,4) -> first accepted step per potential grasp; res (1 + L + L*R*15) doubles =
+/* :1576-1625  the collision / opening tests of ALL push-in poses of a potential grasp in one wave (they share a frame
+ * and lie on the approach axis) — straight to found / sfirst, the outputs of pngpd_gpg_finish's first stage, which is
+ * then called with counts2 == NULL.  poses2 (L*R,S,2,12) from pngpd_gpg_pushin, *total potential grasps (device), S <= 32
+ * (else PNGPD_ERR_UNSUPPORTED); cloud_sorted / spheres / boxes / tol / stats as for pngpd_gpg_sweep_select (tol in
+ * push-in steps).  Equal to pngpd_hand_box_counts_indexed_n + the first-accept rule on the exact counts, always.      */
+int pngpd_gpg_pushin_sweep(const void *cloud_sorted, int cloud_is_f64, int P, const double *spheres, int C,
+                           const double *poses2, const int *total, int L, int R, int S, const double *boxes,
+                           int min_open, double tol, int *found, int *sfirst, unsigned long long *stats,
+                           void *stream);
+/* :1614-1637  counts2 (L*R,S,2,4) [NULL: found / sfirst already hold the first accepted steps] -> first accepted step per potential grasp; res (1 + L + L*R*15) doubles =
  * [n_found, grasps per live sample point (L), rows [bottom, approach, binormal, minor, bottom_modified] in the
  * reference's output order]; found/sfirst/olist (L*R), ototal (1): scratch */
 int pngpd_gpg_finish(const int *counts2, const int *list, const int *total, const double *ab, const double *frames,

@@ -170,6 +170,9 @@ SIGNATURES = {
     "pngpd_gpg_sweep_select": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, ctypes.c_int, c_void, c_void,
                                               ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void, c_void, ctypes.c_double,
                                               c_void, c_void, c_void, c_void, c_void, c_void, c_void]),
+    "pngpd_gpg_pushin_sweep": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, ctypes.c_int, c_void, c_void,
+                                              ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void, ctypes.c_int,
+                                              ctypes.c_double, c_void, c_void, c_void, c_void]),
     "pngpd_gpg_pushin": (ctypes.c_int, [c_void] * 6 + [ctypes.c_int] * 4 + [c_void] * 4 + [c_void]),
     "pngpd_gpg_finish": (ctypes.c_int, [c_void] * 7 + [ctypes.c_int] * 4 + [c_void] * 5 + [c_void]),
     # ---- GPD baseline + depth registration

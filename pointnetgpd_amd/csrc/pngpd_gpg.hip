@@ -545,6 +545,7 @@ __global__ __launch_bounds__(256) void gpg_pack_kernel(const int *__restrict__ o
 
 #include "pngpd_gpg_sweep.h"
 #include "pngpd_gpg_moments.h"
+#include "pngpd_gpg_pushin.h"
 
 extern "C" {
 
@@ -646,16 +647,19 @@ int pngpd_gpg_pushin(const int *list, const int *total, const int *dsel, const d
 int pngpd_gpg_finish(const int *counts2, const int *list, const int *total, const double *ab, const double *frames,
                      const double *back, const double *mod, int L, int R, int S, int min_open, int *found,
                      int *sfirst, int *olist, int *ototal, double *res, void *stream) {
-    if (!counts2 || !list || !total || !ab || !frames || !back || !mod || !found || !sfirst || !olist || !ototal ||
+    if (!list || !total || !ab || !frames || !back || !mod || !found || !sfirst || !olist || !ototal ||
         !res || L <= 0 || R <= 0 || S <= 0)
         return PNGPD_ERR_INVALID_ARG;
     const int cap = L * R;
     hipError_t e = hipMemsetAsync(res, 0, (size_t)(1 + L) * sizeof(double), (hipStream_t)stream);
     if (e != hipSuccess) return PNGPD_ERR_HIP + (int)e;
-    hipLaunchKernelGGL(gpg_first_accept_kernel, dim3((cap + 255) / 256), dim3(256), 0, (hipStream_t)stream, counts2,
-                       total, S, cap, min_open, found, sfirst);
-    int st = pngpd_launch_status();
-    if (st != PNGPD_OK) return st;
+    int st = PNGPD_OK;
+    if (counts2) {      // NULL: found / sfirst were filled by pngpd_gpg_pushin_sweep
+        hipLaunchKernelGGL(gpg_first_accept_kernel, dim3((cap + 255) / 256), dim3(256), 0, (hipStream_t)stream, counts2,
+                           total, S, cap, min_open, found, sfirst);
+        st = pngpd_launch_status();
+        if (st != PNGPD_OK) return st;
+    }
     hipLaunchKernelGGL(gpg_flag_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, found, cap, olist, ototal);
     st = pngpd_launch_status();
     if (st != PNGPD_OK) return st;
@@ -698,6 +702,24 @@ int pngpd_gpg_normal_moments_indexed(const void *cloud_sorted, int cloud_is_f64,
     else
         hipLaunchKernelGGL(gpg_normal_moments_indexed_kernel<false>, dim3(K), dim3(256), 0, (hipStream_t)stream,
                            cloud_sorted, order, normals, P, spheres, C, queries, radius, max_nn, M_out, nsel_out);
+    return pngpd_launch_status();
+}
+
+int pngpd_gpg_pushin_sweep(const void *cloud_sorted, int cloud_is_f64, int P, const double *spheres, int C,
+                           const double *poses2, const int *total, int L, int R, int S, const double *boxes,
+                           int min_open, double tol, int *found, int *sfirst, unsigned long long *stats,
+                           void *stream) {
+    if (!cloud_sorted || !spheres || !poses2 || !total || !boxes || !found || !sfirst || P <= 0 || L <= 0 || R <= 0 ||
+        S <= 0 || C != (P + 63) / 64 || !(tol >= 0.0))
+        return PNGPD_ERR_INVALID_ARG;
+    if (S > 32) return PNGPD_ERR_UNSUPPORTED;                   // (use pngpd_hand_box_counts_indexed_n + pngpd_gpg_finish)
+    const int cap = L * R;
+    if (cloud_is_f64)
+        hipLaunchKernelGGL(gpg_pushin_sweep_kernel<true>, dim3((cap + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                           cloud_sorted, P, spheres, C, poses2, total, cap, S, boxes, min_open, tol, found, sfirst, stats);
+    else
+        hipLaunchKernelGGL(gpg_pushin_sweep_kernel<false>, dim3((cap + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                           cloud_sorted, P, spheres, C, poses2, total, cap, S, boxes, min_open, tol, found, sfirst, stats);
     return pngpd_launch_status();
 }
 

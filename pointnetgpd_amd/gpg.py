@@ -31,6 +31,7 @@ draws come from ``sample_indices`` (explicit), else ``numpy.random.default_rng(s
 """
 import collections
 import ctypes
+import os
 import threading
 
 import numpy as np
@@ -57,6 +58,27 @@ def _pin_pool():
     if pool is None:
         pool = _TLS.pool = []
     return pool
+
+
+_EIG_POOL = None
+
+
+def _batched_eig(M):
+    """``np.linalg.eig`` of a (n,3,3) stack — the very LAPACK call of the reference (:1493; its eigenvector signs decide
+    the sweep's enumeration order), one matrix at a time inside numpy's gufunc loop.  Each matrix is solved on its own, so
+    slicing the stack over a few host threads returns the same bits (numpy releases the GIL inside the loop): 20,000
+    matrices take 28 ms on one core of the GPU box and 4.3 ms on eight."""
+    global _EIG_POOL
+    n = M.shape[0]
+    workers = min(8, os.cpu_count() or 1)
+    if n < 512 or workers < 2:
+        return np.linalg.eig(M)
+    if _EIG_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _EIG_POOL = ThreadPoolExecutor(workers, thread_name_prefix="pngpd-eig")
+    parts = np.array_split(np.arange(n), workers)
+    res = list(_EIG_POOL.map(lambda ix: np.linalg.eig(M[ix[0]:ix[-1] + 1]), [ix for ix in parts if ix.size]))
+    return np.concatenate([r[0] for r in res]), np.concatenate([r[1] for r in res])
 
 
 def _gripper_dict(gripper):
@@ -229,6 +251,19 @@ def hand_box_counts(cloud, poses, boxes, index=None, valid_units=None, per_unit=
     return counts
 
 
+def pushin_sweep(index, poses2, total, L, R, S, boxes, min_open, found, sfirst, tol=1e-9, stats=None):
+    """All push-in poses of every potential grasp in one launch (``pngpd_gpg_pushin_sweep``): poses2 (L*R*S*2,12) from
+    ``pngpd_gpg_pushin``, total (1) int32 on the device -> found / sfirst (L*R) int32 filled in place, identical to
+    ``hand_box_counts(..., index=index)`` + the first-accept rule of ``pngpd_gpg_finish``."""
+    lib = _lib.load()
+    c = index.cloud
+    with _lib.device_guard(c.device):
+        _lib.check(lib.pngpd_gpg_pushin_sweep(_p(c), int(c.dtype == torch.float64), index.P, _p(index.spheres), index.C,
+                                              _p(poses2), _p(total), int(L), int(R), int(S), _p(boxes), int(min_open),
+                                              float(tol), _p(found), _p(sfirst),
+                                              _p(stats) if stats is not None else None, _stream(c)), "gpg_pushin_sweep")
+
+
 def sweep_select(index, poses, ab, L, R, D, boxes, prm, tol=1e-9, want_masks=False, stats=None):
     """The lateral sweep + selection of all (sample point, rotation) units in one launch
     (``pngpd_gpg_sweep_select``): index = the scene's ``CloudIndex``; poses (L*R*D,12), ab (L*R,6) from
@@ -278,6 +313,7 @@ class GpgGraspSamplerPcl:
         self.last_stats = {}
         self._const_cache = {}
         self.sweep_stats = None                   # a CUDA int64 (4,) tensor: pngpd_gpg_sweep_select adds its diagnostics
+        self.pushin_stats = None                  # the same for pngpd_gpg_pushin_sweep
         self.profile = None                       # set to {} to collect per-stage times (synchronising; diagnostics only)
 
     # -- device work for one batch of draws --------------------------------------------------
@@ -382,7 +418,7 @@ class GpgGraspSamplerPcl:
         if live.size == 0:
             return
         # local frames (:1493-1512) — np.linalg.eig exactly as the reference calls it, once for the whole round
-        eigval, eigvec = np.linalg.eig(M[live])
+        eigval, eigvec = _batched_eig(M[live])
         eigval, eigvec = np.real(eigval), np.real(eigvec)
         ar = np.arange(live.size)
         minor = _unit(eigvec[ar, :, np.argmin(eigval, 1)])
@@ -421,10 +457,14 @@ class GpgGraspSamplerPcl:
         bm = torch.empty(2 * cap * S, 3, **f64)
         back, mod = bm[:cap * S], bm[cap * S:]
         _call("pngpd_gpg_pushin", up_d, plist, total, dsel, poses, ab, frames_d, L, R, D, S, prm_d, poses2, back, mod)
-        cnt2 = hand_box_counts(cloud_d, poses2, boxes_d, index=index, valid_units=total, per_unit=2 * S)
-        tick("pushin+sweep2", dev)
         jbuf = torch.empty(3 * cap + 1, **i32)
         found, sfirst, olist, ototal = jbuf[:cap], jbuf[cap:2 * cap], jbuf[2 * cap:3 * cap], jbuf[3 * cap:]
+        if self.fused_sweep and index is not None and S <= 32:
+            pushin_sweep(index, poses2, total, L, R, S, boxes_d, MIN_OPEN_POINTS, found, sfirst, stats=self.pushin_stats)
+            cnt2 = None                                    # pngpd_gpg_finish then starts from found / sfirst
+        else:
+            cnt2 = hand_box_counts(cloud_d, poses2, boxes_d, index=index, valid_units=total, per_unit=2 * S)
+        tick("pushin+sweep2", dev)
         nres = 1 + L + cap * 15 + 1
         out = torch.empty(nres, **f64)
         _call("pngpd_gpg_finish", up_d, cnt2, plist, total, ab, frames_d, back, mod, L, R, S, MIN_OPEN_POINTS, found,

@@ -301,3 +301,67 @@ def test_sampler_same_result_fused_and_per_pose_sweep(cuda_device):
     a = gpg.GpgGraspSamplerPcl(device=cuda_device, fused_sweep=True).sample_grasps(pts, pfs, nrm, 10 ** 6, 300, sample_indices=draws, as_array=True)
     b = gpg.GpgGraspSamplerPcl(device=cuda_device, fused_sweep=False).sample_grasps(pts, pfs, nrm, 10 ** 6, 300, sample_indices=draws, as_array=True)
     assert len(a) > 20 and np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("dtype,P,kind,L", [(np.float32, 6000, "cylinder", 60), (np.float64, 3000, "box", 200),
+                                            (np.float32, 20000, "ellipsoid", 80)])
+def test_fused_pushin_sweep_equals_counts_then_first_accept(dtype, P, kind, L, cuda_device):
+    """pngpd_gpg_pushin_sweep (one wave per potential grasp; pose lanes keep a collision bit and a saturating opening
+    count, point lanes test intervals along the approach axis, near-boundary points re-evaluated exactly) against
+    pngpd_hand_box_counts_indexed_n + the first-accept rule on the exact counts: found / sfirst identical — default
+    margin, exact path forced everywhere (tol = 1e30), and a margin wide enough (0.2 steps = 1 mm) that many points take
+    the exact path.  Frames as the sampler builds them, sample points on the cloud, normals pointing outwards (so that
+    approach axes point down into the object for part of the rotations and potential grasps exist)."""
+    from pointnetgpd_amd import gpg
+    from pointnetgpd_amd.ops import _call
+    pts, nrm = go.synth_scene(kind, P, 19)
+    pts = pts.astype(dtype)
+    g = gpg._gripper_dict(gpg.ROBOTIQ_85)
+    s = gpg.GpgGraspSamplerPcl(device=cuda_device)
+    boxes_d, prm, R, D, S = s._constants(g, cuda_device)
+    rng = np.random.default_rng(P + L)
+    ids = rng.integers(0, P, L)
+    sel = pts[ids].astype(np.float64)
+    normal = -nrm[ids] / np.linalg.norm(nrm[ids], axis=1, keepdims=True)         # approach = into the surface
+    tmp = rng.normal(size=(L, 3))
+    minor = np.cross(normal, tmp); minor /= np.linalg.norm(minor, axis=1, keepdims=True)
+    major = np.cross(minor, normal)
+    frames = np.concatenate([minor, normal, major, sel], 1)
+    up = torch.from_numpy(np.concatenate([frames.reshape(-1), prm])).to(cuda_device)
+    frames_d, prm_d = up[:L * 12], up[L * 12:]
+    cap = L * R
+    f64 = dict(device=cuda_device, dtype=torch.float64)
+    poses, ab = torch.empty(cap * D, 12, **f64), torch.empty(cap, 6, **f64)
+    _call("pngpd_gpg_enumerate", up, frames_d, L, R, D, prm_d, poses, ab)
+    cloud = torch.from_numpy(pts).to(cuda_device)
+    index = gpg.CloudIndex(cloud)
+    flag, dsel, plist, total = gpg.sweep_select(index, poses, ab, L, R, D, boxes_d, prm_d)
+    n = int(total.item())
+    assert n >= 3, n
+    poses2 = torch.empty(cap * S * 2, 12, **f64)
+    bm = torch.empty(2 * cap * S, 3, **f64)
+    back, mod = bm[:cap * S], bm[cap * S:]
+    _call("pngpd_gpg_pushin", up, plist, total, dsel, poses, ab, frames_d, L, R, D, S, prm_d, poses2, back, mod)
+    # reference: exact counts of every pose, then the first-accept rule (pngpd_gpg_finish with counts2)
+    cnt2 = gpg.hand_box_counts(cloud, poses2, boxes_d, index=index, valid_units=total, per_unit=2 * S)
+    i32 = dict(device=cuda_device, dtype=torch.int32)
+    found0, sfirst0, olist, ototal = torch.empty(cap, **i32), torch.empty(cap, **i32), torch.empty(cap, **i32), torch.empty(1, **i32)
+    out0 = torch.empty(1 + L + cap * 15 + 1, **f64)
+    _call("pngpd_gpg_finish", up, cnt2, plist, total, ab, frames_d, back, mod, L, R, S, gpg.MIN_OPEN_POINTS, found0, sfirst0,
+          olist, ototal, out0)
+    assert 0 < int(found0[:n].sum())
+    for tol in (1e-9, 1e30, 0.2):
+        found1, sfirst1 = torch.full((cap,), -7, **i32), torch.full((cap,), -7, **i32)
+        stats = torch.zeros(4, dtype=torch.int64, device=cuda_device)
+        gpg.pushin_sweep(index, poses2, total, L, R, S, boxes_d, gpg.MIN_OPEN_POINTS, found1, sfirst1, tol=tol, stats=stats)
+        assert torch.equal(found1, found0), tol
+        acc = found0.bool()
+        assert torch.equal(sfirst1[acc], sfirst0[acc]), tol
+        assert int(stats[0]) == n
+        if tol == 0.2:
+            assert int(stats[3]) > 0                 # the exact path really ran
+        out1 = torch.empty_like(out0)
+        _call("pngpd_gpg_finish", up, None, plist, total, ab, frames_d, back, mod, L, R, S, gpg.MIN_OPEN_POINTS, found1,
+              sfirst1, olist, ototal, out1)
+        nf = int(out0[0].item())                     # the packed result: [n_found, per-sample-point counts, rows]
+        assert nf == int(found0[:n].sum()) and torch.equal(out1[:1 + L + nf * 15], out0[:1 + L + nf * 15])

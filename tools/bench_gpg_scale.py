@@ -28,6 +28,7 @@ for fused in ([True, False] if os.environ.get("BOTH", "1") == "1" else [True]):
     dt = sorted(dts)[1]
     s.profile = {}
     s.sweep_stats = torch.zeros(4, dtype=torch.int64, device=dev)
+    s.pushin_stats = torch.zeros(4, dtype=torch.int64, device=dev)
     res2 = s.sample_grasps(cloud_d, pfs, nrm, 10 ** 9, SAMPLES, seed=1, as_array=True)
     prof = {k: round(v * 1e3, 2) for k, v in s.profile.items()}
     assert np.array_equal(res, res2)
@@ -37,4 +38,5 @@ for fused in ([True, False] if os.environ.get("BOTH", "1") == "1" else [True]):
                       "seconds": round(dt, 4), "candidates_per_s": round(len(res) / dt, 1),
                       "identical_to_first_variant": bool(np.array_equal(res, ref)), "stage_ms_synchronised": prof,
                       "sweep_units_chunks_passed_evaluated_exact": s.sweep_stats.tolist(),
+                      "pushin_units_chunks_passed_evaluated_exact": s.pushin_stats.tolist(),
                       "potential": s.last_stats["potential"]}), flush=True)
