@@ -132,9 +132,10 @@ def test_dataset_projection_items():
 
 
 def test_device_loader_host_half(tmp_path, monkeypatch):
-    """CPU: the host half of device_loader.DeviceGraspLoader (arena layout, per-object vectorised frames, cached
-    labels, view picks) against a per-item evaluation with the Dataset mirror's own pieces.  (The device half —
-    two kernel launches — is covered by tests/test_gpu_device_loader.py.)"""
+    """CPU: the host half of device_loader.DeviceGraspLoader — arena layout, the per-DATASET frame / label tables
+    (computed once, indexed by item on the device) and an epoch's tables (permutation, view picks, arena spans; rank
+    shares under one process per GPU) — against a per-item evaluation with the Dataset mirror's own pieces.  (The
+    device half, one foreign call per batch, is covered by tests/test_gpu_device_loader.py.)"""
     from pointnetgpd_amd import crop
     from pointnetgpd_amd.device_loader import DeviceGraspLoader
     from pointnetgpd_amd.model import dataset as ds_mod
@@ -145,28 +146,45 @@ def test_device_loader_host_half(tmp_path, monkeypatch):
                ds_mod.PointGraspMultiClassDataset(obj_points_num=4000, grasp_points_num=100, pc_file_used_num=3,
                                                   grasp_amount_per_file=12, thresh_good=0.5, thresh_bad=1.2, tag="test")):
         ld = object.__new__(DeviceGraspLoader)               # host tables only: no device, no arena upload
+        ld.seed, ld.epoch, ld.shuffle, ld.rank, ld.world, ld.B = 7, 0, True, 0, 1, 8
         chunks = ld._index(ds)
         arena = np.concatenate(chunks, 0)
         n_views = 3 if not ld.fullview else 6
         assert arena.shape == (3 * n_views * 3000, 3)
         for path, (s0, n0) in ld.view_range.items():
             assert np.array_equal(arena[s0:s0 + n0], np.load(path))
-        rng = np.random.default_rng(7)
-        items = rng.permutation(len(ds))[:20]
-        frames, labels, spans, views = ld._assemble(items, rng)
-        for i, item in enumerate(items):
+        assert ld._frames.shape == (len(ds), 18) and ld._labels.shape == (len(ds),)
+        for item in range(len(ds)):                          # the per-dataset tables, item by item
             oi, gi = np.unravel_index(item, (len(ds.object), ds.grasp_amount_per_file))
             obj = ds.object[oi]
             grasp = np.load(ds.d_grasp[obj])[gi]
             ref = crop.frames_from_grasps_train(grasp[None, :], ds.transform[obj][1])[0]
-            np.testing.assert_allclose(frames[i], ref, rtol=0, atol=1e-15)
+            np.testing.assert_allclose(ld._frames[item], ref, rtol=0, atol=1e-15)
             lab = ds._label(grasp[-2] + grasp[-1] * 0.01)
-            assert labels[i] == (-1 if lab is None else lab)
-            files = ds.d_pc[ds.transform[obj][0]]
+            assert ld._labels[item] == (-1 if lab is None else lab)
+        order, obj_of, pick, spans = ld._epoch_tables()
+        assert sorted(order.tolist()) == list(range(len(ds))) and order.dtype == np.int32 and spans.dtype == np.int32
+        for i, item in enumerate(order):
+            oi = item // ds.grasp_amount_per_file
+            assert obj_of[i] == oi
+            files = ld.files[oi]
+            assert sorted(files) == sorted(ds.d_pc[ds.transform[ds.object[oi]][0]])
             if ld.fullview:
-                assert len(views[i]) == 3 and all(v in files for v in views[i])
-                assert [tuple(r) for r in spans[i]] == [ld.view_range[v] for v in views[i]]
+                assert spans[i].shape == (3, 2)
+                assert [tuple(r) for r in spans[i]] == [ld.view_range[files[j]] for j in pick[i]]
             else:
-                assert views[i] in files and tuple(spans[i]) == ld.view_range[views[i]]
+                assert tuple(spans[i]) == ld.view_range[files[pick[i]]]
+        # the same (seed, epoch) reproduces the tables; another epoch reshuffles
+        o2 = ld._epoch_tables()[0]
+        assert np.array_equal(order, o2)
+        ld.epoch = 1
+        assert not np.array_equal(order, ld._epoch_tables()[0])
+        # one process per GPU: strided shares, padded by wrap-around to equal lengths (DistributedSampler's contract)
+        ld.epoch, ld.world = 0, 4
+        shares = []
+        for r in range(4):
+            ld.rank = r
+            shares.append(ld._epoch_tables()[0])
+        assert all(len(sh) == 9 for sh in shares) and sorted(set(np.concatenate(shares).tolist())) == list(range(36))
         if not ld.fullview:
-            assert (labels == -1).any() and (labels >= 0).any()      # thresholds 0.45 / 1.2 leave a None band
+            assert (ld._labels == -1).any() and (ld._labels >= 0).any()      # thresholds 0.45 / 1.2 leave a None band
