@@ -463,6 +463,21 @@ int pngpd_crop_resample(const void *cloud, int cloud_is_f64, int P, const double
                         const int *gather, int Pg, int G, const int *counts, const int *idx, int max_keep, int N,
                         int mode, int min_points, unsigned long long seed, long long g_base, const int *rows,
                         const int *sel, float *out, unsigned char *valid, void *stream);
+/* The inference crop over a spatial index — BASELINE configs[4]: 100,000 candidate hands cropped out of ONE scene
+ * (kinect2grasp.py:238-258).  cloud_sorted (P,3) / spheres (C = ceil(P/64), 4) f64: the scene re-ordered along a Morton
+ * curve and the bounding sphere of each 64-point chunk (gpg.CloudIndex, as for pngpd_hand_box_counts_indexed); only the
+ * chunks whose sphere meets the hand's box are evaluated, with the same fp64 per-point test.  counts as
+ * pngpd_crop_count_compact; idx = SORTED positions in ascending order (= the order a plain scan of cloud_sorted visits
+ * the in-box points, so pngpd_crop_resample(cloud_sorted, ...) applies unchanged).                                  */
+int pngpd_crop_count_compact_indexed(const void *cloud_sorted, int cloud_is_f64, int P, const double *spheres, int C,
+                                     const double *frames, int G, int max_keep, int *counts, int *idx, void *stream);
+/* pngpd_crop_count_compact_indexed + pngpd_crop_resample in ONE launch: the index list of a hand lives in its
+ * workgroup's LDS and never reaches HBM (it was ~1 GB written and read back per 100,000 hands).  Outputs and draw keys
+ * exactly as the two calls in sequence.  Dynamic LDS: (max(max_keep, N) + max_keep) * 4 bytes.                      */
+int pngpd_crop_indexed(const void *cloud_sorted, int cloud_is_f64, int P, const double *spheres, int C,
+                       const double *frames, int G, int max_keep, int N, int mode, int min_points,
+                       unsigned long long seed, long long g_base, int *counts, float *out, unsigned char *valid,
+                       void *stream);
 /* my_collate (main_1v.py:48-50) without a host round trip: sample g of a training batch is kept iff counts[g] >=
  * min_points (dataset.py:71-72) and labels[g] >= 0 (-1 = the reference's label None, dataset.py:446-453).
  * rows (G) int32 = its row in the compacted batch or -1; labels_out[0..n) = the kept labels in order (int64, what

@@ -147,6 +147,11 @@ SIGNATURES = {
                                            ctypes.c_int, c_void, c_void, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_int, ctypes.c_ulonglong, ctypes.c_longlong, c_void, c_void, c_void,
                                            c_void, c_void]),
+    "pngpd_crop_count_compact_indexed": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, ctypes.c_int, c_void,
+                                                        ctypes.c_int, ctypes.c_int, c_void, c_void, c_void]),
+    "pngpd_crop_indexed": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, ctypes.c_int, c_void, ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_ulonglong,
+                                          ctypes.c_longlong, c_void, c_void, c_void, c_void]),
     "pngpd_batch_keep_rows": (ctypes.c_int, [c_void, c_void, ctypes.c_int, ctypes.c_int, c_void, c_void, c_void, c_void]),
     "pngpd_stack_gather_lists": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_ulonglong,
                                                 ctypes.c_longlong, c_void, c_void]),

@@ -197,6 +197,45 @@ def crop_resample(cloud, frames, counts, idx, num_points, mode=MODE_INFER, min_p
     return out, valid.bool()
 
 
+def crop_count_compact_indexed(index, frames, max_keep=4096):
+    """``crop_count_compact`` over a spatial index (``gpg.CloudIndex`` of the scene): counts (G) int32 as before, idx
+    (G,max_keep) int32 = positions in ``index.cloud`` (the Morton-sorted scene), ascending — resample with
+    ``crop_resample(index.cloud, ...)``.  Only the chunks whose bounding sphere meets a hand's box are evaluated."""
+    lib = _lib.load()
+    if not frames.is_cuda or frames.dtype != torch.float64 or frames.dim() != 2 or frames.shape[1] != 18:
+        raise RuntimeError("frames: expected a CUDA (G,18) float64 tensor")
+    frames = frames.contiguous()
+    c, G = index.cloud, frames.shape[0]
+    counts = torch.empty(G, device=c.device, dtype=torch.int32)
+    idx = torch.empty(G, max_keep, device=c.device, dtype=torch.int32)
+    with _lib.device_guard(c.device):
+        _lib.check(lib.pngpd_crop_count_compact_indexed(_p(c), int(c.dtype == torch.float64), index.P, _p(index.spheres),
+                                                        index.C, _p(frames), G, int(max_keep), _p(counts), _p(idx),
+                                                        _stream(c)), "crop_count_compact_indexed")
+    return counts, idx
+
+
+def crop_indexed(index, frames, num_points, mode=MODE_INFER, min_points=MIN_POINTS_TO_NET, seed=0, g_base=0,
+                 max_keep=4096):
+    """Crop + resample of G hands against one indexed scene in ONE launch (``pngpd_crop_indexed``): the in-box index
+    list of a hand stays in its workgroup's LDS.  -> out (G,3,num_points) fp32, counts (G) int32, valid (G) bool —
+    bit-identical to ``crop_count_compact_indexed`` + ``crop_resample(index.cloud, ...)`` with the same seed / g_base."""
+    lib = _lib.load()
+    if not frames.is_cuda or frames.dtype != torch.float64 or frames.dim() != 2 or frames.shape[1] != 18:
+        raise RuntimeError("frames: expected a CUDA (G,18) float64 tensor")
+    frames = frames.contiguous()
+    c, G = index.cloud, frames.shape[0]
+    counts = torch.empty(G, device=c.device, dtype=torch.int32)
+    out = torch.empty(G, 3, num_points, device=c.device, dtype=torch.float32)
+    valid = torch.empty(G, device=c.device, dtype=torch.uint8)
+    with _lib.device_guard(c.device):
+        _lib.check(lib.pngpd_crop_indexed(_p(c), int(c.dtype == torch.float64), index.P, _p(index.spheres), index.C,
+                                          _p(frames), G, int(max_keep), int(num_points), int(mode), int(min_points),
+                                          ctypes.c_ulonglong(int(seed) & (2 ** 64 - 1)), ctypes.c_longlong(int(g_base)),
+                                          _p(counts), _p(out), _p(valid), _stream(c)), "crop_indexed")
+    return out, counts, valid.bool()
+
+
 def batch_keep_rows(counts, labels, min_points):
     """counts (G) int32 CUDA, labels (G) int64 CUDA (-1 = the reference's ``None``) -> rows (G) int32 (row in the
     compacted batch, -1 = dropped), labels_out (G) int64 (first n entries valid), n_keep () int32 CUDA — ``my_collate``

@@ -152,20 +152,20 @@ __device__ __forceinline__ int crop_block_sum(int v, int *sh) {
 // list.  Without replacement: the same keys (counter hash of the in-box RANK) are recomputed on the fly and the
 // N-th smallest is found by a 4-level radix histogram (4 scans) + 1 emitting scan.  With replacement (only
 // possible when max_keep < count <= N): the full list (count <= N entries) is rebuilt in LDS first.
+// The body of the resample step for grasp g = blockIdx.x (one workgroup): ``cnt`` in-box points, the first
+// min(cnt, max_keep) of them listed in ``gi`` (global memory — crop_resample_kernel — or the workgroup's own LDS —
+// crop_indexed_kernel, where the list never leaves the CU); ``keys``: max(max_keep, N) words of LDS scratch.
 template <bool F64>
-__global__ __launch_bounds__(256) void crop_resample_kernel(
+__device__ __forceinline__ void crop_resample_body(
     const void *__restrict__ cloud, int P, const double *__restrict__ frames, const int *__restrict__ ranges,
-    const int *__restrict__ gather, int Pg, const int *__restrict__ counts,
-    const int *__restrict__ idx, int max_keep, int N, int mode, int min_points, unsigned long long seed,
-    long long g_base, const int *__restrict__ rows, const int *__restrict__ sel, float *__restrict__ out,
-    unsigned char *__restrict__ valid, const int *__restrict__ item) {
-    extern __shared__ unsigned keys[];   // [max(max_keep, N)]: keys of the without-replacement draw / rebuilt list
+    const int *__restrict__ gather, int Pg, const int cnt, const int *gi, int max_keep, int N, int mode, int min_points,
+    unsigned long long seed, long long g_base, const int *__restrict__ rows, const int *__restrict__ sel,
+    float *__restrict__ out, unsigned char *__restrict__ valid, const int *__restrict__ item, unsigned *keys) {
     __shared__ int shi[4];
     __shared__ int wsel[4], wtie[4];
     __shared__ int hist[256];
     __shared__ int hsel[2];
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cnt = counts[g];
     int m = cnt < max_keep ? cnt : max_keep;
     // the draw of a grasp is keyed by its GLOBAL index: a candidate scores the same whichever shard / scoring batch
     // it lands in (kinect2grasp.py:454-497 scores every candidate independently of the others)
@@ -181,7 +181,6 @@ __global__ __launch_bounds__(256) void crop_resample_kernel(
     }
     Frame F;
     load_frame(frames + (size_t)(item ? item[g] : g) * 18, F);
-    const int *gi = idx + (size_t)g * max_keep;
     if (cnt > max_keep && !sel) {
         // ---- overflow: scan the grasp's own cloud (same order and test as crop_count_compact_kernel)
         const int p_begin = (!gather && ranges) ? ranges[2 * g] : 0;
@@ -345,6 +344,123 @@ __global__ __launch_bounds__(256) void crop_resample_kernel(
         to_frame(F, x, y, z, a, b, c);
         o[n] = (float)a; o[N + n] = (float)b; o[2 * N + n] = (float)c;
     }
+}
+
+template <bool F64>
+__global__ __launch_bounds__(256) void crop_resample_kernel(
+    const void *__restrict__ cloud, int P, const double *__restrict__ frames, const int *__restrict__ ranges,
+    const int *__restrict__ gather, int Pg, const int *__restrict__ counts,
+    const int *__restrict__ idx, int max_keep, int N, int mode, int min_points, unsigned long long seed,
+    long long g_base, const int *__restrict__ rows, const int *__restrict__ sel, float *__restrict__ out,
+    unsigned char *__restrict__ valid, const int *__restrict__ item) {
+    extern __shared__ unsigned keys[];   // [max(max_keep, N)]: keys of the without-replacement draw / rebuilt list
+    crop_resample_body<F64>(cloud, P, frames, ranges, gather, Pg, counts[blockIdx.x], idx + (size_t)blockIdx.x * max_keep,
+                            max_keep, N, mode, min_points, seed, g_base, rows, sel, out, valid, item, keys);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Crop over a spatial index (gpg.CloudIndex: the cloud re-ordered along a Morton curve + the bounding sphere of every
+// 64-point chunk) — BASELINE configs[4], where 100,000 candidate hands are cropped out of ONE 50,000-point scene
+// (kinect2grasp.py:238-258).  A hand's box holds a few percent of the scene: lane c tests chunk c's sphere against the
+// box in the hand frame, only the surviving chunks' points are evaluated (the same fp64 per-point test), in ascending
+// SORTED position — so a list is the in-box points in the order of the sorted cloud, which is also the order a plain scan
+// of that cloud visits them (the overflow path of the resample step stays consistent).
+//   crop_count_compact_indexed_kernel  counts + lists in global memory (the API twin of crop_count_compact_kernel);
+//   crop_indexed_kernel                count -> list in the workgroup's LDS -> resample, ONE launch per batch of grasps:
+//                                      the index lists (4.8 k entries per hand on the bench scene, ~1 GB per launch
+//                                      written and read back) never leave the CU.
+template <bool F64>
+__device__ __forceinline__ int crop_indexed_list(const void *__restrict__ cloud, int P, const double *__restrict__ spheres,
+                                                 int C, const Frame &F, int max_keep, int *list /* LDS or global */) {
+    __shared__ int ch_list[256];
+    __shared__ int ch_cnt[4];
+    __shared__ int pt_cnt[4][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int running = 0;
+    for (int cbase = 0; cbase < C; cbase += 256) {
+        // ---- broad phase: 256 chunks, ordered compaction of the survivors into ch_list
+        const int c = cbase + tid;
+        bool pass = false;
+        if (c < C) {
+            const double4 sp = *(const double4 *)(spheres + (size_t)c * 4);
+            double a, b, cc;
+            to_frame(F, sp.x, sp.y, sp.z, a, b, cc);
+            const double r = sp.w * (1.0 + 1e-9) + 1e-12;
+            pass = a + r > F.lo[0] && a - r < F.hi[0] && b + r > F.lo[1] && b - r < F.hi[1] && cc + r > F.lo[2] &&
+                   cc - r < F.hi[2];
+        }
+        const unsigned long long pm = __ballot(pass);
+        __syncthreads();                                    // (the previous round's readers of ch_list are done)
+        if (lane == 0) ch_cnt[wave] = __popcll(pm);
+        __syncthreads();
+        int woff = 0, nch = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const int n = ch_cnt[w]; if (w < wave) woff += n; nch += n; }
+        if (pass) ch_list[woff + __popcll(pm & below)] = c;
+        __syncthreads();
+        // ---- narrow phase: 16 chunks a trip (wave w takes chunks 4 j + w of the trip, j = 0..3), exact per-point test
+        for (int t0 = 0; t0 < nch; t0 += 16) {
+            bool in[4]; int p[4]; unsigned long long mask[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int e = t0 + j * 4 + wave;
+                in[j] = false; p[j] = 0;
+                if (e < nch) {
+                    p[j] = ch_list[e] * 64 + lane;
+                    if (p[j] < P) {
+                        double x, y, z, a, b, cc;
+                        load_point<F64>(cloud, p[j], x, y, z);
+                        to_frame(F, x, y, z, a, b, cc);
+                        in[j] = (a > F.lo[0]) && (a < F.hi[0]) && (b > F.lo[1]) && (b < F.hi[1]) && (cc > F.lo[2]) && (cc < F.hi[2]);
+                    }
+                }
+                mask[j] = __ballot(in[j]);
+                if (lane == 0) pt_cnt[j][wave] = __popcll(mask[j]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int off = 0, tot = 0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { const int n = pt_cnt[j][w]; if (w < wave) off += n; tot += n; }
+                if (in[j]) {
+                    const int pos = running + off + __popcll(mask[j] & below);
+                    if (pos < max_keep) list[pos] = p[j];
+                }
+                running += tot;
+            }
+            __syncthreads();
+        }
+    }
+    return running;
+}
+
+template <bool F64>
+__global__ __launch_bounds__(256) void crop_count_compact_indexed_kernel(
+    const void *__restrict__ cloud, int P, const double *__restrict__ spheres, int C, const double *__restrict__ frames,
+    int max_keep, int *__restrict__ counts, int *__restrict__ idx) {
+    Frame F;
+    load_frame(frames + (size_t)blockIdx.x * 18, F);
+    const int n = crop_indexed_list<F64>(cloud, P, spheres, C, F, max_keep, idx + (size_t)blockIdx.x * max_keep);
+    if (threadIdx.x == 0) counts[blockIdx.x] = n;
+}
+
+template <bool F64>
+__global__ __launch_bounds__(256) void crop_indexed_kernel(
+    const void *__restrict__ cloud, int P, const double *__restrict__ spheres, int C, const double *__restrict__ frames,
+    int max_keep, int N, int mode, int min_points, unsigned long long seed, long long g_base, int *__restrict__ counts,
+    float *__restrict__ out, unsigned char *__restrict__ valid) {
+    extern __shared__ unsigned dyn[];                       // keys[max(max_keep, N)] | list[max_keep]
+    unsigned *keys = dyn;
+    int *list = (int *)(dyn + (max_keep > N ? max_keep : N));
+    Frame F;
+    load_frame(frames + (size_t)blockIdx.x * 18, F);
+    const int n = crop_indexed_list<F64>(cloud, P, spheres, C, F, max_keep, list);
+    if (threadIdx.x == 0) counts[blockIdx.x] = n;
+    __syncthreads();                                        // the list is complete
+    crop_resample_body<F64>(cloud, P, frames, nullptr, nullptr, 0, n, list, max_keep, N, mode, min_points, seed, g_base,
+                            nullptr, nullptr, out, valid, nullptr, keys);
 }
 
 // my_collate (main_1v.py:48-50) on the device: sample g of a training batch is kept iff its crop holds at least
@@ -534,6 +650,43 @@ int pngpd_train_batch(const void *arena, int arena_is_f64, int P, const double *
         hipLaunchKernelGGL(crop_resample_kernel<false>, dim3(G), dim3(256), lds, st, arena, P, frames, ranges, gather,
                            k_views ? Pg : 0, counts, idx, max_keep, N, 0, min_points, seed, g_base, rows,
                            (const int *)nullptr, out, valid, item);
+    }
+    return pngpd_launch_status();
+}
+
+int pngpd_crop_count_compact_indexed(const void *cloud_sorted, int cloud_is_f64, int P, const double *spheres, int C,
+                                     const double *frames, int G, int max_keep, int *counts, int *idx, void *stream) {
+    if (!cloud_sorted || !spheres || !frames || !counts || !idx || P <= 0 || G <= 0 || max_keep <= 0 ||
+        C != (P + 63) / 64)
+        return PNGPD_ERR_INVALID_ARG;
+    if (cloud_is_f64)
+        hipLaunchKernelGGL(crop_count_compact_indexed_kernel<true>, dim3(G), dim3(256), 0, (hipStream_t)stream,
+                           cloud_sorted, P, spheres, C, frames, max_keep, counts, idx);
+    else
+        hipLaunchKernelGGL(crop_count_compact_indexed_kernel<false>, dim3(G), dim3(256), 0, (hipStream_t)stream,
+                           cloud_sorted, P, spheres, C, frames, max_keep, counts, idx);
+    return pngpd_launch_status();
+}
+
+int pngpd_crop_indexed(const void *cloud_sorted, int cloud_is_f64, int P, const double *spheres, int C,
+                       const double *frames, int G, int max_keep, int N, int mode, int min_points,
+                       unsigned long long seed, long long g_base, int *counts, float *out, unsigned char *valid,
+                       void *stream) {
+    if (!cloud_sorted || !spheres || !frames || !counts || !out || !valid || P <= 0 || G <= 0 || max_keep <= 0 ||
+        N <= 0 || (mode != 0 && mode != 1) || C != (P + 63) / 64)
+        return PNGPD_ERR_INVALID_ARG;
+    const size_t lds = ((size_t)(max_keep > N ? max_keep : N) + (size_t)max_keep) * sizeof(int);
+    if (lds > 150 * 1024) return PNGPD_ERR_UNSUPPORTED;
+    if (cloud_is_f64) {
+        const int st = pngpd_allow_lds((const void *)crop_indexed_kernel<true>, lds);
+        if (st != PNGPD_OK) return st;
+        hipLaunchKernelGGL(crop_indexed_kernel<true>, dim3(G), dim3(256), lds, (hipStream_t)stream, cloud_sorted, P,
+                           spheres, C, frames, max_keep, N, mode, min_points, seed, g_base, counts, out, valid);
+    } else {
+        const int st = pngpd_allow_lds((const void *)crop_indexed_kernel<false>, lds);
+        if (st != PNGPD_OK) return st;
+        hipLaunchKernelGGL(crop_indexed_kernel<false>, dim3(G), dim3(256), lds, (hipStream_t)stream, cloud_sorted, P,
+                           spheres, C, frames, max_keep, N, mode, min_points, seed, g_base, counts, out, valid);
     }
     return pngpd_launch_status();
 }

@@ -119,14 +119,17 @@ def test_scorer_end_to_end(cuda_device):
     counts_ref = np.array([len(i) for i in ind_ref])
     np.testing.assert_array_equal(res["counts"].cpu().numpy(), counts_ref)
     np.testing.assert_array_equal(res["valid"].cpu().numpy(), counts_ref >= 20)
-    # re-run the resample with the scorer's seeds to get the exact clouds it scored
+    # re-run the crop with the scorer's keys to get the exact clouds it scored (the scorer crops over the scene's
+    # spatial index: lists in the order of the Morton-sorted cloud, resample against that cloud)
+    from pointnetgpd_amd.gpg import CloudIndex
     frames = torch.from_numpy(crop.frames_from_grasps_infer(grasps)).to(cuda_device)
     cloud = torch.from_numpy(pc32).to(cuda_device)
-    counts, idx = crop.crop_count_compact(cloud, frames, 4096)
+    index = CloudIndex(cloud)
+    counts, idx = crop.crop_count_compact_indexed(index, frames, 4096)
     probs = res["probs"][0].cpu().numpy()
     for s in range(0, 40, 16):
         e = min(40, s + 16)
-        pts, v = crop.crop_resample(cloud, frames[s:e], counts[s:e], idx[s:e], N, crop.MODE_INFER, 20,
+        pts, v = crop.crop_resample(index.cloud, frames[s:e], counts[s:e], idx[s:e], N, crop.MODE_INFER, 20,
                                     seed=5 * 1000003, g_base=s)
         with torch.no_grad():
             lp_ref, _ = po.forward_torch(sd, pts.cpu())
@@ -143,7 +146,7 @@ def test_scorer_end_to_end(cuda_device):
     # test_network (main_test.py:59-69) on one cloud agrees with the batched path
     g0 = int(np.nonzero(valid)[0][0])
     # the draw of candidate g0 depends on (seed, global index) only: resample it ALONE, as the reference's loop does
-    pts, _ = crop.crop_resample(cloud, frames[g0:g0 + 1], counts[g0:g0 + 1], idx[g0:g0 + 1], N,
+    pts, _ = crop.crop_resample(index.cloud, frames[g0:g0 + 1], counts[g0:g0 + 1], idx[g0:g0 + 1], N,
                                 crop.MODE_INFER, 20, seed=5 * 1000003, g_base=g0)
     p1, pr1 = test_network(mg, pts[0].cpu().numpy().T)
     assert int(p1) == int(pred[g0])
@@ -279,3 +282,44 @@ def test_resample_uniform_over_all_points_when_count_exceeds_max_keep(max_keep, 
     assert float((freq - p).abs().max()) < 5.5 * sd, (float((freq - p).abs().max()), sd)
     # the points beyond the truncated list are drawn as often as the ones inside it
     assert abs(float(freq[max_keep:].mean()) / float(freq[:max_keep].mean()) - 1.0) < 0.05
+
+
+@pytest.mark.parametrize("dtype,P,G,max_keep,N", [(np.float32, 30000, 50, 4096, 64), (np.float64, 5000, 33, 256, 100),
+                                                  (np.float32, 130, 7, 64, 16), (np.float32, 50000, 24, 8192, 1024)])
+def test_indexed_crop_equals_plain_crop(dtype, P, G, max_keep, N, cuda_device):
+    """The crop over the scene's spatial index (``pngpd_crop_count_compact_indexed``: chunk spheres against the hand's
+    box, then the same fp64 per-point test) against the whole-cloud kernel: identical counts; the index lists hold the
+    same POINTS (sorted positions mapped back through ``index.order``), in ascending sorted position; truncation at
+    ``max_keep`` included.  And the one-launch form (``pngpd_crop_indexed``: the list never leaves LDS) is bit-identical to
+    indexed count + resample against the sorted cloud — both resample rules, overflowing hands, invalid hands."""
+    from pointnetgpd_amd import crop
+    from pointnetgpd_amd.gpg import CloudIndex
+    pc, grasps = _scene(G, P, 31)
+    pc = pc.astype(dtype)
+    frames = torch.from_numpy(crop.frames_from_grasps_infer(grasps)).to(cuda_device)
+    cloud = torch.from_numpy(pc).to(cuda_device)
+    index = CloudIndex(cloud)
+    c0, i0 = crop.crop_count_compact(cloud, frames, max_keep=P)                      # untruncated reference lists
+    c1, i1 = crop.crop_count_compact_indexed(index, frames, max_keep=max_keep)
+    assert torch.equal(c0, c1) and int(c0.max()) > 0
+    order = index.order.long()
+    for g in range(G):
+        n = int(c0[g])
+        m = min(n, max_keep)
+        pos = i1[g, :m].long()
+        assert bool((pos[1:] > pos[:-1]).all())                                      # ascending sorted position
+        if n <= max_keep:
+            assert torch.equal(torch.sort(order[pos]).values, i0[g, :n].long())      # the same points
+        else:
+            full = torch.sort(torch.nonzero(torch.isin(order, i0[g, :n].long())).squeeze(1)).values
+            assert torch.equal(pos, full[:m])                                        # the first max_keep in sorted order
+    for mode in (crop.MODE_INFER, crop.MODE_TRAIN):
+        ref, vref = crop.crop_resample(index.cloud, frames, c1, i1, N, mode, 20, seed=77, g_base=1000)
+        out, cnt, v = crop.crop_indexed(index, frames, N, mode, 20, seed=77, g_base=1000, max_keep=max_keep)
+        assert torch.equal(cnt, c1) and torch.equal(v, vref) and torch.equal(out, ref)
+    # every output column is an in-box point of its hand (hand frame): inside the box, strictly
+    f = frames.cpu().numpy()
+    o = out.cpu().numpy()
+    for g in np.nonzero(v.cpu().numpy())[0][:10]:
+        lo, hi = f[g, 12:15], f[g, 15:18]
+        assert (o[g] > lo[:, None] - 1e-6).all() and (o[g] < hi[:, None] + 1e-6).all()
