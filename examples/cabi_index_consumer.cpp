@@ -186,6 +186,76 @@ static int run() {
         if (report("crop_gather")) return 2;
     }
 
+    {   // crop over a spatial index: spheres of consecutive 64-point chunks of the (unsorted) cloud are valid bounds
+        const int Cc = (P + 63) / 64;
+        std::vector<double> sphc((size_t)Cc * 4);
+        for (int c = 0; c < Cc; ++c) {
+            double lo[3] = {1e9, 1e9, 1e9}, hi[3] = {-1e9, -1e9, -1e9};
+            for (int i = c * 64; i < (c + 1) * 64 && i < P; ++i)
+                for (int k = 0; k < 3; ++k) { lo[k] = std::fmin(lo[k], pc64[i * 3 + k]); hi[k] = std::fmax(hi[k], pc64[i * 3 + k]); }
+            double r = 0;
+            for (int k = 0; k < 3; ++k) { sphc[c * 4 + k] = 0.5 * (lo[k] + hi[k]); r += 0.25 * (hi[k] - lo[k]) * (hi[k] - lo[k]); }
+            sphc[c * 4 + 3] = std::sqrt(r) + 1e-9;
+        }
+        double *dsphc; int *dcnt2, *didx2;
+        if (upload(sphc, &dsphc) || dalloc(&dcnt2, G) || dalloc(&didx2, (size_t)G * MAXK)) return 2;
+        for (int f64 = 0; f64 < 2; ++f64) {
+            const void *cl = f64 ? (const void *)dpc64 : (const void *)dpc32;
+            PN_OK(pngpd_crop_count_compact(cl, f64, P, dfr, G, MAXK, dcnt, didx, st));
+            PN_OK(pngpd_crop_count_compact_indexed(cl, f64, P, dsphc, Cc, dfr, G, MAXK, dcnt2, didx2, st));
+            HIP_OK(hipStreamSynchronize(st));
+            std::vector<int> ca(G), cb(G), ia((size_t)G * MAXK), ib((size_t)G * MAXK);
+            if (download(dcnt, ca) || download(dcnt2, cb) || download(didx, ia) || download(didx2, ib)) return 2;
+            long bad = 0;
+            for (int gi = 0; gi < G; ++gi) {
+                bad += ca[gi] != cb[gi];
+                const int m = ca[gi] < MAXK ? ca[gi] : MAXK;
+                for (int i = 0; i < m; ++i) bad += ia[(size_t)gi * MAXK + i] != ib[(size_t)gi * MAXK + i];   // identity order here
+            }
+            if (bad) { std::fprintf(stderr, "indexed crop differs from the plain crop\n"); return 4; }
+            for (int mode = 0; mode < 2; ++mode)
+                PN_OK(pngpd_crop_indexed(cl, f64, P, dsphc, Cc, dfr, G, MAXK, N, mode, 20, 77ull + mode, 5ll, dcnt, dout, dvalid, st));
+            if (report(f64 ? "crop_indexed_f64" : "crop_indexed_f32")) return 2;
+        }
+    }
+    {   // the HBM-resident training batch: device-side collate, gather lists, and the one-call batch (both dataset kinds)
+        const int NI = 40, GB = 12, K = 3, Pg = 500;
+        std::vector<double> frt((size_t)NI * 18);
+        std::vector<long long> lab(NI);
+        for (int it = 0; it < NI; ++it) {
+            for (int k = 0; k < 18; ++k) frt[(size_t)it * 18 + k] = fr[(size_t)(it % G) * 18 + k];
+            lab[it] = (it % 5 == 0) ? -1 : (it % 2);                       // every fifth item has no label (None)
+        }
+        std::vector<int> item(GB), spans1((size_t)GB * 2), spansk((size_t)GB * K * 2);
+        for (int gi = 0; gi < GB; ++gi) {
+            item[gi] = (gi * 7) % NI;
+            spans1[gi * 2] = (gi * 311) % (P - 900); spans1[gi * 2 + 1] = 900;
+            for (int v = 0; v < K; ++v) { spansk[(gi * K + v) * 2] = ((gi + v) * 197) % (P - 600); spansk[(gi * K + v) * 2 + 1] = 300 + 100 * v; }
+        }
+        spans1[1] = P; spans1[0] = 0;                                       // one sample sees the whole arena
+        double *dfrt; long long *dlab, *dlabo; int *ditem, *dsp1, *dspk, *dgat, *drows, *dnk;
+        if (upload(frt, &dfrt) || upload(lab, &dlab) || upload(item, &ditem) || upload(spans1, &dsp1) || upload(spansk, &dspk) ||
+            dalloc(&dgat, (size_t)GB * Pg) || dalloc(&drows, GB) || dalloc(&dnk, 1) || dalloc(&dlabo, GB)) return 2;
+        PN_OK(pngpd_stack_gather_lists(dspk, K, Pg, GB, 11ull, 3ll, dgat, st));
+        for (int kv = 0; kv < 2; ++kv) {
+            PN_OK(pngpd_train_batch(dpc64, 1, P, dfrt, dlab, ditem, kv ? dspk : dsp1, kv ? K : 0, kv ? Pg : 0, dgat, GB, MAXK, N, 50,
+                                    21ull + kv, 100ll, dcnt, didx, drows, dvalid, dout, dlabo, dnk, st));
+            HIP_OK(hipStreamSynchronize(st));
+            std::vector<int> rows(GB), nk(1), cn(GB);
+            if (download(drows, rows) || download(dnk, nk) || download(dcnt, cn)) return 2;
+            int kept = 0;
+            for (int gi = 0; gi < GB; ++gi) {
+                const bool keep = cn[gi] >= 50 && lab[item[gi]] >= 0;
+                if ((rows[gi] >= 0) != keep || (keep && rows[gi] != kept)) { std::fprintf(stderr, "batch_keep_rows mismatch\n"); return 4; }
+                kept += keep;
+            }
+            if (kept != nk[0]) { std::fprintf(stderr, "kept count mismatch\n"); return 4; }
+            std::printf("train_batch %s kept %d of %d\n", kv ? "full-view" : "one-view", nk[0], GB);
+        }
+        PN_OK(pngpd_batch_keep_rows(dcnt, dlab, GB, 50, drows, dlabo, dnk, st));
+        HIP_OK(hipStreamSynchronize(st));
+    }
+
     // =====================================================================================================
     // GPG sampler kernels
     // =====================================================================================================
@@ -286,6 +356,59 @@ static int run() {
         for (size_t i = 0; i < c1.size(); ++i) { diff += c1[i] != c2[i]; s1 += c1[i]; }
         std::printf("gpg_chain sweep_counts %ld indexed_vs_bruteforce_mismatches %ld potential %d found %.0f\n", s1, diff, tot[0], res[0]);
         if (diff) { std::fprintf(stderr, "indexed counts differ from brute force\n"); return 4; }
+        {   // the per-unit kernels of the sampler at scale must reproduce the per-pose path: flag / dsel / list / total,
+            // found / sfirst, and the packed result
+            int *dflag2, *ddsel2, *dlist2, *dtotal2, *dfound2, *dsfirst2; unsigned *dmasks; unsigned long long *dstats; double *dres2;
+            if (dalloc(&dflag2, cap) || dalloc(&ddsel2, cap) || dalloc(&dlist2, cap) || dalloc(&dtotal2, 1) || dalloc(&dfound2, cap) ||
+                dalloc(&dsfirst2, cap) || dalloc(&dmasks, (size_t)cap * 2) || dalloc(&dstats, 4) || dalloc(&dres2, (size_t)1 + L + cap * 15)) return 2;
+            HIP_OK(hipMemsetAsync(dstats, 0, 4 * sizeof(unsigned long long), st));
+            for (double tol : {1e-9, 1e30, 0.2}) {
+                PN_OK(pngpd_gpg_sweep_select(dwall, 0, PW, dsph, C, dposes, dab, L, R, D, dboxes, dprm, tol, dflag2, ddsel2, dlist2, dtotal2,
+                                             tol == 0.2 ? dmasks : nullptr, dstats, st));
+                PN_OK(pngpd_gpg_pushin_sweep(dwall, 0, PW, dsph, C, dposes2, dtotal, L, R, S, dboxes, 10, tol, dfound2, dsfirst2, dstats, st));
+                PN_OK(pngpd_gpg_finish(nullptr, dlist, dtotal, dab, dframes, dback, dmod, L, R, S, 10, dfound2, dsfirst2, dolist, dototal,
+                                       dres2, st));
+                HIP_OK(hipStreamSynchronize(st));
+                std::vector<int> fa(cap), fb(cap), da(cap), db(cap), la(cap), lb(cap), ta(1), tb(1), fo(cap), fo2(cap), sf(cap), sf2(cap);
+                std::vector<double> res2((size_t)1 + L + cap * 15);
+                if (download(dflag, fa) || download(dflag2, fb) || download(ddsel, da) || download(ddsel2, db) || download(dlist, la) ||
+                    download(dlist2, lb) || download(dtotal, ta) || download(dtotal2, tb) || download(dfound, fo) || download(dfound2, fo2) ||
+                    download(dsfirst, sf) || download(dsfirst2, sf2) || download(dres2, res2)) return 2;
+                long bad = ta[0] != tb[0];
+                for (int i = 0; i < cap; ++i) bad += fa[i] != fb[i];
+                for (int i = 0; i < ta[0]; ++i) bad += la[i] != lb[i] || da[la[i]] != db[la[i]];
+                for (int i = 0; i < ta[0]; ++i) bad += fo[i] != fo2[i] || (fo[i] && sf[i] != sf2[i]);
+                bad += res2[0] != res[0];
+                for (size_t i = 0; i < (size_t)1 + L + (size_t)res[0] * 15; ++i) bad += res2[i] != res[i];
+                if (bad) { std::fprintf(stderr, "fused sweep / push-in differ from the per-pose path (tol %g): %ld\n", tol, bad); return 4; }
+            }
+            std::vector<unsigned long long> stv(4);
+            if (download(dstats, stv)) return 2;
+            std::printf("gpg_fused units %llu chunks_passed %llu evaluated %llu exact_points %llu\n", stv[0], stv[1], stv[2], stv[3]);
+            // moments over the index (identity order on this unsorted cloud) against the whole-cloud kernel
+            const int K2 = 6;
+            std::vector<double> q2((size_t)K2 * 3);
+            for (int i = 0; i < K2; ++i) { const int p = g.below(PW); for (int k = 0; k < 3; ++k) q2[i * 3 + k] = wall64[p * 3 + k]; }
+            std::vector<int> ident(PW);
+            for (int i = 0; i < PW; ++i) ident[i] = i;
+            std::vector<double> wn((size_t)PW * 3);
+            for (auto &v : wn) v = g.next();
+            double *dq2, *dMa, *dMb, *dwn; int *dna, *dnb, *dident;
+            if (upload(q2, &dq2) || upload(ident, &dident) || upload(wn, &dwn) || dalloc(&dMa, (size_t)K2 * 9) || dalloc(&dMb, (size_t)K2 * 9) ||
+                dalloc(&dna, K2) || dalloc(&dnb, K2)) return 2;
+            for (int mnn : {100, 7}) {
+                PN_OK(pngpd_gpg_normal_moments(dwall, 0, dwn, PW, dq2, K2, 0.05, mnn, dMa, dna, st));
+                PN_OK(pngpd_gpg_normal_moments_indexed(dwall, 0, dident, dwn, PW, dsph, C, dq2, K2, 0.05, mnn, dMb, dnb, st));
+                HIP_OK(hipStreamSynchronize(st));
+                std::vector<double> Ma((size_t)K2 * 9), Mb((size_t)K2 * 9);
+                std::vector<int> na(K2), nb(K2);
+                if (download(dMa, Ma) || download(dMb, Mb) || download(dna, na) || download(dnb, nb)) return 2;
+                long bad = 0;
+                for (int i = 0; i < K2; ++i) bad += na[i] != nb[i];
+                for (size_t i = 0; i < Ma.size(); ++i) bad += Ma[i] != Mb[i];
+                if (bad) { std::fprintf(stderr, "indexed moments differ from the whole-cloud kernel\n"); return 4; }
+            }
+        }
         // single-box variant and Q = 1
         PN_OK(pngpd_hand_box_counts(dwall, 0, PW, dposes, 1, dboxes, 1, dcounts_bf, st));
         PN_OK(pngpd_hand_box_counts_indexed_n(dwall, 0, PW, dsph, C, dposes, 1, dboxes, 1, nullptr, 1, dcounts, st));

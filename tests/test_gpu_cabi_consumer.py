@@ -178,3 +178,21 @@ def test_probe_mfma_rate_runs_and_counts_flops(cuda_device):
             tf = flops.value / (e0.elapsed_time(e1) * 1e-3) / 1e12
             peak = 157.3 if dtype == 0 else 2500.0
             assert 0.5 * peak < tf < 1.02 * peak, (dtype, wps, tf)
+
+
+def test_cabi_index_consumer_cross_checks(cuda_device):
+    """examples/cabi_index_consumer.cpp — the torch-free consumer of the index-heavy entries (crop incl. the indexed and
+    one-launch forms, the HBM-resident training batch, the GPG sampler's per-pose AND per-unit kernels, GPD) on edge-case
+    shapes.  It cross-checks inside: indexed crop == plain crop, device-side collate == the keep rule, indexed sweep ==
+    brute force, fused sweep / push-in == the per-pose path (three margins, packed result included), indexed moments ==
+    whole-cloud moments — and exits non-zero on any mismatch."""
+    import subprocess
+    exe = os.path.join(ROOT, "examples", "cabi_index_consumer")
+    assert os.path.exists(exe), "run `make -C pointnetgpd_amd/csrc example` (or __graft_entry__.build())"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    for tag in ("crop_indexed_f32", "crop_indexed_f64", "train_batch one-view", "train_batch full-view", "gpg_chain", "gpg_fused",
+                "gpd_projection"):
+        assert tag in out.stdout, (tag, out.stdout[-1500:])
+    line = [l for l in out.stdout.splitlines() if l.startswith("gpg_chain")][0]
+    assert "indexed_vs_bruteforce_mismatches 0" in line and int(line.split("potential")[1].split()[0]) > 0
