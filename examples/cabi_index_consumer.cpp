@@ -70,6 +70,7 @@ static void random_rows(Lcg &g, double R[9]) {
 static int run();
 
 int main() {
+    std::setvbuf(stdout, nullptr, _IOLBF, 0);   // line-buffered even into a pipe: a device fault must not eat the progress lines
     const int rc = run();
     std::fflush(stdout);
     std::fflush(stderr);
@@ -237,6 +238,30 @@ static int run() {
         if (upload(frt, &dfrt) || upload(lab, &dlab) || upload(item, &ditem) || upload(spans1, &dsp1) || upload(spansk, &dspk) ||
             dalloc(&dgat, (size_t)GB * Pg) || dalloc(&drows, GB) || dalloc(&dnk, 1) || dalloc(&dlabo, GB)) return 2;
         PN_OK(pngpd_stack_gather_lists(dspk, K, Pg, GB, 11ull, 3ll, dgat, st));
+        HIP_OK(hipStreamSynchronize(st));
+        {   // every drawn row lies inside one of its sample's view spans
+            std::vector<int> gat((size_t)GB * Pg);
+            if (download(dgat, gat)) return 2;
+            for (int gi = 0; gi < GB; ++gi)
+                for (int i = 0; i < Pg; ++i) {
+                    bool ok = false;
+                    for (int v = 0; v < K; ++v) {
+                        const int s0 = spansk[(gi * K + v) * 2], n0 = spansk[(gi * K + v) * 2 + 1];
+                        ok = ok || (gat[(size_t)gi * Pg + i] >= s0 && gat[(size_t)gi * Pg + i] < s0 + n0);
+                    }
+                    if (!ok) { std::fprintf(stderr, "gather row outside its views\n"); return 4; }
+                }
+            std::printf("stack_gather_lists ok\n");
+        }
+        // the pieces first, one by one (a fault is then attributed to its kernel), then the one-call batch
+        PN_OK(pngpd_crop_count_compact_ranges(dpc64, 1, P, dfr, dsp1, GB, MAXK, dcnt, didx, st));
+        HIP_OK(hipStreamSynchronize(st));
+        PN_OK(pngpd_batch_keep_rows(dcnt, dlab, GB, 50, drows, dlabo, dnk, st));
+        HIP_OK(hipStreamSynchronize(st));
+        std::printf("batch_keep_rows ok\n");
+        PN_OK(pngpd_crop_resample(dpc64, 1, P, dfr, dsp1, nullptr, 0, GB, dcnt, didx, MAXK, N, 0, 50, 5ull, 7ll, drows, nullptr, dout, dvalid, st));
+        HIP_OK(hipStreamSynchronize(st));
+        std::printf("crop_resample into compacted rows ok\n");
         for (int kv = 0; kv < 2; ++kv) {
             PN_OK(pngpd_train_batch(dpc64, 1, P, dfrt, dlab, ditem, kv ? dspk : dsp1, kv ? K : 0, kv ? Pg : 0, dgat, GB, MAXK, N, 50,
                                     21ull + kv, 100ll, dcnt, didx, drows, dvalid, dout, dlabo, dnk, st));

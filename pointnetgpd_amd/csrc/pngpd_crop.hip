@@ -468,16 +468,17 @@ __global__ __launch_bounds__(256) void crop_indexed_kernel(
 // One workgroup: an ordered prefix over keep[] gives each kept sample its row in the compacted batch (rows[g], -1 =
 // dropped; pngpd_crop_resample then writes straight to that row), compacts the labels, and leaves the kept count in
 // device memory — the host learns it from a pinned copy one batch later, never by stalling on this one.
-__global__ __launch_bounds__(1024) void batch_keep_rows_kernel(const int *__restrict__ counts,
+constexpr int KEEP_NT = PNGPD_ASAN ? 256 : 1024;      // (sanitizer builds: see pngpd_common.h on 1024-thread workgroups)
+__global__ __launch_bounds__(KEEP_NT) void batch_keep_rows_kernel(const int *__restrict__ counts,
                                                                const long long *__restrict__ labels, int G,
                                                                int min_points, int *__restrict__ rows,
                                                                long long *__restrict__ labels_out,
                                                                int *__restrict__ n_keep,
                                                                const int *__restrict__ item) {
-    __shared__ int wcnt[16];
+    __shared__ int wcnt[KEEP_NT / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int running = 0;
-    for (int base = 0; base < G; base += 1024) {
+    for (int base = 0; base < G; base += KEEP_NT) {
         const int g = base + tid;
         const long long lab = g < G ? labels[item ? item[g] : g] : -1;
         const bool keep = g < G && counts[g] >= min_points && counts[g] > 0 && lab >= 0;
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(1024) void batch_keep_rows_kernel(const int *__rest
         __syncthreads();
         int woff = 0, total = 0;
 #pragma unroll
-        for (int w = 0; w < 16; ++w) { const int c = wcnt[w]; if (w < wave) woff += c; total += c; }
+        for (int w = 0; w < KEEP_NT / 64; ++w) { const int c = wcnt[w]; if (w < wave) woff += c; total += c; }
         if (g < G) {
             const int r = running + woff + __popcll(mask & ((1ull << lane) - 1ull));
             rows[g] = keep ? r : -1;
@@ -597,7 +598,7 @@ int pngpd_crop_resample(const void *cloud, int cloud_is_f64, int P, const double
 int pngpd_batch_keep_rows(const int *counts, const long long *labels, int G, int min_points, int *rows,
                           long long *labels_out, int *n_keep, void *stream) {
     if (!counts || !labels || !rows || !labels_out || !n_keep || G <= 0) return PNGPD_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(batch_keep_rows_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, labels, G,
+    hipLaunchKernelGGL(batch_keep_rows_kernel, dim3(1), dim3(KEEP_NT), 0, (hipStream_t)stream, counts, labels, G,
                        min_points, rows, labels_out, n_keep, (const int *)nullptr);
     return pngpd_launch_status();
 }
@@ -634,7 +635,7 @@ int pngpd_train_batch(const void *arena, int arena_is_f64, int P, const double *
                            k_views ? Pg : 0, max_keep, counts, idx, item);
     int rc = pngpd_launch_status();
     if (rc != PNGPD_OK) return rc;
-    hipLaunchKernelGGL(batch_keep_rows_kernel, dim3(1), dim3(1024), 0, st, counts, labels, G, min_points, rows,
+    hipLaunchKernelGGL(batch_keep_rows_kernel, dim3(1), dim3(KEEP_NT), 0, st, counts, labels, G, min_points, rows,
                        labels_out, n_keep, item);
     rc = pngpd_launch_status();
     if (rc != PNGPD_OK) return rc;

@@ -11,7 +11,7 @@ def run(B, N, k, flat, seq="fused", reps=200):
     opt = FlatAdam(m.parameters(), lr=0.005) if flat else torch.optim.Adam(m.parameters(), lr=0.005, fused=True)
     x = bench.synth_clouds(B, N, 1, dev); y = (torch.arange(B, device=dev) % k).long()
     def step():
-        opt.zero_grad(); lp, _ = m(x); F.nll_loss(lp, y).backward(); opt.step()
+        opt.zero_grad(); loss, _, _ = m.forward_loss(x, y); train.loss_backward(loss); opt.step()   # mains.py's step
     for _ in range(10): step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(reps): step()

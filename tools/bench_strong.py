@@ -16,6 +16,7 @@ import torch
 import torch.nn.functional as F
 
 import bench
+from pointnetgpd_amd import train as _tr
 from pointnetgpd_amd import ddp
 from pointnetgpd_amd.optim import FlatAdam
 from pointnetgpd_amd.train import GraphedTrainStep
@@ -57,14 +58,14 @@ def main():
         x = bench.synth_clouds(B, N, 1, dev); y = (torch.arange(B, device=dev) % k).long()
 
         def plain():
-            opt.zero_grad(); F.nll_loss(m(x)[0], y).backward(); opt.step()
+            opt.zero_grad(); loss, _, _ = m.forward_loss(x, y); _tr.loss_backward(loss); opt.step()   # mains.py's step
         row = {"B": B, "N": N, "step_ms": round(timeit(plain, 20 if B >= 512 else 60), 4)}
         if use_rccl:
             avg = ddp.GradAverager(m, optimizer=opt, early_bucket_at_world_1=True)
 
             def dp():
                 opt.zero_grad()
-                total = avg.backward(F.nll_loss(m(x)[0], y, reduction="sum"), B)
+                total = avg.backward(m.forward_loss(x, y, "sum")[0], B)
                 opt.step(grad_div=total)
             row["step_dp_rccl_world1_ms"] = round(timeit(dp, 20 if B >= 512 else 60), 4)
         mg = bench.build_model(N, k, dev)

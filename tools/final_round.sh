@@ -1,18 +1,23 @@
 # Evidence of a round (GPU box): full GPU suite, smoke, default bench, per-config / scoring / sampler / loader benches,
 # kernel traces and PMC passes.  usage: bash tools/final_round.sh TAG     Every profiler call is bounded by a timeout.
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 python -m pytest tests -m gpu -q 2>&1 | tail -2 | tee gpurun_out/${TAG}_gpu_suite.txt
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_gpu_suite.txt
-python bench.py --pmc > gpurun_out/${TAG}_bench_final.json 2> /tmp/bench.err; echo "bench rc=$?"; cut -c1-300 gpurun_out/${TAG}_bench_final.json
+python bench.py > gpurun_out/${TAG}_bench_final.json 2> /tmp/bench.err      # traffic measured in-run by default; echo "bench rc=$?"; cut -c1-300 gpurun_out/${TAG}_bench_final.json
 timeout 300 python tools/bench_configs.py > gpurun_out/${TAG}_bench_configs.jsonl 2> /tmp/cfg.err; echo "cfg rc=$?"
 timeout 120 python tools/bench_latency.py 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_latency.json
 timeout 200 python tools/bench_gpg.py --P 3000 20000 50000 --cpu-draws 2 2>/dev/null | tail -3 > gpurun_out/${TAG}_bench_gpg.jsonl
 timeout 200 python tools/bench_scoring.py 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_scoring.json
 timeout 200 python tools/bench_pipeline.py 2>/dev/null | tail -3 > gpurun_out/${TAG}_bench_pipeline.jsonl
 timeout 120 python tools/bench_loader.py 2>/dev/null > gpurun_out/${TAG}_bench_loader.jsonl
+timeout 200 python tools/bench_epoch.py 2>/dev/null > gpurun_out/${TAG}_bench_epoch.jsonl
+timeout 200 python tools/bench_gpg_scale.py 2>/dev/null > gpurun_out/${TAG}_bench_gpg_scale.jsonl
+timeout 100 python tools/bench_crop.py 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_crop.json
+FUSED_LOSS=1 timeout 100 python tools/find_copies.py 2>/dev/null > gpurun_out/${TAG}_aten_launches_in_a_step.txt; echo "(empty = no ATen launch inside a training step)" >> gpurun_out/${TAG}_aten_launches_in_a_step.txt
+timeout 600 python tools/localise_residual.py > gpurun_out/${TAG}_localise_residual.txt 2>/dev/null
 timeout 100 python tools/bench_pass.py 2>/dev/null > gpurun_out/${TAG}_bench_pass.txt
 bash tools/prof_round.sh ${TAG} gpg > /tmp/prof.log 2>&1; grep "rc=" /tmp/prof.log
 bash tools/trace_train.sh ${TAG} > /tmp/tr.log 2>&1; grep "rc=" /tmp/tr.log

@@ -6,13 +6,13 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 rm -rf /tmp/prof_kt /tmp/prof_gpg
-( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --min-seconds 0.4 > /tmp/kt.log 2>&1; echo "kt rc=$?" )
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pmc --no-epoch --min-seconds 0.4 > /tmp/kt.log 2>&1; echo "kt rc=$?" )
 KT=$(find /tmp/prof_kt -name "*.db" | head -1)
 [ -n "$KT" ] && python tools/rocprof_summary.py gpurun_out/${TAG}_bench_trace.md "bench.py kernel trace (infer fp32 + bf16x3 + train legs)=$KT" > /dev/null
 if [ "$2" = "gpg" ]; then
-( cd /tmp && timeout 180 rocprofv3 --kernel-trace --stats -d /tmp/prof_gpg -o gpg -- python $GRAFT_REPO_ROOT/tools/bench_gpg.py --P 20000 --cpu-draws 1 --reps 3 > /tmp/gpg.log 2>&1; echo "gpg rc=$?" )
+( cd /tmp && BOTH=0 timeout 180 rocprofv3 --kernel-trace --stats -d /tmp/prof_gpg -o gpg -- python $GRAFT_REPO_ROOT/tools/bench_gpg_scale.py > /tmp/gpg.log 2>&1; echo "gpg rc=$?" )
 GP=$(find /tmp/prof_gpg -name "*.db" | head -1)
-[ -n "$GP" ] && python tools/rocprof_summary.py gpurun_out/${TAG}_gpg_trace.md "tools/bench_gpg.py kernel trace, P 20000, 150 sample points=$GP" > /dev/null
+[ -n "$GP" ] && python tools/rocprof_summary.py gpurun_out/${TAG}_gpg_trace.md "tools/bench_gpg_scale.py kernel trace: the GPG sampler on 20,000 sample points of a 50,000-point scene, 6 calls (1 warm-up, 3 timed, 1 staged, the index build)=$GP" > /dev/null
 tail -n 3 /tmp/gpg.log
 fi
 ls -la gpurun_out/ | tail -5

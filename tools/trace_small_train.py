@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.nn.functional as F
 import bench
 from pointnetgpd_amd.model import pointnet as pn
+from pointnetgpd_amd import train as _tr
 dev = torch.device("cuda:0")
 B, N, k = int(os.environ.get("B", 64)), int(os.environ.get("N", 750)), 2
 torch.manual_seed(0)
@@ -13,5 +14,5 @@ from pointnetgpd_amd.optim import FlatAdam
 opt = FlatAdam(m.parameters(), lr=0.005)
 for i in range(12):
     opt.zero_grad()
-    lp, _ = m(x); F.nll_loss(lp, y).backward(); opt.step()
+    loss, _, _ = m.forward_loss(x, y); _tr.loss_backward(loss); opt.step()      # mains.py's step
 torch.cuda.synchronize()

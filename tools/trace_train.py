@@ -20,8 +20,8 @@ x = bench.synth_clouds(B, N, 1234, dev)
 y = (torch.arange(B, device=dev) % k).long()
 for _ in range(steps):
     opt.zero_grad()
-    lp, _ = m(x)
-    F.nll_loss(lp, y).backward()
+    loss, _, _ = m.forward_loss(x, y)          # mains.py's step (main_1v.py:72-76): the loss inside the head's calls
+    _train.loss_backward(loss)
     opt.step()
 torch.cuda.synchronize()
 print("steps", steps, prec, "B", B, "N", N, "k", k)
