@@ -60,6 +60,42 @@ def _pin_pool():
     return pool
 
 
+class _RoundWorkspace:
+    """Device scratch of one sampler round: ONE allocation, carved per round.  The per-round tensors are hundreds of MB
+    (poses2 alone: 0.75 GB at 8,192 sample points) of slightly different sizes from round to round (the live count
+    varies, the last round is short): handed to the caching allocator they fragment its large pool, and a fresh 400 MB
+    hipMalloc costs 60-90 ms — measured as a stall per call that moved from stage to stage.  Rounds in flight use
+    different slots; a slot is reused only by a later round on the SAME stream, i.e. behind its previous user."""
+
+    def __init__(self):
+        self.buf, self.off = None, 0
+
+    def reset(self, dev, nbytes):
+        if self.buf is None or self.buf.device != dev or self.buf.numel() < nbytes:
+            self.buf = None                                   # drop first: never hold two generations
+            self.buf = torch.empty(int(nbytes * 1.25) + 4096, device=dev, dtype=torch.uint8)
+        self.off = 0
+
+    def take(self, shape, dtype):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        t = self.buf[self.off:self.off + nbytes].view(dtype).view(*shape)
+        self.off += (nbytes + 255) & ~255
+        return t
+
+
+def _ws_ring(dev):
+    ring = getattr(_TLS, "ws", None)
+    if ring is None:
+        ring = _TLS.ws = {}
+    key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
+    if key not in ring:
+        ring[key] = [_RoundWorkspace() for _ in range(4)]
+    return ring[key]
+
+
 _EIG_POOL = None
 
 
@@ -264,7 +300,7 @@ def pushin_sweep(index, poses2, total, L, R, S, boxes, min_open, found, sfirst, 
                                               _p(stats) if stats is not None else None, _stream(c)), "gpg_pushin_sweep")
 
 
-def sweep_select(index, poses, ab, L, R, D, boxes, prm, tol=1e-9, want_masks=False, stats=None):
+def sweep_select(index, poses, ab, L, R, D, boxes, prm, tol=1e-9, want_masks=False, stats=None, ibuf=None):
     """The lateral sweep + selection of all (sample point, rotation) units in one launch
     (``pngpd_gpg_sweep_select``): index = the scene's ``CloudIndex``; poses (L*R*D,12), ab (L*R,6) from
     ``pngpd_gpg_enumerate``; boxes (4,6); prm the sampler's parameter block.
@@ -273,8 +309,9 @@ def sweep_select(index, poses, ab, L, R, D, boxes, prm, tol=1e-9, want_masks=Fal
     lib = _lib.load()
     cap = L * R
     dev = poses.device
-    ibuf = torch.empty(3 * cap + 1, device=dev, dtype=torch.int32)
-    flag, dsel, plist, total = ibuf[:cap], ibuf[cap:2 * cap], ibuf[2 * cap:3 * cap], ibuf[3 * cap:]
+    if ibuf is None:
+        ibuf = torch.empty(3 * cap + 1, device=dev, dtype=torch.int32)
+    flag, dsel, plist, total = ibuf[:cap], ibuf[cap:2 * cap], ibuf[2 * cap:3 * cap], ibuf[3 * cap:3 * cap + 1]
     masks = torch.empty(cap, 2, device=dev, dtype=torch.int32) if want_masks else None
     c = index.cloud
     with _lib.device_guard(dev):
@@ -299,7 +336,7 @@ class GpgGraspSamplerPcl:
     init_bite (default: robotiq_85).  ``config`` is accepted for signature compatibility and unused, as in the
     Pcl sampler."""
 
-    def __init__(self, gripper=None, config=None, device=None, use_index=True, batch_samples=2048, fused_sweep=True):
+    def __init__(self, gripper=None, config=None, device=None, use_index=True, batch_samples=4096, fused_sweep=True):
         # sphere-culled collision kernel (identical counts).  False = brute force (debugging): it cannot skip the unused
         # tail of the capacity-sized push-in buffer and is slower even on 3,000-point clouds (3.4 vs 2.6 ms per scene).
         self.use_index = bool(use_index)
@@ -344,10 +381,13 @@ class GpgGraspSamplerPcl:
         are short-lived — scoring.detect_grasps builds one per scene — so the pool outlives them).  Several rounds are in
         flight at once, each with its own buffers; ``_unpin`` hands a buffer back once its copy has been consumed."""
         pool = _pin_pool()
-        for i, t in enumerate(pool):
-            if t.numel() >= n:
-                return pool.pop(i)
-        return torch.empty(max(n, 1 << 15), dtype=torch.float64).pin_memory()
+        best = -1
+        for i, t in enumerate(pool):                         # best fit: a small request must not take the big buffer
+            if t.numel() >= n and (best < 0 or t.numel() < pool[best].numel()):
+                best = i
+        if best >= 0:
+            return pool.pop(best)
+        return torch.empty(max(n + n // 8, 1 << 15), dtype=torch.float64).pin_memory()
 
     @staticmethod
     def _unpin(t):
@@ -387,7 +427,7 @@ class GpgGraspSamplerPcl:
         # uploads go through pinned staging buffers: a pageable copy would block the host until the device has drained
         # everything queued before it — i.e. the previous round's whole chain — and serialise the pipeline
         q_h = self._pinned(K * 3)
-        q_h[:K * 3].copy_(torch.from_numpy(np.ascontiguousarray(sel_pts).reshape(-1)))
+        q_h.numpy()[:K * 3] = np.ascontiguousarray(sel_pts).reshape(-1)      # numpy's memcpy: see _stage_chain's upload
         q_d = torch.empty(K, 3, device=dev, dtype=torch.float64)
         q_d.view(-1).copy_(q_h[:K * 3], non_blocking=True)
         M_d, _ = normal_moments(cloud_d, normals_d, q_d, r_ball, MAX_NN, index=index)
@@ -433,31 +473,37 @@ class GpgGraspSamplerPcl:
         up = np.concatenate([np.concatenate([minor, normal, major, sel_pts[live]], 1).reshape(-1), prm])
         tick("host eig+frames", dev)
         up_h = self._pinned(up.size)
-        up_h[:up.size].copy_(torch.from_numpy(up))
+        # host-side staging copies go through numpy, not torch: torch parallelises a CPU copy above 32,768 elements over its
+        # OpenMP pool (128 threads on the GPU box) whose workers then spin — under the container's 16-CPU cgroup quota that
+        # exhausted the period and throttled the whole process for ~80 ms, once per call, at rounds of >= 4,096 sample points
+        up_h.numpy()[:up.size] = up
         up_d = torch.empty(up.size, device=dev, dtype=torch.float64)
         up_d.copy_(up_h[:up.size], non_blocking=True)                                           # upload: frames + constants
         rd["up_h"] = up_h
         frames_d, prm_d = up_d[:L * 12], up_d[L * 12:]
         cap = L * R
-        f64 = dict(device=dev, dtype=torch.float64)
-        i32 = dict(device=dev, dtype=torch.int32)
-        poses = torch.empty(cap * D, 12, **f64)
-        ab = torch.empty(cap, 6, **f64)
+        f64, i32 = torch.float64, torch.int32
+        nres = 1 + L + cap * 15 + 1
+        ws = _ws_ring(dev)[rd["slot"] % 4]
+        ws.reset(dev, 8 * (cap * D * 12 + cap * 6 + cap * S * 2 * 12 + 2 * cap * S * 3 + nres) + 4 * 2 * (3 * cap + 1) + 4096)
+        poses = ws.take((cap * D, 12), f64)
+        ab = ws.take((cap, 6), f64)
         _call("pngpd_gpg_enumerate", up_d, frames_d, L, R, D, prm_d, poses, ab)
         tick("upload+enumerate", dev)
         if self.fused_sweep and index is not None:
-            flag, dsel, plist, total = sweep_select(index, poses, ab, L, R, D, boxes_d, prm_d, stats=self.sweep_stats)
+            flag, dsel, plist, total = sweep_select(index, poses, ab, L, R, D, boxes_d, prm_d, stats=self.sweep_stats,
+                                                    ibuf=ws.take((3 * cap + 1,), i32))
         else:
             cnt = hand_box_counts(cloud_d, poses, boxes_d, index=index)                         # (L*R*D,4)
-            ibuf = torch.empty(3 * cap + 1, **i32)
+            ibuf = ws.take((3 * cap + 1,), i32)
             flag, dsel, plist, total = ibuf[:cap], ibuf[cap:2 * cap], ibuf[2 * cap:3 * cap], ibuf[3 * cap:]
             _call("pngpd_gpg_select", up_d, cnt, poses, ab, L, R, D, prm_d, flag, dsel, plist, total)
         tick("sweep+select", dev)
-        poses2 = torch.empty(cap * S * 2, 12, **f64)
-        bm = torch.empty(2 * cap * S, 3, **f64)
+        poses2 = ws.take((cap * S * 2, 12), f64)
+        bm = ws.take((2 * cap * S, 3), f64)
         back, mod = bm[:cap * S], bm[cap * S:]
         _call("pngpd_gpg_pushin", up_d, plist, total, dsel, poses, ab, frames_d, L, R, D, S, prm_d, poses2, back, mod)
-        jbuf = torch.empty(3 * cap + 1, **i32)
+        jbuf = ws.take((3 * cap + 1,), i32)
         found, sfirst, olist, ototal = jbuf[:cap], jbuf[cap:2 * cap], jbuf[2 * cap:3 * cap], jbuf[3 * cap:]
         if self.fused_sweep and index is not None and S <= 32:
             pushin_sweep(index, poses2, total, L, R, S, boxes_d, MIN_OPEN_POINTS, found, sfirst, stats=self.pushin_stats)
@@ -465,8 +511,7 @@ class GpgGraspSamplerPcl:
         else:
             cnt2 = hand_box_counts(cloud_d, poses2, boxes_d, index=index, valid_units=total, per_unit=2 * S)
         tick("pushin+sweep2", dev)
-        nres = 1 + L + cap * 15 + 1
-        out = torch.empty(nres, **f64)
+        out = ws.take((nres,), f64)
         _call("pngpd_gpg_finish", up_d, cnt2, plist, total, ab, frames_d, back, mod, L, R, S, MIN_OPEN_POINTS, found,
               sfirst, olist, ototal, out)
         out[-1:].copy_(total)               # the potential-grasp count rides in the same download (it was a third sync)
@@ -496,7 +541,8 @@ class GpgGraspSamplerPcl:
         return m_zero, counts, grasps
 
     def sample_grasps(self, point_cloud, points_for_sample, all_normal, num_grasps=20, max_num_samples=200,
-                      show_final_grasp=False, sample_indices=None, seed=None, as_array=False, **kwargs):
+                      show_final_grasp=False, sample_indices=None, seed=None, as_array=False, scene_index=None,
+                      **kwargs):
         g = _gripper_dict(self.gripper)
         self.last_stats = {"draws": 0, "sampled": 0, "potential": 0}
         if isinstance(point_cloud, torch.Tensor):
@@ -514,7 +560,7 @@ class GpgGraspSamplerPcl:
         pfs = np.asarray(points_for_sample.cpu() if isinstance(points_for_sample, torch.Tensor) else points_for_sample,
                          dtype=np.float64).reshape(-1, 3)
         normals_d = torch.from_numpy(np.ascontiguousarray(all_normal)).to(dev)
-        scene = {"index": None}                                          # CloudIndex: built once per scene, lazily
+        scene = {"index": scene_index if self.use_index else None}       # CloudIndex: built once per scene, lazily
         chunks = []
         if num_grasps <= 0 or max_num_samples <= 0 or pfs.shape[0] == 0:                       # :1432 loop never entered
             return np.zeros((0, 5, 3)) if as_array else []
@@ -529,7 +575,7 @@ class GpgGraspSamplerPcl:
         # sized as if no draw of the rounds in flight had a zero moment matrix (those do not count, :1486-1489); the
         # stop rule is applied to the rounds in order, one round behind, and a stop abandons the rounds in flight.
         sampled, found, done = 0, 0, False
-        st = dict(pos=0, issued=0, credit=0)       # credit: draws issued but not yet known to count (or not)
+        st = dict(pos=0, issued=0, credit=0, rounds=0)       # credit: draws issued but not yet known to count (or not)
 
         def issue():
             want = min(self.batch_samples, max_num_samples - sampled - st["credit"])
@@ -545,7 +591,8 @@ class GpgGraspSamplerPcl:
                 draws = rng.integers(0, pfs.shape[0], size=want)
             st["pos"] += draws.size; st["issued"] += draws.size; st["credit"] += draws.size
             rd = self._stage_moments(g, cloud_d, normals_d, pfs[draws], all_normal[draws], scene)
-            rd["draws"] = draws
+            rd["draws"], rd["slot"] = draws, st["rounds"]
+            st["rounds"] += 1
             return rd
 
         lookahead = 0 if self.profile is not None else 2             # the stage profile wants one round at a time

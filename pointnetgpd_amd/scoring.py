@@ -207,11 +207,15 @@ def detect_grasps(scene_cloud, surface_normal, scorer, sampler=None, num_grasps=
         sampler = gpg.GpgGraspSamplerPcl(gripper=dict(scorer.gripper, init_bite=gpg.ROBOTIQ_85["init_bite"]), device=dev)
     pfs = pts[np.where(pts[:, 2] > select_point_above_table)[0]]                      # :141
     cloud_d = torch.as_tensor(pts).to(dev)
+    index = None
     if len(pfs) == 0:                                                                 # :142-144
         grasps = np.zeros((0, 5, 3))
     else:
+        if cloud_d.dtype not in (torch.float32, torch.float64):
+            cloud_d = cloud_d.float()
+        index = gpg.CloudIndex(cloud_d)               # ONE spatial index per scene, shared by the sampler and the crop
         grasps = sampler.sample_grasps(cloud_d, pfs, surface_normal, num_grasps, max_num_samples,
-                                       sample_indices=sample_indices, seed=seed, as_array=True)
-    res = scorer.score(cloud_d, grasps)
+                                       sample_indices=sample_indices, seed=seed, as_array=True, scene_index=index)
+    res = scorer.score(cloud_d, grasps, scene_index=index)
     res["grasps"] = grasps
     return res

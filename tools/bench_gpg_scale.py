@@ -16,7 +16,7 @@ pfs = pts32[pts32[:, 2] > 0.01]
 cloud_d = torch.from_numpy(pts32).to(dev)
 ref = None
 for fused in ([True, False] if os.environ.get("BOTH", "1") == "1" else [True]):
-    s = gpg.GpgGraspSamplerPcl(device=dev, fused_sweep=fused)
+    s = gpg.GpgGraspSamplerPcl(device=dev, fused_sweep=fused, **({"batch_samples": int(os.environ["BATCH"])} if "BATCH" in os.environ else {}))
     s.sample_grasps(cloud_d, pfs, nrm, 10 ** 9, SAMPLES, seed=0, as_array=True)   # same sizes: allocator + pinned pools warm
     torch.cuda.synchronize()
     dts = []
@@ -34,7 +34,7 @@ for fused in ([True, False] if os.environ.get("BOTH", "1") == "1" else [True]):
     assert np.array_equal(res, res2)
     if ref is None:
         ref = res
-    print(json.dumps({"P": P, "samples": SAMPLES, "fused_sweep": fused, "candidates": int(len(res)),
+    print(json.dumps({"P": P, "samples": SAMPLES, "fused_sweep": fused, "batch_samples": s.batch_samples, "candidates": int(len(res)),
                       "seconds": round(dt, 4), "candidates_per_s": round(len(res) / dt, 1),
                       "identical_to_first_variant": bool(np.array_equal(res, ref)), "stage_ms_synchronised": prof,
                       "sweep_units_chunks_passed_evaluated_exact": s.sweep_stats.tolist(),
