@@ -56,8 +56,10 @@ __device__ __forceinline__ void to_frame(const Frame &F, double x, double y, dou
 // object clouds resident in one buffer).  gather != NULL: grasp g sees the Pg points arena[gather[g][0..Pg)] (a
 // per-sample random subsample of stacked views, dataset.py:252-254).  Either way the indices written are
 // arena-absolute and in the order of the grasp's own cloud, so crop_resample runs unchanged.
-template <bool F64>
-__global__ __launch_bounds__(256) void crop_count_compact_kernel(
+// NT threads per workgroup: 256 when there are many grasps (config 5: 100,000 workgroups), 1024 when there are few (a
+// training batch of 64: the scan of a 20,000-point view is 5 trips instead of 20, each one memory latency).
+template <bool F64, int NT>
+__global__ __launch_bounds__(NT) void crop_count_compact_kernel(
     const void *__restrict__ cloud, int P, const double *__restrict__ frames, const int *__restrict__ ranges,
     const int *__restrict__ gather, int Pg, int max_keep, int *__restrict__ counts, int *__restrict__ idx,
     const int *__restrict__ item) {
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(256) void crop_count_compact_kernel(
     // and one barrier pair instead of UNR of each (a training batch is 64 workgroups on 256 CUs — latency-, not
     // throughput-bound); positions stay in ascending point order (block-major, then wave, then lane)
     constexpr int UNR = 4;
-    __shared__ int wcnt[UNR][4];
+    __shared__ int wcnt[UNR][NT / 64];
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     Frame F;
     load_frame(frames + (size_t)(item ? item[g] : g) * 18, F);   // item: frames is a per-dataset table, g's row = item[g]
@@ -75,18 +77,18 @@ __global__ __launch_bounds__(256) void crop_count_compact_kernel(
     const int n = gather ? Pg : (ranges ? ranges[2 * g + 1] : P);
     const int *gi = gather ? gather + (size_t)g * Pg : nullptr;
     const unsigned long long below = (1ull << lane) - 1ull;
-    for (int base = 0; base < n; base += 256 * UNR) {
+    for (int base = 0; base < n; base += NT * UNR) {
         bool in[UNR];
         int p[UNR];
         unsigned long long mask[UNR];
 #pragma unroll
         for (int j = 0; j < UNR; ++j) {
-            const int i = base + j * 256 + tid;
+            const int i = base + j * NT + tid;
             p[j] = i < n ? (gi ? gi[i] : p_begin + i) : 0;
         }
 #pragma unroll
         for (int j = 0; j < UNR; ++j) {
-            const int i = base + j * 256 + tid;
+            const int i = base + j * NT + tid;
             in[j] = false;
             if (i < n) {
                 double x, y, z, a, b, c;
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256) void crop_count_compact_kernel(
         for (int j = 0; j < UNR; ++j) {
             int woff = 0, total = 0;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) { const int c = wcnt[j][w]; if (w < wave) woff += c; total += c; }
+            for (int w = 0; w < NT / 64; ++w) { const int c = wcnt[j][w]; if (w < wave) woff += c; total += c; }
             if (in[j]) {
                 const int pos = running + woff + __popcll(mask[j] & below);
                 if (pos < max_keep) out[pos] = p[j];
@@ -293,6 +295,9 @@ __device__ __forceinline__ void crop_resample_body(
             for (int i = tid; i < m; i += 256) c += keys[i] <= T ? 1 : 0;
             return crop_block_sum(c, shi);
         };
+        // (a 4-level radix select over these LDS keys — histogram + bin walk per byte, as the overflow path above — was
+        // measured here and is SLOWER at config-5 scale: 3,248 keys per hand contend on 256 LDS bins, resample of
+        // 100,000 hands 5.5 -> 6.2 ms; and a training batch does not notice either way)
         unsigned lo = 0u, hi = 0xFFFFFFFFu;            // smallest T with #(key <= T) >= N   (m >= N here)
         while (lo < hi) {
             const unsigned mid = lo + ((hi - lo) >> 1);
@@ -535,10 +540,10 @@ int pngpd_crop_count_compact(const void *cloud, int cloud_is_f64, int P, const d
                              int max_keep, int *counts, int *idx, void *stream) {
     if (!cloud || !frames || !counts || !idx || P <= 0 || G <= 0 || max_keep <= 0) return PNGPD_ERR_INVALID_ARG;
     if (cloud_is_f64)
-        hipLaunchKernelGGL(crop_count_compact_kernel<true>, dim3(G), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((crop_count_compact_kernel<true, 256>), dim3(G), dim3(256), 0, (hipStream_t)stream,
                            cloud, P, frames, (const int *)nullptr, (const int *)nullptr, 0, max_keep, counts, idx, (const int *)nullptr);
     else
-        hipLaunchKernelGGL(crop_count_compact_kernel<false>, dim3(G), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((crop_count_compact_kernel<false, 256>), dim3(G), dim3(256), 0, (hipStream_t)stream,
                            cloud, P, frames, (const int *)nullptr, (const int *)nullptr, 0, max_keep, counts, idx, (const int *)nullptr);
     return pngpd_launch_status();
 }
@@ -548,10 +553,10 @@ int pngpd_crop_count_compact_ranges(const void *arena, int cloud_is_f64, int P, 
     if (!arena || !frames || !ranges || !counts || !idx || P <= 0 || G <= 0 || max_keep <= 0)
         return PNGPD_ERR_INVALID_ARG;
     if (cloud_is_f64)
-        hipLaunchKernelGGL(crop_count_compact_kernel<true>, dim3(G), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((crop_count_compact_kernel<true, 256>), dim3(G), dim3(256), 0, (hipStream_t)stream,
                            arena, P, frames, ranges, (const int *)nullptr, 0, max_keep, counts, idx, (const int *)nullptr);
     else
-        hipLaunchKernelGGL(crop_count_compact_kernel<false>, dim3(G), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((crop_count_compact_kernel<false, 256>), dim3(G), dim3(256), 0, (hipStream_t)stream,
                            arena, P, frames, ranges, (const int *)nullptr, 0, max_keep, counts, idx, (const int *)nullptr);
     return pngpd_launch_status();
 }
@@ -562,10 +567,10 @@ int pngpd_crop_count_compact_gather(const void *arena, int cloud_is_f64, int P, 
     if (!arena || !frames || !gather || !counts || !idx || P <= 0 || Pg <= 0 || G <= 0 || max_keep <= 0)
         return PNGPD_ERR_INVALID_ARG;
     if (cloud_is_f64)
-        hipLaunchKernelGGL(crop_count_compact_kernel<true>, dim3(G), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((crop_count_compact_kernel<true, 256>), dim3(G), dim3(256), 0, (hipStream_t)stream,
                            arena, P, frames, (const int *)nullptr, gather, Pg, max_keep, counts, idx, (const int *)nullptr);
     else
-        hipLaunchKernelGGL(crop_count_compact_kernel<false>, dim3(G), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((crop_count_compact_kernel<false, 256>), dim3(G), dim3(256), 0, (hipStream_t)stream,
                            arena, P, frames, (const int *)nullptr, gather, Pg, max_keep, counts, idx, (const int *)nullptr);
     return pngpd_launch_status();
 }
@@ -627,12 +632,14 @@ int pngpd_train_batch(const void *arena, int arena_is_f64, int P, const double *
         const int rc = pngpd_stack_gather_lists(spans, k_views, Pg, G, seed ^ 0x5bd1e995a3c59ac3ull, g_base, gather_ws, stream);
         if (rc != PNGPD_OK) return rc;
     }
+    // a training batch is few workgroups on 256 CUs: 1024 threads each (sanitizer builds: 256, see pngpd_common.h)
+    constexpr int CNT = PNGPD_ASAN ? 256 : 1024;
     if (arena_is_f64)
-        hipLaunchKernelGGL(crop_count_compact_kernel<true>, dim3(G), dim3(256), 0, st, arena, P, frames, ranges, gather,
-                           k_views ? Pg : 0, max_keep, counts, idx, item);
+        hipLaunchKernelGGL((crop_count_compact_kernel<true, CNT>), dim3(G), dim3(CNT), 0, st, arena, P, frames, ranges,
+                           gather, k_views ? Pg : 0, max_keep, counts, idx, item);
     else
-        hipLaunchKernelGGL(crop_count_compact_kernel<false>, dim3(G), dim3(256), 0, st, arena, P, frames, ranges, gather,
-                           k_views ? Pg : 0, max_keep, counts, idx, item);
+        hipLaunchKernelGGL((crop_count_compact_kernel<false, CNT>), dim3(G), dim3(CNT), 0, st, arena, P, frames, ranges,
+                           gather, k_views ? Pg : 0, max_keep, counts, idx, item);
     int rc = pngpd_launch_status();
     if (rc != PNGPD_OK) return rc;
     hipLaunchKernelGGL(batch_keep_rows_kernel, dim3(1), dim3(KEEP_NT), 0, st, counts, labels, G, min_points, rows,
