@@ -61,7 +61,7 @@ __device__ __forceinline__ unsigned sw_wave_or(unsigned v) {
 // flag / dsel (LR): gpg_select_kernel's outputs (dsel is meaningful where flag is set).  masks (LR,2) or NULL: the
 // opening / collision bit masks (bit d) of EVERY unit (no pruning then).
 template <bool F64>
-__global__ __launch_bounds__(256) void gpg_sweep_select_kernel(
+__global__ __launch_bounds__(256, 4) void gpg_sweep_select_kernel(
     const void *__restrict__ cloud, int P, const double *__restrict__ spheres, int C,
     const double *__restrict__ poses, const double *__restrict__ ab, int LR, int D,
     const double *__restrict__ boxes, const double *__restrict__ prm, double tol, int *__restrict__ flag,
