@@ -234,9 +234,9 @@ static int run() {
             for (int v = 0; v < K; ++v) { spansk[(gi * K + v) * 2] = ((gi + v) * 197) % (P - 600); spansk[(gi * K + v) * 2 + 1] = 300 + 100 * v; }
         }
         spans1[1] = P; spans1[0] = 0;                                       // one sample sees the whole arena
-        double *dfrt; long long *dlab, *dlabo; int *ditem, *dsp1, *dspk, *dgat, *drows, *dnk;
+        double *dfrt; long long *dlab, *dlabo; int *ditem, *dsp1, *dspk, *dgat, *drows, *dnk, *dseg;
         if (upload(frt, &dfrt) || upload(lab, &dlab) || upload(item, &ditem) || upload(spans1, &dsp1) || upload(spansk, &dspk) ||
-            dalloc(&dgat, (size_t)GB * Pg) || dalloc(&drows, GB) || dalloc(&dnk, 1) || dalloc(&dlabo, GB)) return 2;
+            dalloc(&dgat, (size_t)GB * Pg) || dalloc(&drows, GB) || dalloc(&dnk, 1) || dalloc(&dlabo, GB) || dalloc(&dseg, (size_t)GB * 4)) return 2;
         PN_OK(pngpd_stack_gather_lists(dspk, K, Pg, GB, 11ull, 3ll, dgat, st));
         HIP_OK(hipStreamSynchronize(st));
         {   // every drawn row lies inside one of its sample's view spans
@@ -264,7 +264,7 @@ static int run() {
         std::printf("crop_resample into compacted rows ok\n");
         for (int kv = 0; kv < 2; ++kv) {
             PN_OK(pngpd_train_batch(dpc64, 1, P, dfrt, dlab, ditem, kv ? dspk : dsp1, kv ? K : 0, kv ? Pg : 0, dgat, GB, MAXK, N, 50,
-                                    21ull + kv, 100ll, dcnt, didx, drows, dvalid, dout, dlabo, dnk, st));
+                                    21ull + kv, 100ll, dcnt, didx, drows, dvalid, dseg, dout, dlabo, dnk, st));
             HIP_OK(hipStreamSynchronize(st));
             std::vector<int> rows(GB), nk(1), cn(GB);
             if (download(drows, rows) || download(dnk, nk) || download(dcnt, cn)) return 2;
@@ -279,6 +279,27 @@ static int run() {
         }
         PN_OK(pngpd_batch_keep_rows(dcnt, dlab, GB, 50, drows, dlabo, dnk, st));
         HIP_OK(hipStreamSynchronize(st));
+        {   // long sample clouds (>= 16384 rows): the segmented two-launch scan against the one-workgroup scan
+            const int PgL = 16501;
+            int *dgatL;
+            if (dalloc(&dgatL, (size_t)GB * PgL)) return 2;
+            std::vector<int> cn[2], ix[2];
+            for (int seg = 0; seg < 2; ++seg) {
+                PN_OK(pngpd_train_batch(dpc64, 1, P, dfrt, dlab, ditem, dspk, K, PgL, dgatL, GB, MAXK, N, 50, 23ull, 100ll, dcnt,
+                                        didx, drows, dvalid, seg ? dseg : nullptr, dout, dlabo, dnk, st));
+                HIP_OK(hipStreamSynchronize(st));
+                cn[seg].resize(GB); ix[seg].resize((size_t)GB * MAXK);
+                if (download(dcnt, cn[seg]) || download(didx, ix[seg])) return 2;
+            }
+            for (int gi = 0; gi < GB; ++gi) {
+                if (cn[0][gi] != cn[1][gi]) { std::fprintf(stderr, "segmented scan: count mismatch\n"); return 4; }
+                const int m = cn[0][gi] < MAXK ? cn[0][gi] : MAXK;
+                for (int i = 0; i < m; ++i)
+                    if (ix[0][(size_t)gi * MAXK + i] != ix[1][(size_t)gi * MAXK + i]) { std::fprintf(stderr, "segmented scan: list mismatch\n"); return 4; }
+            }
+            std::printf("train_batch segmented scan == single pass (Pg %d)\n", PgL);
+            hipFree(dgatL);
+        }
     }
 
     // =====================================================================================================

@@ -497,13 +497,15 @@ int pngpd_stack_gather_lists(const int *spans, int k_views, int Pg, int G, unsig
  * per-DATASET tables resident in HBM; item (G) int32 = this batch's rows of them (an epoch's permutation slice).
  * k_views == 0: one-view datasets, spans (G,2) = the arena range of the view drawn for each sample;
  * k_views  > 0: full-view datasets, spans (G,k_views,2), gather_ws (G,Pg) int32 scratch.
- * Scratch: counts (G), idx (G,max_keep), rows (G), valid (G).  Outputs: out (>= kept,3,N) fp32, labels_out (G)
+ * Scratch: counts (G), idx (G,max_keep), rows (G), valid (G), seg_scratch (4 G) int32 or NULL (with it, the scan of a
+ * long full-view sample cloud — Pg >= 16384 — is cut into 4 segments per sample, two launches: same lists).  Outputs: out (>= kept,3,N) fp32, labels_out (G)
  * int64 (first kept entries), *n_keep (int32; device memory, or device-visible pinned host memory — the host then
  * reads the kept count after the stream's next event without a copy launch).  Draws keyed by (seed, g_base + g).   */
 int pngpd_train_batch(const void *arena, int arena_is_f64, int P, const double *frames, const long long *labels,
                       const int *item, const int *spans, int k_views, int Pg, int *gather_ws, int G, int max_keep,
                       int N, int min_points, unsigned long long seed, long long g_base, int *counts, int *idx,
-                      int *rows, unsigned char *valid, float *out, long long *labels_out, int *n_keep, void *stream);
+                      int *rows, unsigned char *valid, int *seg_scratch, float *out, long long *labels_out, int *n_keep,
+                      void *stream);
 
 /* =======================================================================================
  * GPG grasp-candidate sampler, device half (upstream of the crop at inference) —

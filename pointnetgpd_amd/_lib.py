@@ -157,7 +157,7 @@ SIGNATURES = {
                                                 ctypes.c_longlong, c_void, c_void]),
     "pngpd_train_batch": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, c_void, c_void, c_void, ctypes.c_int,
                                          ctypes.c_int, c_void, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                         ctypes.c_ulonglong, ctypes.c_longlong] + [c_void] * 8),
+                                         ctypes.c_ulonglong, ctypes.c_longlong] + [c_void] * 9),
     # ---- GPG sampler (device half)
     "pngpd_gpg_normal_moments": (ctypes.c_int, [c_void, ctypes.c_int, c_void, ctypes.c_int, c_void, ctypes.c_int,
                                                 ctypes.c_double, ctypes.c_int, c_void, c_void, c_void]),

@@ -62,7 +62,12 @@ template <bool F64, int NT>
 __global__ __launch_bounds__(NT) void crop_count_compact_kernel(
     const void *__restrict__ cloud, int P, const double *__restrict__ frames, const int *__restrict__ ranges,
     const int *__restrict__ gather, int Pg, int max_keep, int *__restrict__ counts, int *__restrict__ idx,
-    const int *__restrict__ item) {
+    const int *__restrict__ item, int *__restrict__ seg_counts = nullptr, int phase = 0) {
+    // Segmented form (gridDim.y = SEG > 1, a training batch of few samples with LONG clouds — 64 x 50,000 gathered rows in
+    // the full-view datasets): a sample's rows are cut into SEG consecutive segments, one workgroup each, in two launches —
+    // phase 1 counts a segment's in-box rows into seg_counts (g, SEG); phase 2 scans again and writes from the offset the
+    // preceding segments' counts give, so the list keeps the single-pass order.  Twice the loads, SEG x the workgroups:
+    // the scan is a chain of dependent random reads, i.e. latency (0.12 -> ~0.04 ms per full-view batch).
     // UNR blocks of 256 points per trip: the UNR loads of a thread are independent, so a trip costs ONE memory latency
     // and one barrier pair instead of UNR of each (a training batch is 64 workgroups on 256 CUs — latency-, not
     // throughput-bound); positions stay in ascending point order (block-major, then wave, then lane)
@@ -74,10 +79,37 @@ __global__ __launch_bounds__(NT) void crop_count_compact_kernel(
     int running = 0;
     int *out = idx + (size_t)g * max_keep;
     const int p_begin = (!gather && ranges) ? ranges[2 * g] : 0;
-    const int n = gather ? Pg : (ranges ? ranges[2 * g + 1] : P);
+    const int n_all = gather ? Pg : (ranges ? ranges[2 * g + 1] : P);
     const int *gi = gather ? gather + (size_t)g * Pg : nullptr;
     const unsigned long long below = (1ull << lane) - 1ull;
-    for (int base = 0; base < n; base += NT * UNR) {
+    const int SEG = gridDim.y, seg = blockIdx.y;
+    const int seg_len = (n_all + SEG - 1) / SEG;
+    const int i0 = seg * seg_len;
+    const int n = i0 + seg_len < n_all ? i0 + seg_len : n_all;      // this workgroup scans rows [i0, n)
+    if (phase == 2)
+        for (int s2 = 0; s2 < seg; ++s2) running += seg_counts[(size_t)g * SEG + s2];
+    if (phase == 1) {                                               // count only: no order needed, no barriers per trip
+        int c = 0;
+#pragma unroll 4
+        for (int i = i0 + tid; i < n; i += NT) {
+            const int p = gi ? gi[i] : p_begin + i;
+            double x, y, z, a, b, cc;
+            load_point<F64>(cloud, p, x, y, z);
+            to_frame(F, x, y, z, a, b, cc);
+            c += ((a > F.lo[0]) && (a < F.hi[0]) && (b > F.lo[1]) && (b < F.hi[1]) && (cc > F.lo[2]) && (cc < F.hi[2])) ? 1 : 0;
+        }
+#pragma unroll
+        for (int k = 32; k >= 1; k >>= 1) c += __shfl_xor(c, k);
+        if (lane == 0) wcnt[0][wave] = c;
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int w = 0; w < NT / 64; ++w) t += wcnt[0][w];
+            seg_counts[(size_t)g * SEG + seg] = t;
+        }
+        return;
+    }
+    for (int base = i0; base < n; base += NT * UNR) {
         bool in[UNR];
         int p[UNR];
         unsigned long long mask[UNR];
@@ -115,6 +147,14 @@ __global__ __launch_bounds__(NT) void crop_count_compact_kernel(
             running += total;
         }
         __syncthreads();
+    }
+    if (phase == 2) {
+        if (tid == 0 && seg == 0) {
+            int t = 0;
+            for (int s2 = 0; s2 < SEG; ++s2) t += seg_counts[(size_t)g * SEG + s2];
+            counts[g] = t;
+        }
+        return;
     }
     if (tid == 0) counts[g] = running;
 }
@@ -619,7 +659,8 @@ int pngpd_stack_gather_lists(const int *spans, int k_views, int Pg, int G, unsig
 int pngpd_train_batch(const void *arena, int arena_is_f64, int P, const double *frames, const long long *labels,
                       const int *item, const int *spans, int k_views, int Pg, int *gather_ws, int G, int max_keep,
                       int N, int min_points, unsigned long long seed, long long g_base, int *counts, int *idx,
-                      int *rows, unsigned char *valid, float *out, long long *labels_out, int *n_keep, void *stream) {
+                      int *rows, unsigned char *valid, int *seg_scratch, float *out, long long *labels_out, int *n_keep,
+                      void *stream) {
     if (!arena || !frames || !labels || !spans || !counts || !idx || !rows || !valid || !out || !labels_out ||
         !n_keep || P <= 0 || G <= 0 || max_keep <= 0 || N <= 0 || k_views < 0 || (k_views > 0 && (!gather_ws || Pg <= 0)))
         return PNGPD_ERR_INVALID_ARG;
@@ -632,14 +673,19 @@ int pngpd_train_batch(const void *arena, int arena_is_f64, int P, const double *
         const int rc = pngpd_stack_gather_lists(spans, k_views, Pg, G, seed ^ 0x5bd1e995a3c59ac3ull, g_base, gather_ws, stream);
         if (rc != PNGPD_OK) return rc;
     }
-    // a training batch is few workgroups on 256 CUs: 1024 threads each (sanitizer builds: 256, see pngpd_common.h)
+    // a training batch is few workgroups on 256 CUs: 1024 threads each (sanitizer builds: 256, see pngpd_common.h); long
+    // gathered clouds are additionally cut into 4 segments per sample when the caller provides the scratch for it
     constexpr int CNT = PNGPD_ASAN ? 256 : 1024;
-    if (arena_is_f64)
-        hipLaunchKernelGGL((crop_count_compact_kernel<true, CNT>), dim3(G), dim3(CNT), 0, st, arena, P, frames, ranges,
-                           gather, k_views ? Pg : 0, max_keep, counts, idx, item);
-    else
-        hipLaunchKernelGGL((crop_count_compact_kernel<false, CNT>), dim3(G), dim3(CNT), 0, st, arena, P, frames, ranges,
-                           gather, k_views ? Pg : 0, max_keep, counts, idx, item);
+    const int SEG = (seg_scratch && k_views && Pg >= 16384 && G <= 1024) ? 4 : 1;
+    int *segc = SEG > 1 ? seg_scratch : nullptr;
+    for (int phase = (SEG > 1 ? 1 : 0); phase <= (SEG > 1 ? 2 : 0); ++phase) {
+        if (arena_is_f64)
+            hipLaunchKernelGGL((crop_count_compact_kernel<true, CNT>), dim3(G, SEG), dim3(CNT), 0, st, arena, P, frames,
+                               ranges, gather, k_views ? Pg : 0, max_keep, counts, idx, item, segc, phase);
+        else
+            hipLaunchKernelGGL((crop_count_compact_kernel<false, CNT>), dim3(G, SEG), dim3(CNT), 0, st, arena, P, frames,
+                               ranges, gather, k_views ? Pg : 0, max_keep, counts, idx, item, segc, phase);
+    }
     int rc = pngpd_launch_status();
     if (rc != PNGPD_OK) return rc;
     hipLaunchKernelGGL(batch_keep_rows_kernel, dim3(1), dim3(KEEP_NT), 0, st, counts, labels, G, min_points, rows,

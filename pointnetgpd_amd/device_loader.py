@@ -48,15 +48,19 @@ class _Slot:
         self.rows = torch.empty(B, device=dev, dtype=torch.int32)
         self.valid = torch.empty(B, device=dev, dtype=torch.uint8)
         self.gather = torch.empty(B, Pg, device=dev, dtype=torch.int32) if Pg else None
+        self.seg = torch.empty(4 * B, device=dev, dtype=torch.int32)      # segment counts of the two-launch scan
         self.pin = torch.zeros((), dtype=torch.int32).pin_memory()
         self.pin_np = self.pin.numpy()                       # the same 4 bytes, read without a tensor op
         self.event = torch.cuda.Event()
         self.counts_ptr, self.idx_ptr, self.rows_ptr = self.counts.data_ptr(), self.idx.data_ptr(), self.rows.data_ptr()
         self.valid_ptr, self.pin_ptr = self.valid.data_ptr(), self.pin.data_ptr()
         self.gather_ptr = self.gather.data_ptr() if Pg else None
+        self.seg_ptr = self.seg.data_ptr()
 
 
 class DeviceGraspLoader:
+    segmented_scan = True       # long full-view sample clouds: 4 workgroups per sample, two launches (same batches)
+
     """Iterable of ``(data (B',3,N) fp32 CUDA, target (B',) int64 CUDA)`` batches over one of the four mirror
     datasets of ``model.dataset`` (one-view and full-view, 2- and 3-class).  ``len()`` = batches per epoch.
     ``last_meta`` holds, for the most recent batch, the item indices, the chosen view files, the in-box counts, the
@@ -172,6 +176,7 @@ class DeviceGraspLoader:
         args = (ep["arena"], ep["f64"], ep["P"], ep["frames"], ep["labels"], ep["order"] + 4 * s,
                 ep["spans"] + ep["span_stride"] * s, ep["k"], ep["Pg"], slot.gather_ptr, G, self.max_keep, ep["N"],
                 ep["min_pts"], ep["seed"], s, slot.counts_ptr, slot.idx_ptr, slot.rows_ptr, slot.valid_ptr,
+                slot.seg_ptr if self.segmented_scan else None,
                 out.data_ptr(), labels_out.data_ptr(), slot.pin_ptr, stream.cuda_stream)
         if ep["guard"]:                                       # another device is current: the slow, guarded launch
             with torch.cuda.device(self.device):

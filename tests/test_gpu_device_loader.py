@@ -189,6 +189,41 @@ def test_overlapped_and_serial_loaders_yield_identical_batches(fullview, tmp_pat
         assert torch.equal(d0, d1) and torch.equal(t0, t1)
 
 
+def test_segmented_scan_of_long_sample_clouds_is_the_single_pass_scan(tmp_path, monkeypatch, cuda_device):
+    """Full-view sample clouds of >= 16384 rows are scanned by 4 workgroups per sample in two launches (segment counts,
+    then ordered writes): counts, in-box lists and therefore the batches are those of the one-workgroup scan, and the
+    counts are the mirror's numpy crop of the same gathered rows."""
+    from pointnetgpd_amd import crop
+    from pointnetgpd_amd.device_loader import DeviceGraspLoader
+    from pointnetgpd_amd.model import dataset as ds_mod
+    root = synth_dataset.build(str(tmp_path / "tree"), grasps_per_obj=20, points=9000)
+    monkeypatch.setenv("PointNetGPD_FOLDER", root)
+    ds = ds_mod.PointGraspMultiClassDataset(obj_points_num=20001, grasp_points_num=300, pc_file_used_num=3,
+                                            grasp_amount_per_file=20, thresh_good=0.5, thresh_bad=1.2, tag="train")
+    out = {}
+    for seg in (True, False):
+        ld = DeviceGraspLoader(ds, 16, cuda_device, seed=11, prefetch=0, max_keep=16384)
+        ld.segmented_scan = seg
+        got = []
+        for d, t in ld:
+            m = ld.last_meta
+            got.append((d.clone(), t.clone(), m["counts"].clone(), m["gather"].clone(), list(m["items"])))
+        out[seg] = got
+    arena = ld.arena.cpu().numpy()
+    assert len(out[True]) == len(out[False]) and sum(d.shape[0] for d, *_ in out[True]) > 0
+    for (d0, t0, c0, g0, it0), (d1, t1, c1, g1, it1) in zip(out[True], out[False]):
+        assert torch.equal(g0, g1) and torch.equal(c0, c1) and it0 == it1
+        assert d0.shape == d1.shape and torch.equal(d0, d1) and torch.equal(t0, t1)
+    d0, t0, c0, g0, it0 = out[True][0]
+    assert g0.shape[1] == 20001 and int(c0.max()) > 0
+    for i, item in enumerate(it0[:6]):
+        oi, gi = np.unravel_index(item, (len(ds.object), ds.grasp_amount_per_file))
+        obj = ds.object[oi]
+        frame = crop.frames_from_grasps_train(np.load(ds.d_grasp[obj])[gi][None, :], ds.transform[obj][1])[0]
+        ind, _ = crop.collect_pc_numpy(frame, arena[g0[i].cpu().numpy()])
+        assert int(c0[i]) == len(ind)
+
+
 def test_device_loader_rank_shards_cover_the_epoch(tmp_path, monkeypatch, cuda_device):
     """One process per GPU: the ranks' strided shares of one epoch's permutation are disjoint up to the wrap-around
     padding and cover every item (DistributedSampler's contract, main_1v.py:120-128 under torchrun)."""
