@@ -526,6 +526,55 @@ static int run() {
         double a = 0;
         for (float v : h2) a += std::fabs(v);
         std::printf("gpd_stem abs %.6e\n", a);
+        // the training form of the two stages and their backward (main_1v_gpd.py:105): outputs equal the inference form,
+        // the second stage's weight / bias / input gradients against plain host loops over the recorded window positions
+        {
+            unsigned char *da1, *da2;
+            float *dt1, *dt2, *dg2, *ddw2, *ddb2, *ddp1, *ddw1, *ddb1, *dws;
+            const size_t ws2 = pngpd_conv5_pool2_bwd_workspace_bytes(Bc, 20, 50), ws1 = pngpd_conv5_pool2_bwd_workspace_bytes(Bc, 12, 20);
+            const size_t wsb = ws1 > ws2 ? ws1 : ws2;
+            std::vector<float> g2((size_t)Bc * 50 * 144);
+            for (auto &v : g2) v = (float)g.next() - 0.5f;
+            if (dalloc(&da1, (size_t)Bc * 20 * 784) || dalloc(&da2, (size_t)Bc * 50 * 144) || dalloc(&dt1, (size_t)Bc * 20 * 784) ||
+                dalloc(&dt2, (size_t)Bc * 50 * 144) || upload(g2, &dg2) || dalloc(&ddw2, (size_t)50 * 20 * 25) || dalloc(&ddb2, 50) ||
+                dalloc(&ddp1, (size_t)Bc * 20 * 784) || dalloc(&ddw1, (size_t)20 * 12 * 25) || dalloc(&ddb1, 20) ||
+                dalloc(&dws, wsb / sizeof(float) + 1)) return 2;
+            PN_OK(pngpd_conv5_pool2_arg(din, Bc, 12, 60, dw1, db1, 20, dt1, da1, st));
+            PN_OK(pngpd_conv5_pool2_arg(dt1, Bc, 20, 28, dw2, db2, 50, dt2, da2, st));
+            PN_OK(pngpd_conv5_pool2_bwd(dt1, Bc, 20, 28, dw2, 50, dg2, da2, ddw2, ddb2, ddp1, dws, wsb, st));
+            PN_OK(pngpd_conv5_pool2_bwd(din, Bc, 12, 60, dw1, 20, ddp1, da1, ddw1, ddb1, nullptr, dws, wsb, st));
+            PN_OK(pngpd_relu_bwd(dt2, dg2, (long long)Bc * 50 * 144, st));
+            HIP_OK(hipStreamSynchronize(st));
+            std::vector<float> t1((size_t)Bc * 20 * 784), t2((size_t)Bc * 50 * 144), gw2((size_t)50 * 20 * 25), gb2(50), gp1((size_t)Bc * 20 * 784),
+                gw1((size_t)20 * 12 * 25), gb1(20);
+            std::vector<unsigned char> a2((size_t)Bc * 50 * 144);
+            if (download(dt1, t1) || download(dt2, t2) || download(da2, a2) || download(ddw2, gw2) || download(ddb2, gb2) ||
+                download(ddp1, gp1) || download(ddw1, gw1) || download(ddb1, gb1)) return 2;
+            for (size_t i = 0; i < t2.size(); ++i)
+                if (t2[i] != h2[i]) { std::fprintf(stderr, "conv5_pool2_arg: output differs from conv5_pool2\n"); return 4; }
+            std::vector<double> rw((size_t)50 * 20 * 25, 0.0), rb(50, 0.0), rp((size_t)Bc * 20 * 784, 0.0);
+            for (int b = 0; b < Bc; ++b)
+                for (int oc = 0; oc < 50; ++oc)
+                    for (int pp = 0; pp < 144; ++pp) {
+                        const size_t idx = ((size_t)b * 50 + oc) * 144 + pp;
+                        const int code = a2[idx], y = 2 * (pp / 12) + (code >> 1), x = 2 * (pp % 12) + (code & 1);
+                        const double gv = g2[idx];
+                        rb[oc] += gv;
+                        for (int ic = 0; ic < 20; ++ic)
+                            for (int ky = 0; ky < 5; ++ky)
+                                for (int kx = 0; kx < 5; ++kx) {
+                                    rw[((size_t)oc * 20 + ic) * 25 + ky * 5 + kx] += gv * t1[(((size_t)b * 20 + ic) * 28 + y + ky) * 28 + x + kx];
+                                    rp[(((size_t)b * 20 + ic) * 28 + y + ky) * 28 + x + kx] += gv * w2[((size_t)oc * 20 + ic) * 25 + ky * 5 + kx];
+                                }
+                    }
+            double ew = 0, eb = 0, ep = 0, s1 = 0;
+            for (size_t i = 0; i < rw.size(); ++i) ew = std::fmax(ew, std::fabs(rw[i] - gw2[i]));
+            for (size_t i = 0; i < rb.size(); ++i) eb = std::fmax(eb, std::fabs(rb[i] - gb2[i]));
+            for (size_t i = 0; i < rp.size(); ++i) ep = std::fmax(ep, std::fabs(rp[i] - gp1[i]));
+            for (float v : gw1) s1 += std::fabs(v);
+            std::printf("conv5_pool2_bwd max err dW %.2e db %.2e din %.2e; stage-1 |dW| %.6e\n", ew, eb, ep, s1);
+            if (ew > 2e-3 || eb > 2e-4 || ep > 2e-4 || !(s1 > 0)) { std::fprintf(stderr, "conv5_pool2_bwd mismatch\n"); return 4; }
+        }
     }
     std::printf("index consumer done\n");
     return 0;

@@ -248,10 +248,11 @@ __global__ __launch_bounds__(256) void depth_emit_kernel(const double *__restric
 // accumulates the 2x2 window's four convolution results for its OCG channels from a 6x6 input window.
 // The two FC layers run on pngpd_fc_fwd (MFMA).
 // ---------------------------------------------------------------------------------------
-template <int OCG, int CCH>
+template <int OCG, int CCH, bool ARG>
 __global__ __launch_bounds__(256) void conv5_pool2_kernel(const float *__restrict__ in, int Cin, int Hin,
                                                           const float *__restrict__ W, const float *__restrict__ bias,
-                                                          int Cout, float *__restrict__ out) {
+                                                          int Cout, float *__restrict__ out,
+                                                          unsigned char *__restrict__ arg) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int Hc = Hin - 4, Hp = Hc / 2;                       // conv output / pooled output size (square images)
     float *plane = sm;                                          // [CCH][Hin*Hin]
@@ -309,6 +310,15 @@ __global__ __launch_bounds__(256) void conv5_pool2_kernel(const float *__restric
                 if (oc < Cout) {
                     const float m = fmaxf(fmaxf(acc[q][0], acc[q][1]), fmaxf(acc[q][2], acc[q][3])) + bias[oc];
                     out[(((size_t)b * Cout + oc) * Hp + py) * Hp + px] = m;
+                    if (ARG) {      // which of the window's four positions the maximum came from: the FIRST in row-major
+                                    // order on a tie, like ATen's max_pool2d scan (strict >) — where its backward routes
+                        int code = 0;
+                        float mv = acc[q][0];
+                        if (acc[q][1] > mv) { mv = acc[q][1]; code = 1; }
+                        if (acc[q][2] > mv) { mv = acc[q][2]; code = 2; }
+                        if (acc[q][3] > mv) { code = 3; }
+                        arg[(((size_t)b * Cout + oc) * Hp + py) * Hp + px] = (unsigned char)code;
+                    }
                 }
             }
         }
@@ -364,21 +374,37 @@ int pngpd_depth_to_cloud(const double *depth, int h, int w, const double *cam28,
     return pngpd_launch_status();
 }
 
-int pngpd_conv5_pool2(const float *in, int B, int Cin, int Hin, const float *W, const float *bias, int Cout,
-                      float *out, void *stream) {
+static int conv5_pool2_launch(const float *in, int B, int Cin, int Hin, const float *W, const float *bias, int Cout,
+                              float *out, unsigned char *arg, void *stream) {
     if (!in || !W || !bias || !out || B <= 0 || Cin <= 0 || Cout <= 0 || Hin < 6 || ((Hin - 4) & 1))
         return PNGPD_ERR_INVALID_ARG;
     constexpr int OCG = 5, CCH = 4;
     const size_t lds = ((size_t)CCH * Hin * Hin + (size_t)OCG * CCH * 25) * sizeof(float);
     if (lds > 150 * 1024) return PNGPD_ERR_UNSUPPORTED;
-    int st = pngpd_allow_lds((const void *)conv5_pool2_kernel<OCG, CCH>, lds);
+    int st = pngpd_allow_lds(arg ? (const void *)conv5_pool2_kernel<OCG, CCH, true>
+                                 : (const void *)conv5_pool2_kernel<OCG, CCH, false>, lds);
     if (st != PNGPD_OK) return st;
     const int ngroups = (Cout + OCG - 1) / OCG;
     const int Hp = (Hin - 4) / 2;
-    hipLaunchKernelGGL((conv5_pool2_kernel<OCG, CCH>), dim3((unsigned)B * ngroups, (Hp * Hp + 255) / 256), dim3(256), lds,
-                       (hipStream_t)stream,
-                       in, Cin, Hin, W, bias, Cout, out);
+    const dim3 grid((unsigned)B * ngroups, (Hp * Hp + 255) / 256);
+    if (arg)
+        hipLaunchKernelGGL((conv5_pool2_kernel<OCG, CCH, true>), grid, dim3(256), lds, (hipStream_t)stream,
+                           in, Cin, Hin, W, bias, Cout, out, arg);
+    else
+        hipLaunchKernelGGL((conv5_pool2_kernel<OCG, CCH, false>), grid, dim3(256), lds, (hipStream_t)stream,
+                           in, Cin, Hin, W, bias, Cout, out, arg);
     return pngpd_launch_status();
+}
+
+int pngpd_conv5_pool2(const float *in, int B, int Cin, int Hin, const float *W, const float *bias, int Cout,
+                      float *out, void *stream) {
+    return conv5_pool2_launch(in, B, Cin, Hin, W, bias, Cout, out, nullptr, stream);
+}
+
+int pngpd_conv5_pool2_arg(const float *in, int B, int Cin, int Hin, const float *W, const float *bias, int Cout,
+                          float *out, unsigned char *arg, void *stream) {
+    if (!arg) return PNGPD_ERR_INVALID_ARG;
+    return conv5_pool2_launch(in, B, Cin, Hin, W, bias, Cout, out, arg, stream);
 }
 
 }  // extern "C"

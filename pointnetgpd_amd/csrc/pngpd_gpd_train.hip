@@ -1,0 +1,250 @@
+// libpngpd — backward of the GPD comparator's convolution stages:
+//   GPDClassifier  conv(5x5) -> MaxPool2d(2,2), twice      PointNetGPD/model/gpd.py:13-24
+//   trained by     loss.backward()                         PointNetGPD/main_1v_gpd.py:105
+// The forward (pngpd_conv5_pool2_arg, pngpd_gpd.hip) records which of the four window positions each pooled pixel took;
+// the gradient of a stage is therefore SPARSE in the convolution's output — one position per pooled pixel — and neither
+// kernel below materialises it in HBM:
+//   * weights / bias: a workgroup owns (5 output channels, <= 5 input planes, a slice of the batch); the planes and the
+//     pooled gradients (as a list of (offset, value)) are staged in LDS, a thread owns one (plane, ky, kx) tap and
+//     walks the list.  Per-slice partial sums, reduced in a fixed order by a second launch: deterministic, no atomics.
+//   * input (the second stage only — the first stage's input is the image): a workgroup owns (sample, 4 input planes);
+//     the sparse gradient of 25 output channels is expanded into zero-padded planes in LDS and every thread evaluates
+//     the full correlation for a 1x4 strip of pixels with the 100 weights of the channel in registers.
+// Small, latency-bound VALU kernels: the comparator is not the hot path, these exist so that a CUDA tensor
+// in train() mode has a libpngpd path instead of ATen / MIOpen.
+#include "pngpd_common.h"
+
+#define C5_OCG 5
+#define C5_CCH 5
+#define C5_ICG 4
+
+template <int OCG, int CCH>
+__global__ __launch_bounds__(256) void conv5_pool2_bwd_w_kernel(
+    const float *__restrict__ in, int Cin, int Hin, const float *__restrict__ dout,
+    const unsigned char *__restrict__ arg, int Cout, int B, int S, float *__restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int Hp = (Hin - 4) / 2, HP2 = Hp * Hp, HH = Hin * Hin;
+    const int plane_floats = CCH * HH > 256 * OCG ? CCH * HH : 256 * OCG;
+    float *plane = sm;                                 // [CCH][HH]; at the end the cross-slice reduction buffer
+    float *gv = plane + plane_floats;                  // [OCG][HP2] pooled gradients
+    int *off = (int *)(gv + OCG * HP2);                // [OCG][HP2] offset of the chosen window position in a plane
+    const int nchunks = (Cin + CCH - 1) / CCH;
+    const int og = blockIdx.x / nchunks, ch = blockIdx.x - og * nchunks;
+    const int s = blockIdx.y;
+    const int c0 = ch * CCH, nc = (Cin - c0) < CCH ? (Cin - c0) : CCH;
+    const int NJ = nc * 25, PS = 256 / NJ;             // taps of this workgroup; slices of the list walked in parallel
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = tid % NJ, ps = tid / NJ;
+    const bool act = ps < PS;
+    const int jc = j / 25, k = j - jc * 25, ky = k / 5, kx = k - ky * 5;
+    const int jbase = jc * HH + ky * Hin + kx;
+    float acc[OCG];
+#pragma unroll
+    for (int q = 0; q < OCG; ++q) acc[q] = 0.f;
+    float dbq[(OCG + 3) / 4];
+#pragma unroll
+    for (int q = 0; q < (OCG + 3) / 4; ++q) dbq[q] = 0.f;
+    const int b0 = (int)((long long)B * s / S), b1 = (int)((long long)B * (s + 1) / S);
+    const size_t pstride = (size_t)Cout * Cin * 25 + Cout;
+    for (int b = b0; b < b1; ++b) {
+        __syncthreads();
+        const float *inb = in + ((size_t)b * Cin + c0) * HH;
+        for (int i = tid; i < nc * HH; i += 256) plane[i] = inb[i];
+        for (int i = tid; i < OCG * HP2; i += 256) {
+            const int q = i / HP2, pp = i - q * HP2, oc = og * OCG + q;
+            if (oc < Cout) {
+                const size_t idx = ((size_t)b * Cout + oc) * HP2 + pp;
+                const int code = arg[idx], py = pp / Hp, px = pp - py * Hp;
+                off[i] = (2 * py + (code >> 1)) * Hin + 2 * px + (code & 1);
+                gv[i] = dout[idx];
+            } else {
+                off[i] = 0;
+                gv[i] = 0.f;
+            }
+        }
+        __syncthreads();
+        if (act)
+            for (int pp = ps; pp < HP2; pp += PS) {
+#pragma unroll
+                for (int q = 0; q < OCG; ++q) acc[q] = fmaf(gv[q * HP2 + pp], plane[jbase + off[q * HP2 + pp]], acc[q]);
+            }
+        if (ch == 0) {                                 // bias: wave w sums the lists of channels w, w + 4, ...
+#pragma unroll
+            for (int r = 0; r < (OCG + 3) / 4; ++r) {
+                const int q = wave + 4 * r;
+                if (q < OCG) {
+                    float t = 0.f;
+                    for (int pp = lane; pp < HP2; pp += 64) t += gv[q * HP2 + pp];
+#pragma unroll
+                    for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m);
+                    dbq[r] += t;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (act) {
+#pragma unroll
+        for (int q = 0; q < OCG; ++q) plane[(ps * NJ + j) * OCG + q] = acc[q];
+    }
+    __syncthreads();
+    float *ps_out = part + (size_t)s * pstride;
+    if (tid < NJ) {
+#pragma unroll
+        for (int q = 0; q < OCG; ++q) {
+            float t = 0.f;
+            for (int p2 = 0; p2 < PS; ++p2) t += plane[(p2 * NJ + tid) * OCG + q];
+            const int oc = og * OCG + q;
+            if (oc < Cout) ps_out[((size_t)oc * Cin + c0 + jc) * 25 + k] = t;
+        }
+    }
+    if (ch == 0 && lane == 0) {
+#pragma unroll
+        for (int r = 0; r < (OCG + 3) / 4; ++r) {
+            const int q = wave + 4 * r, oc = og * OCG + q;
+            if (q < OCG && oc < Cout) ps_out[(size_t)Cout * Cin * 25 + oc] = dbq[r];
+        }
+    }
+}
+
+// dW (nW) | db (Cout) = sum over the S batch slices, in slice order, accumulated in fp64
+__global__ __launch_bounds__(256) void conv5_bwd_reduce_kernel(const float *__restrict__ part, int S, int nW, int Cout,
+                                                               float *__restrict__ dW, float *__restrict__ db) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nW + Cout) return;
+    double t = 0.0;
+    for (int s = 0; s < S; ++s) t += (double)part[(size_t)s * (nW + Cout) + i];
+    if (i < nW) dW[i] = (float)t;
+    else db[i - nW] = (float)t;
+}
+
+template <int ICG>
+__global__ __launch_bounds__(256) void conv5_pool2_bwd_x_kernel(
+    const float *__restrict__ dout, const unsigned char *__restrict__ arg, const float *__restrict__ W, int Cin, int Hin,
+    int Cout, int OCC, float *__restrict__ din) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int Hp = (Hin - 4) / 2, HP2 = Hp * Hp, PW = Hin + 4, PP = PW * PW;
+    float *pl = sm;                                    // [OCC][PP]: d(conv output) at (y + 4, x + 4), zeros around
+    float *wl = pl + (size_t)OCC * PP;                 // [OCC][ICG][25]
+    const int nicg = (Cin + ICG - 1) / ICG;
+    const int b = blockIdx.x / nicg, ic0 = (blockIdx.x - b * nicg) * ICG;
+    const int SW = Hin / 4, tid = threadIdx.x;
+    const bool act = tid < Hin * SW;
+    const int Y = act ? tid / SW : 0, X0 = act ? (tid - (tid / SW) * SW) * 4 : 0;
+    float acc[4][ICG];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int ic = 0; ic < ICG; ++ic) acc[d][ic] = 0.f;
+    for (int oc0 = 0; oc0 < Cout; oc0 += OCC) {
+        const int noc = (Cout - oc0) < OCC ? (Cout - oc0) : OCC;
+        __syncthreads();
+        for (int i = tid; i < noc * PP; i += 256) pl[i] = 0.f;
+        for (int i = tid; i < noc * ICG * 25; i += 256) {
+            const int q = i / (ICG * 25), r = i - q * (ICG * 25), ic = r / 25, k = r - ic * 25;
+            wl[i] = (ic0 + ic < Cin) ? W[((size_t)(oc0 + q) * Cin + ic0 + ic) * 25 + k] : 0.f;
+        }
+        __syncthreads();
+        for (int i = tid; i < noc * HP2; i += 256) {
+            const int q = i / HP2, pp = i - q * HP2;
+            const size_t idx = ((size_t)b * Cout + oc0 + q) * HP2 + pp;
+            const int code = arg[idx], py = pp / Hp, px = pp - py * Hp;
+            pl[(size_t)q * PP + (2 * py + (code >> 1) + 4) * PW + 2 * px + (code & 1) + 4] = dout[idx];
+        }
+        __syncthreads();
+        if (act)
+            for (int q = 0; q < noc; ++q) {
+                const float *P = pl + (size_t)q * PP;
+                const float *Wq = wl + q * ICG * 25;
+#pragma unroll
+                for (int ky = 0; ky < 5; ++ky) {
+                    // din[Y][X0 + d] += dconv[Y - ky][X0 + d - kx] * w[ky][kx]: padded row Y - ky + 4, columns X0 + (d - kx + 4)
+                    const float4 r0 = *(const float4 *)(P + (Y - ky + 4) * PW + X0);
+                    const float4 r1 = *(const float4 *)(P + (Y - ky + 4) * PW + X0 + 4);
+                    const float row[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+                    for (int kx = 0; kx < 5; ++kx)
+#pragma unroll
+                        for (int ic = 0; ic < ICG; ++ic) {
+                            const float w = Wq[ic * 25 + ky * 5 + kx];
+#pragma unroll
+                            for (int d = 0; d < 4; ++d) acc[d][ic] = fmaf(row[d - kx + 4], w, acc[d][ic]);
+                        }
+                }
+            }
+    }
+    if (act)
+#pragma unroll
+        for (int ic = 0; ic < ICG; ++ic)
+            if (ic0 + ic < Cin) {
+                float4 o = {acc[0][ic], acc[1][ic], acc[2][ic], acc[3][ic]};
+                *(float4 *)(din + (((size_t)b * Cin + ic0 + ic) * Hin + Y) * Hin + X0) = o;
+            }
+}
+
+// backward of F.relu given its OUTPUT: g <- g * (y > 0), in place (gpd.py:27)
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float *__restrict__ y, float *__restrict__ g, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) g[i] = y[i] > 0.f ? g[i] : 0.f;
+}
+
+static int conv5_bwd_splits(int B, int Cin, int Cout) {
+    const int wgs = ((Cout + C5_OCG - 1) / C5_OCG) * ((Cin + C5_CCH - 1) / C5_CCH);
+    int S = (1024 + wgs - 1) / wgs;
+    if (S > B) S = B;
+    return S < 1 ? 1 : S;
+}
+
+extern "C" {
+
+size_t pngpd_conv5_pool2_bwd_workspace_bytes(int B, int Cin, int Cout) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    return (size_t)conv5_bwd_splits(B, Cin, Cout) * ((size_t)Cout * Cin * 25 + Cout) * sizeof(float);
+}
+
+int pngpd_conv5_pool2_bwd(const float *in, int B, int Cin, int Hin, const float *W, int Cout, const float *dout,
+                          const unsigned char *arg, float *dW, float *db, float *din, void *workspace,
+                          size_t workspace_bytes, void *stream) {
+    if (!in || !W || !dout || !arg || !dW || !db || !workspace || B <= 0 || Cin <= 0 || Cout <= 0 || Hin < 6 ||
+        ((Hin - 4) & 1))
+        return PNGPD_ERR_INVALID_ARG;
+    if (workspace_bytes < pngpd_conv5_pool2_bwd_workspace_bytes(B, Cin, Cout)) return PNGPD_ERR_WORKSPACE;
+    if (din && ((Hin & 3) || Hin > 32)) return PNGPD_ERR_UNSUPPORTED;   // the strip mapping of the input-gradient kernel
+    hipStream_t st = (hipStream_t)stream;
+    const int Hp = (Hin - 4) / 2, HP2 = Hp * Hp, HH = Hin * Hin;
+    {
+        const int S = conv5_bwd_splits(B, Cin, Cout);
+        const int plane_floats = C5_CCH * HH > 256 * C5_OCG ? C5_CCH * HH : 256 * C5_OCG;
+        const size_t lds = ((size_t)plane_floats + 2 * (size_t)C5_OCG * HP2) * sizeof(float);
+        if (lds > 150 * 1024) return PNGPD_ERR_UNSUPPORTED;
+        int rc = pngpd_allow_lds((const void *)conv5_pool2_bwd_w_kernel<C5_OCG, C5_CCH>, lds);
+        if (rc != PNGPD_OK) return rc;
+        const dim3 grid(((Cout + C5_OCG - 1) / C5_OCG) * ((Cin + C5_CCH - 1) / C5_CCH), S);
+        hipLaunchKernelGGL((conv5_pool2_bwd_w_kernel<C5_OCG, C5_CCH>), grid, dim3(256), lds, st, in, Cin, Hin, dout, arg,
+                           Cout, B, S, (float *)workspace);
+        const int n = Cout * Cin * 25 + Cout;
+        hipLaunchKernelGGL(conv5_bwd_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float *)workspace, S,
+                           Cout * Cin * 25, Cout, dW, db);
+    }
+    if (din) {
+        const int PW = Hin + 4;
+        const size_t per_oc = ((size_t)PW * PW + C5_ICG * 25) * sizeof(float);
+        int OCC = (int)((112 * 1024) / per_oc);
+        if (OCC > Cout) OCC = Cout;
+        if (OCC < 1) return PNGPD_ERR_UNSUPPORTED;
+        const size_t lds = OCC * per_oc;
+        int rc = pngpd_allow_lds((const void *)conv5_pool2_bwd_x_kernel<C5_ICG>, lds);
+        if (rc != PNGPD_OK) return rc;
+        hipLaunchKernelGGL((conv5_pool2_bwd_x_kernel<C5_ICG>), dim3((unsigned)B * ((Cin + C5_ICG - 1) / C5_ICG)), dim3(256),
+                           lds, st, dout, arg, W, Cin, Hin, Cout, OCC, din);
+    }
+    return pngpd_launch_status();
+}
+
+int pngpd_relu_bwd(const float *y, float *g, long long n, void *stream) {
+    if (!y || !g || n <= 0) return PNGPD_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, g, n);
+    return pngpd_launch_status();
+}
+
+}  // extern "C"

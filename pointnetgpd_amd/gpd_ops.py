@@ -5,7 +5,9 @@
                             hand frame AND their normals (the reference estimates normals with open3d, which is an input
                             here: SURVEY.md §8c);
 * ``register_depth_map`` / ``depth_map_to_cloud`` — PointNetGPD/ycb_cloud_generate.py:60-184;
-* ``conv5_pool2``         — one convolution stage of ``GPDClassifier`` (PointNetGPD/model/gpd.py:13-24).
+* ``conv5_pool2``         — one convolution stage of ``GPDClassifier`` (PointNetGPD/model/gpd.py:13-24);
+* ``GPDNetFn``            — the classifier as ONE autograd node for train() mode on CUDA: forward and backward
+                            (``loss.backward()`` of PointNetGPD/main_1v_gpd.py:105) on libpngpd kernels only.
 CUDA tensors only; there is no CPU implementation behind these calls.
 """
 import numpy as np
@@ -108,3 +110,71 @@ def conv5_pool2(x, weight, bias):
     out = torch.empty(B, Cout, (H - 4) // 2, (H - 4) // 2, device=x.device, dtype=torch.float32)
     _call("pngpd_conv5_pool2", x, x, B, Cin, H, weight, bias, Cout, out)
     return out
+
+
+def conv5_pool2_arg(x, weight, bias):
+    """``conv5_pool2`` that also returns the window position of every pooled maximum (u8, first on a tie)."""
+    B, Cin, H, W = x.shape
+    if H != W or not x.is_cuda or x.dtype != torch.float32:
+        raise RuntimeError("conv5_pool2_arg: expected a square fp32 CUDA image batch")
+    Cout = weight.shape[0]
+    out = torch.empty(B, Cout, (H - 4) // 2, (H - 4) // 2, device=x.device, dtype=torch.float32)
+    arg = torch.empty(out.shape, device=x.device, dtype=torch.uint8)
+    _call("pngpd_conv5_pool2_arg", x, x, B, Cin, H, weight, bias, Cout, out, arg)
+    return out, arg
+
+
+def conv5_pool2_bwd(x, weight, dout, arg, need_input_grad):
+    """Backward of one stage: -> (dx or None, dW, db).  Deterministic (slice partials reduced in order)."""
+    B, Cin, H, _ = x.shape
+    Cout = weight.shape[0]
+    dW = torch.empty_like(weight)
+    db = torch.empty(Cout, device=x.device, dtype=torch.float32)
+    dx = torch.empty_like(x) if need_input_grad else None
+    nbytes = _lib.load().pngpd_conv5_pool2_bwd_workspace_bytes(B, Cin, Cout)
+    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+    _call("pngpd_conv5_pool2_bwd", x, x, B, Cin, H, weight, Cout, dout, arg, dW, db, dx, ws, nbytes)
+    return dx, dW, db
+
+
+class GPDNetFn(torch.autograd.Function):
+    """GPDClassifier.forward (gpd.py:22-31, dropout off) as one autograd node on libpngpd: two conv+pool stages that
+    record their pooling choices, fc1 + ReLU and fc2 + log_softmax on the MFMA FC kernel; backward = log_softmax_bwd,
+    fc_bwd x2 (one launch each: dW, db, dx), relu_bwd and the two sparse convolution backward kernels."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, fw1, fb1, fw2, fb2):
+        from . import ops
+        x = x.float().contiguous()
+        w1, b1, w2, b2 = (t.detach().contiguous() for t in (w1, b1, w2, b2))
+        fw1, fb1, fw2, fb2 = (t.detach().contiguous() for t in (fw1, fb1, fw2, fb2))
+        p1, a1 = conv5_pool2_arg(x, w1, b1)                          # (B,20,28,28)
+        p2, a2 = conv5_pool2_arg(p1, w2, b2)                         # (B,50,12,12)
+        flat = p2.view(p2.shape[0], -1)
+        h1 = ops.fc_fwd(flat, fw1, fb1, ops.EPI_RELU)
+        K = fw2.shape[1]
+        pad = (-K) % 8                                               # the FC kernel walks K in 8-wide blocks
+        if pad:
+            h1p = torch.nn.functional.pad(h1, (0, pad)).contiguous()
+            fw2p = torch.nn.functional.pad(fw2, (0, pad)).contiguous()
+        else:
+            h1p, fw2p = h1, fw2
+        logp = ops.fc_fwd(h1p, fw2p, fb2, ops.EPI_LOG_SOFTMAX)
+        ctx.save_for_backward(x, w1, p1, a1, w2, flat, a2, fw1, h1, fw2, logp)
+        ctx.need_dx = ctx.needs_input_grad[0]
+        return logp
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import ops
+        x, w1, p1, a1, w2, flat, a2, fw1, h1, fw2, logp = ctx.saved_tensors
+        dz = ops.log_softmax_bwd(g.float().contiguous(), logp)
+        dh1, dfw2, dfb2 = ops.fc_bwd(dz, h1, fw2)
+        _call("pngpd_relu_bwd", h1, h1, dh1, h1.numel())
+        dflat, dfw1, dfb1 = ops.fc_bwd(dh1, flat, fw1)
+        dp1, dw2, db2 = conv5_pool2_bwd(p1, w2, dflat.view(a2.shape), a2, True)
+        if ctx.need_dx:
+            raise RuntimeError("GPDNetFn: the gradient with respect to the input images is not implemented "
+                               "(main_1v_gpd.py trains the weights only)")
+        _, dw1, db1 = conv5_pool2_bwd(x, w1, dp1, a1, False)
+        return None, dw1, db1, dw2, db2, dfw1, dfb1, dfw2, dfb2

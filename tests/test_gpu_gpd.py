@@ -107,13 +107,75 @@ def test_gpd_classifier_forward(chann, cuda_device):
     assert (got.argmax(1) == ref.argmax(1)).all()
 
 
-def test_gpd_classifier_cuda_training_is_explicit(cuda_device):
-    """A CUDA tensor in train() mode has no libpngpd kernel (the comparator's backward is outside the hot path): it
-    raises like every other CUDA path without one, instead of silently dispatching to ATen / MIOpen; the opt-in runs
-    the reference's own composite (gpd.py:5-31 under main_1v_gpd.py:105)."""
+@pytest.mark.parametrize("chann,B", [(3, 1), (3, 37), (12, 16)])
+def test_gpd_classifier_training_on_hip(chann, B, cuda_device):
+    """train() mode on a CUDA tensor runs libpngpd forward AND backward (gpd_ops.GPDNetFn; main_1v_gpd.py:97-106's
+    ``loss = F.nll_loss(model(data), target); loss.backward()``): every parameter gradient against the same module in
+    fp64 on the CPU (ATen), on projection-like images — mostly empty, so whole pooling windows tie at the bias and the
+    first-position rule of ATen's max_pool2d decides where the gradient goes."""
+    import torch.nn.functional as F
+    from pointnetgpd_amd.model.gpd import GPDClassifier
+    torch.manual_seed(40 + chann + B)
+    m = GPDClassifier(chann)
+    ref = GPDClassifier(chann).double()
+    ref.load_state_dict({k: v.double() for k, v in m.state_dict().items()})
+    g = torch.Generator().manual_seed(B)
+    x = torch.rand(B, chann, 60, 60, generator=g)
+    x = x * (torch.rand(B, 1, 60, 60, generator=g) < 0.3)             # 70 % empty pixels, as the projection images
+    x[:, :, :20, :] = 0                                               # and an empty band: exact ties over whole windows
+    target = torch.randint(0, 2, (B,), generator=g)
+    ref.train()
+    lref = F.nll_loss(ref(x.double()), target)
+    lref.backward()
+    m = m.to(cuda_device).train()
+    out = m(x.to(cuda_device))
+    assert "libpngpd.so" in open("/proc/self/maps").read() and out.grad_fn.name().startswith("GPDNetFn")
+    loss = F.nll_loss(out, target.to(cuda_device))
+    loss.backward()
+    assert abs(loss.item() - lref.item()) < 1e-5
+    with torch.no_grad():
+        assert torch.equal(m.eval()(x.to(cuda_device)), out.detach())  # the stages of train() are the stages of eval()
+    for (name, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        got, want = p.grad.double().cpu(), q.grad
+        err = (got - want).abs().max().item()
+        assert err <= 2e-5 * want.abs().max().item() + 1e-9, (name, err, want.abs().max().item())
+    # deterministic: a second backward reproduces the gradients bit for bit
+    first = [p.grad.clone() for p in m.parameters()]
+    m.zero_grad(set_to_none=True)
+    m.train()
+    F.nll_loss(m(x.to(cuda_device)), target.to(cuda_device)).backward()
+    assert all(torch.equal(a, p.grad) for a, p in zip(first, m.parameters()))
+
+
+def test_conv5_pool2_arg_records_first_maximum(cuda_device):
+    """The recorded window position reproduces the pooled value, and on exact ties it is the first in row-major order
+    (ATen max_pool2d: strict >)."""
+    from pointnetgpd_amd import gpd_ops
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(3, 4, 28, 28, generator=g)
+    x[:, :, 10:, :] = 0.0
+    w = torch.randn(7, 4, 5, 5, generator=g) * 0.1
+    b = torch.randn(7, generator=g)
+    out, arg = gpd_ops.conv5_pool2_arg(x.to(cuda_device), w.to(cuda_device), b.to(cuda_device))
+    assert torch.equal(out, gpd_ops.conv5_pool2(x.to(cuda_device), w.to(cuda_device), b.to(cuda_device)))
+    conv = torch.nn.functional.conv2d(x.double(), w.double(), b.double())
+    pooled, idx = torch.nn.functional.max_pool2d(conv, 2, 2, return_indices=True)
+    yy, xx = idx // 24, idx % 24
+    code = ((yy % 2) * 2 + (xx % 2)).to(torch.uint8)
+    a = arg.cpu()
+    assert (a[:, :, 6:, :] == 0).all()                                 # the empty band: ties -> position 0
+    # elsewhere the fp32 choice equals the fp64 one except at near-ties, where the chosen VALUE is still the maximum
+    chosen = conv.view(3, 7, 12, 2, 12, 2).permute(0, 1, 2, 4, 3, 5).reshape(3, 7, 12, 12, 4).gather(
+        4, a.long().unsqueeze(-1)).squeeze(-1)
+    assert (chosen - pooled).abs().max() < 1e-5 and (a == code).float().mean() > 0.999
+
+
+def test_gpd_classifier_cuda_dropout_is_explicit(cuda_device):
+    """dropout=True in train() mode has no libpngpd kernel: a CUDA tensor raises like every other CUDA path without one,
+    instead of silently dispatching to ATen / MIOpen; the opt-in runs the reference's own composite (gpd.py:5-31)."""
     from pointnetgpd_amd.model.gpd import GPDClassifier
     torch.manual_seed(3)
-    m = GPDClassifier(3).to(cuda_device).train()
+    m = GPDClassifier(3, dropout=True).to(cuda_device).train()
     x = torch.rand(4, 3, 60, 60, device=cuda_device)
     with pytest.raises(RuntimeError, match="allow_aten_training"):
         m(x)
@@ -124,5 +186,6 @@ def test_gpd_classifier_cuda_training_is_explicit(cuda_device):
         assert out.shape == (4, 2) and m.conv1.weight.grad is not None
     finally:
         GPDClassifier.allow_aten_training = False
-    with torch.no_grad():
-        assert torch.allclose(m.eval()(x), out.detach(), atol=1e-4)       # eval: the HIP path, same numbers
+    x.requires_grad_(True)
+    with pytest.raises(RuntimeError, match="input images"):
+        GPDClassifier(3).to(cuda_device).train()(x).sum().backward()
