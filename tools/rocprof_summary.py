@@ -10,7 +10,9 @@ import sqlite3
 import sys
 
 OURS = ("trunk_", "fc_", "pool_", "fold_conv_bn", "crop_", "resample", "bn", "pngpd", "gpg_", "hand_box", "split_pack",
-        "cloud_moments", "a_cvec", "bwd_e_prep", "dtrans", "dw1_", "dw3_", "log_softmax_bwd", "reduce_partials")
+        "cloud_moments", "a_cvec", "bwd_e_prep", "dtrans", "dw1_", "dw3_", "log_softmax_bwd", "reduce_partials", "adam_",
+        "batch_keep_rows", "block_scan", "conv5_", "depth_", "gpd_", "mfma_rate", "nll_", "reduce_fin", "relu_bwd",
+        "stack_gather_lists", "train_pack")
 
 
 def short(name):
