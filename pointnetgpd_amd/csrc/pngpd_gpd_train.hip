@@ -26,8 +26,8 @@ __global__ __launch_bounds__(256) void conv5_pool2_bwd_w_kernel(
     const int Hp = (Hin - 4) / 2, HP2 = Hp * Hp, HH = Hin * Hin;
     const int plane_floats = CCH * HH > 256 * OCG ? CCH * HH : 256 * OCG;
     float *plane = sm;                                 // [CCH][HH]; at the end the cross-slice reduction buffer
-    float *gv = plane + plane_floats;                  // [OCG][HP2] pooled gradients
-    int *off = (int *)(gv + OCG * HP2);                // [OCG][HP2] offset of the chosen window position in a plane
+    int2 *lst = (int2 *)(plane + plane_floats);        // [OCG][HP2] (offset of the chosen window position in a plane,
+                                                       //  pooled gradient): one 8-byte LDS read per list entry
     const int nchunks = (Cin + CCH - 1) / CCH;
     const int og = blockIdx.x / nchunks, ch = blockIdx.x - og * nchunks;
     const int s = blockIdx.y;
@@ -55,26 +55,29 @@ __global__ __launch_bounds__(256) void conv5_pool2_bwd_w_kernel(
             if (oc < Cout) {
                 const size_t idx = ((size_t)b * Cout + oc) * HP2 + pp;
                 const int code = arg[idx], py = pp / Hp, px = pp - py * Hp;
-                off[i] = (2 * py + (code >> 1)) * Hin + 2 * px + (code & 1);
-                gv[i] = dout[idx];
+                lst[i] = make_int2((2 * py + (code >> 1)) * Hin + 2 * px + (code & 1), __float_as_int(dout[idx]));
             } else {
-                off[i] = 0;
-                gv[i] = 0.f;
+                lst[i] = make_int2(0, 0);
             }
         }
         __syncthreads();
-        if (act)
+        if (act) {
+#pragma unroll 4
             for (int pp = ps; pp < HP2; pp += PS) {
 #pragma unroll
-                for (int q = 0; q < OCG; ++q) acc[q] = fmaf(gv[q * HP2 + pp], plane[jbase + off[q * HP2 + pp]], acc[q]);
+                for (int q = 0; q < OCG; ++q) {
+                    const int2 e = lst[q * HP2 + pp];
+                    acc[q] = fmaf(__int_as_float(e.y), plane[jbase + e.x], acc[q]);
+                }
             }
+        }
         if (ch == 0) {                                 // bias: wave w sums the lists of channels w, w + 4, ...
 #pragma unroll
             for (int r = 0; r < (OCG + 3) / 4; ++r) {
                 const int q = wave + 4 * r;
                 if (q < OCG) {
                     float t = 0.f;
-                    for (int pp = lane; pp < HP2; pp += 64) t += gv[q * HP2 + pp];
+                    for (int pp = lane; pp < HP2; pp += 64) t += __int_as_float(lst[q * HP2 + pp].y);
 #pragma unroll
                     for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m);
                     dbq[r] += t;
@@ -188,8 +191,8 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const float *__restrict__
     if (i < n) g[i] = y[i] > 0.f ? g[i] : 0.f;
 }
 
-static int conv5_bwd_splits(int B, int Cin, int Cout) {
-    const int wgs = ((Cout + C5_OCG - 1) / C5_OCG) * ((Cin + C5_CCH - 1) / C5_CCH);
+static int conv5_bwd_splits(int B, int Cin, int Cout, int cch) {
+    const int wgs = ((Cout + C5_OCG - 1) / C5_OCG) * ((Cin + cch - 1) / cch);
     int S = (1024 + wgs - 1) / wgs;
     if (S > B) S = B;
     return S < 1 ? 1 : S;
@@ -199,7 +202,8 @@ extern "C" {
 
 size_t pngpd_conv5_pool2_bwd_workspace_bytes(int B, int Cin, int Cout) {
     if (B <= 0 || Cin <= 0 || Cout <= 0) return 0;
-    return (size_t)conv5_bwd_splits(B, Cin, Cout) * ((size_t)Cout * Cin * 25 + Cout) * sizeof(float);
+    const int s2 = conv5_bwd_splits(B, Cin, Cout, 2), s5 = conv5_bwd_splits(B, Cin, Cout, C5_CCH);   // whatever Hin selects
+    return (size_t)(s2 > s5 ? s2 : s5) * ((size_t)Cout * Cin * 25 + Cout) * sizeof(float);
 }
 
 int pngpd_conv5_pool2_bwd(const float *in, int B, int Cin, int Hin, const float *W, int Cout, const float *dout,
@@ -213,15 +217,24 @@ int pngpd_conv5_pool2_bwd(const float *in, int B, int Cin, int Hin, const float 
     hipStream_t st = (hipStream_t)stream;
     const int Hp = (Hin - 4) / 2, HP2 = Hp * Hp, HH = Hin * Hin;
     {
-        const int S = conv5_bwd_splits(B, Cin, Cout);
-        const int plane_floats = C5_CCH * HH > 256 * C5_OCG ? C5_CCH * HH : 256 * C5_OCG;
+        // big images (the first stage, 60x60): 2 planes per workgroup so that two workgroups share a CU's LDS and one
+        // stages while the other computes; small ones (the second stage): 5 planes, 7 workgroups per CU either way
+        const int cch = Hin > 32 ? 2 : C5_CCH;
+        const int S = conv5_bwd_splits(B, Cin, Cout, cch);
+        const int plane_floats = cch * HH > 256 * C5_OCG ? cch * HH : 256 * C5_OCG;
         const size_t lds = ((size_t)plane_floats + 2 * (size_t)C5_OCG * HP2) * sizeof(float);
         if (lds > 150 * 1024) return PNGPD_ERR_UNSUPPORTED;
-        int rc = pngpd_allow_lds((const void *)conv5_pool2_bwd_w_kernel<C5_OCG, C5_CCH>, lds);
+        const void *fn = cch == 2 ? (const void *)conv5_pool2_bwd_w_kernel<C5_OCG, 2>
+                                  : (const void *)conv5_pool2_bwd_w_kernel<C5_OCG, C5_CCH>;
+        int rc = pngpd_allow_lds(fn, lds);
         if (rc != PNGPD_OK) return rc;
-        const dim3 grid(((Cout + C5_OCG - 1) / C5_OCG) * ((Cin + C5_CCH - 1) / C5_CCH), S);
-        hipLaunchKernelGGL((conv5_pool2_bwd_w_kernel<C5_OCG, C5_CCH>), grid, dim3(256), lds, st, in, Cin, Hin, dout, arg,
-                           Cout, B, S, (float *)workspace);
+        const dim3 grid(((Cout + C5_OCG - 1) / C5_OCG) * ((Cin + cch - 1) / cch), S);
+        if (cch == 2)
+            hipLaunchKernelGGL((conv5_pool2_bwd_w_kernel<C5_OCG, 2>), grid, dim3(256), lds, st, in, Cin, Hin, dout, arg,
+                               Cout, B, S, (float *)workspace);
+        else
+            hipLaunchKernelGGL((conv5_pool2_bwd_w_kernel<C5_OCG, C5_CCH>), grid, dim3(256), lds, st, in, Cin, Hin, dout,
+                               arg, Cout, B, S, (float *)workspace);
         const int n = Cout * Cin * 25 + Cout;
         hipLaunchKernelGGL(conv5_bwd_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float *)workspace, S,
                            Cout * Cin * 25, Cout, dW, db);
@@ -229,7 +242,7 @@ int pngpd_conv5_pool2_bwd(const float *in, int B, int Cin, int Hin, const float 
     if (din) {
         const int PW = Hin + 4;
         const size_t per_oc = ((size_t)PW * PW + C5_ICG * 25) * sizeof(float);
-        int OCC = (int)((112 * 1024) / per_oc);
+        int OCC = (int)((48 * 1024) / per_oc);      // 10 channels of a 28x28 stage: three workgroups per CU overlap their staging
         if (OCC > Cout) OCC = Cout;
         if (OCC < 1) return PNGPD_ERR_UNSUPPORTED;
         const size_t lds = OCC * per_oc;
