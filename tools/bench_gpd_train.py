@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--chann", type=int, default=12)
     ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--hip-only", action="store_true", help="skip the ATen / MIOpen leg (kernel traces)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -41,7 +42,7 @@ def main():
         F.nll_loss(F.log_softmax(F.linear(h, m.fc2.weight, m.fc2.bias), -1), t).backward()
 
     out = {"batch": a.batch, "chann": a.chann, "steps": a.steps}
-    for name, fn in (("hip", hip), ("aten_miopen", aten)):
+    for name, fn in (("hip", hip), ("aten_miopen", aten))[:1 if a.hip_only else 2]:
         for _ in range(5):
             fn()
         torch.cuda.synchronize()
@@ -52,11 +53,12 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         out[f"{name}_ms"] = round(e0.elapsed_time(e1) / a.steps, 4)
-    hip()
-    gh = [p.grad.clone() for p in m.parameters()]
-    aten()
-    out["max_rel_grad_diff_vs_aten"] = max(((g - p.grad).abs().max() / p.grad.abs().max()).item()
-                                           for g, p in zip(gh, m.parameters()))
+    if not a.hip_only:
+        hip()
+        gh = [p.grad.clone() for p in m.parameters()]
+        aten()
+        out["max_rel_grad_diff_vs_aten"] = max(((g - p.grad).abs().max() / p.grad.abs().max()).item()
+                                               for g, p in zip(gh, m.parameters()))
     print(json.dumps(out))
 
 

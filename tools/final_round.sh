@@ -15,6 +15,8 @@ timeout 200 python tools/bench_pipeline.py 2>/dev/null | tail -3 > gpurun_out/${
 timeout 120 python tools/bench_loader.py 2>/dev/null > gpurun_out/${TAG}_bench_loader.jsonl
 timeout 200 python tools/bench_epoch.py 2>/dev/null > gpurun_out/${TAG}_bench_epoch.jsonl
 timeout 200 python tools/bench_gpg_scale.py 2>/dev/null > gpurun_out/${TAG}_bench_gpg_scale.jsonl
+( for a in "--batch 1 --chann 3" "--batch 16 --chann 3" "--batch 64 --chann 12" "--batch 256 --chann 12"; do timeout 60 python tools/bench_gpd_train.py $a 2>/dev/null | tail -1; done ) > gpurun_out/${TAG}_bench_gpd_train.jsonl
+rm -rf /tmp/pgpd; ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/pgpd -o t -- python $GRAFT_REPO_ROOT/tools/bench_gpd_train.py --batch 64 --chann 12 --hip-only > /tmp/gpdtr.log 2>&1 ); DB=$(find /tmp/pgpd -name "*.db" | head -1); [ -n "$DB" ] && python tools/rocprof_summary.py --all gpurun_out/${TAG}_gpd_train_trace.md "GPD comparator, 55 training steps on libpngpd at B 64, 12 channels (tools/bench_gpd_train.py --hip-only)=$DB" > /dev/null
 timeout 100 python tools/bench_crop.py 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_crop.json
 FUSED_LOSS=1 timeout 100 python tools/find_copies.py 2>/dev/null > gpurun_out/${TAG}_aten_launches_in_a_step.txt; echo "(empty = no ATen launch inside a training step)" >> gpurun_out/${TAG}_aten_launches_in_a_step.txt
 timeout 600 python tools/localise_residual.py > gpurun_out/${TAG}_localise_residual.txt 2>/dev/null
