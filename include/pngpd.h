@@ -93,7 +93,7 @@ int pngpd_trunk_fwd_infer(const float *x, int B, int N, const float *trans,
 /*
  * out = epilogue(in @ W^T + bias)   in (B,K), W (Nout,K) rowmajor (BN pre-folded), out (B,Nout).
  * Replaces the Linear(+BatchNorm1d eval)(+ReLU) stacks pointnet.py:35-37,191-193 and the
- * `+ iden` (:39-43) / `F.log_softmax` (:194) tails.  K % 8 == 0.  ADD_IDEN3 needs Nout == 9,
+ * `+ iden` (:39-43) / `F.log_softmax` (:194) tails.  K % 4 == 0 (rows are read as 16-byte vectors).  ADD_IDEN3 needs Nout == 9,
  * LOG_SOFTMAX needs Nout <= 32.
  */
 int pngpd_fc_fwd(const float *in, int B, int K, const float *W, const float *bias, int Nout,

@@ -78,6 +78,13 @@ __global__ __launch_bounds__(256) void fc_kernel(const float *__restrict__ in, i
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc = mfma32(a[t], w[t], acc);
     }
+    if (!KSPLIT && (K & 7) == 4) {   // K = 8 m + 4 (GPDClassifier's fc2, K = 500): the last half block — lanes of the upper
+                                     // half (k index 1 of each MFMA) contribute zeros
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, w = {0.f, 0.f, 0.f, 0.f};
+        if (h == 0) { a = ap[KBall * 2]; w = wp[KBall * 2]; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = mfma32(a[t], w[t], acc);
+    }
     if (KSPLIT) {
         if (wave > 0) {
 #pragma unroll
@@ -152,7 +159,7 @@ int pngpd_fold_conv_bn(const float *W, const float *b, const float *gamma, const
 
 int pngpd_fc_fwd(const float *in, int B, int K, const float *W, const float *bias, int Nout,
                  int epilogue, float *out, void *stream) {
-    if (!in || !W || !bias || !out || B <= 0 || K <= 0 || Nout <= 0 || (K & 7)) return PNGPD_ERR_INVALID_ARG;
+    if (!in || !W || !bias || !out || B <= 0 || K <= 0 || Nout <= 0 || (K & 3)) return PNGPD_ERR_INVALID_ARG;
     if (epilogue < PNGPD_EPI_NONE || epilogue > PNGPD_EPI_LOG_SOFTMAX) return PNGPD_ERR_INVALID_ARG;
     if (epilogue == PNGPD_EPI_ADD_IDEN3 && Nout != 9) return PNGPD_ERR_INVALID_ARG;
     if (epilogue == PNGPD_EPI_LOG_SOFTMAX && Nout > 32) return PNGPD_ERR_INVALID_ARG;

@@ -66,7 +66,5 @@ class GPDClassifier(nn.Module):
         x = gpd_ops.conv5_pool2(x, self.conv2.weight, self.conv2.bias)          # (B,50,12,12)
         x = x.view(-1, 7200)
         x = ops.fc_fwd(x, self.fc1.weight.detach().contiguous(), self.fc1.bias.detach().contiguous(), ops.EPI_RELU)
-        # fc2: K = 500 is not a multiple of the FC kernel's 8-wide k-blocks: zero-pad input and weight columns to 504
-        w2 = F.pad(self.fc2.weight.detach(), (0, 4)).contiguous()
-        x = F.pad(x, (0, 4)).contiguous()
-        return ops.fc_fwd(x, w2, self.fc2.bias.detach().contiguous(), ops.EPI_LOG_SOFTMAX)
+        return ops.fc_fwd(x, self.fc2.weight.detach().contiguous(), self.fc2.bias.detach().contiguous(),
+                          ops.EPI_LOG_SOFTMAX)                                   # K = 500 = 8 * 62 + 4: the kernel's tail

@@ -118,7 +118,7 @@ def test_argument_validation_of_every_family():
     assert lib.pngpd_reduce_partials4(*([None, 0, 0, 0, None] * 4), None) == INV                   # no segment
     assert lib.pngpd_reduce_partials4(p, 1, 0, 8, p, *([None, 0, 0, 0, None] * 3), None) == INV    # R == 0
     assert lib.pngpd_fold_conv_bn(p, p, None, None, None, None, 1e-5, 30, 8, 1, p, p, None) == INV      # MFMA_B needs C % 32 == 0
-    assert lib.pngpd_fc_fwd(p, 4, 12, p, p, 3, 0, p, None) == INV                                  # K % 8 != 0
+    assert lib.pngpd_fc_fwd(p, 4, 10, p, p, 3, 0, p, None) == INV                                  # K % 4 != 0
     assert lib.pngpd_fc_fwd(p, 4, 16, p, p, 40, 3, p, None) == INV                                 # log_softmax needs Nout <= 32
     assert lib.pngpd_strerror(UNSUP) == b"unsupported configuration"
 

@@ -61,7 +61,8 @@ def test_fc_kernel_vs_torch(cuda_device):
     """pngpd_fc_fwd epilogues vs a plain fp32 torch composite (ragged B and Nout)."""
     from pointnetgpd_amd import ops
     g = torch.Generator().manual_seed(5)
-    for (B, K, Nout) in [(1, 256, 9), (5, 256, 2), (33, 1024, 512), (64, 512, 256), (70, 256, 3), (2, 256, 32)]:
+    for (B, K, Nout) in [(1, 256, 9), (5, 256, 2), (33, 1024, 512), (64, 512, 256), (70, 256, 3), (2, 256, 32),
+                         (37, 500, 2), (64, 12, 130), (3, 4, 5), (40, 504, 40)]:     # K = 8 m + 4: the half-block tail
         a = torch.randn(B, K, generator=g); W = torch.randn(Nout, K, generator=g) / K ** 0.5
         bias = torch.randn(Nout, generator=g)
         ref = a.double() @ W.double().T + bias.double()
