@@ -531,7 +531,7 @@ static int run() {
         {
             unsigned char *da1, *da2;
             float *dt1, *dt2, *dg2, *ddw2, *ddb2, *ddp1, *ddw1, *ddb1, *dws;
-            const size_t ws2 = pngpd_conv5_pool2_bwd_workspace_bytes(Bc, 20, 50), ws1 = pngpd_conv5_pool2_bwd_workspace_bytes(Bc, 12, 20);
+            const size_t ws2 = pngpd_conv5_pool2_bwd_workspace_bytes(Bc, 20, 28, 50), ws1 = pngpd_conv5_pool2_bwd_workspace_bytes(Bc, 12, 60, 20);
             const size_t wsb = ws1 > ws2 ? ws1 : ws2;
             std::vector<float> g2((size_t)Bc * 50 * 144);
             for (auto &v : g2) v = (float)g.next() - 0.5f;

@@ -629,12 +629,13 @@ int pngpd_conv5_pool2(const float *in, int B, int Cin, int Hin, const float *W, 
  * _arg: the same outputs as pngpd_conv5_pool2, plus arg (B,Cout,Hp,Hp) u8 = which window position (2*dy + dx) gave each
  * pooled maximum — the first in row-major order on a tie, as ATen's max_pool2d.
  * _bwd: dout (B,Cout,Hp,Hp) -> dW (Cout,Cin,5,5), db (Cout) and, unless NULL, din (B,Cin,Hin,Hin; needs Hin % 4 == 0 and
- * Hin <= 32: the second stage — the first stage's input is the image).  Deterministic: per-batch-slice partial sums in
- * `workspace` (pngpd_conv5_pool2_bwd_workspace_bytes), reduced in slice order; no atomics.
+ * Hin <= 32: the second stage — the first stage's input is the image).  Deterministic: per-batch-slice partial sums (and the
+ * pooled gradients as an (offset, value) list) in `workspace` (pngpd_conv5_pool2_bwd_workspace_bytes), reduced in slice
+ * order; no atomics.
  * pngpd_relu_bwd: g <- g * (y > 0) in place, y = the ReLU's OUTPUT (gpd.py:27).                                        */
 int pngpd_conv5_pool2_arg(const float *in, int B, int Cin, int Hin, const float *W, const float *bias, int Cout,
                           float *out, unsigned char *arg, void *stream);
-size_t pngpd_conv5_pool2_bwd_workspace_bytes(int B, int Cin, int Cout);
+size_t pngpd_conv5_pool2_bwd_workspace_bytes(int B, int Cin, int Hin, int Cout);
 int pngpd_conv5_pool2_bwd(const float *in, int B, int Cin, int Hin, const float *W, int Cout, const float *dout,
                           const unsigned char *arg, float *dW, float *db, float *din, void *workspace,
                           size_t workspace_bytes, void *stream);

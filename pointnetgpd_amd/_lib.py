@@ -192,7 +192,7 @@ SIGNATURES = {
                                          c_f32p, c_void]),
     "pngpd_conv5_pool2_arg": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, ctypes.c_int,
                                              c_f32p, c_void, c_void]),
-    "pngpd_conv5_pool2_bwd_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "pngpd_conv5_pool2_bwd_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "pngpd_conv5_pool2_bwd": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, ctypes.c_int, c_f32p,
                                              c_void, c_f32p, c_f32p, c_f32p, c_void, ctypes.c_size_t, c_void]),
     "pngpd_relu_bwd": (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_longlong, c_void]),

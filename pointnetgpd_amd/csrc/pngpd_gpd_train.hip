@@ -2,11 +2,12 @@
 //   GPDClassifier  conv(5x5) -> MaxPool2d(2,2), twice      PointNetGPD/model/gpd.py:13-24
 //   trained by     loss.backward()                         PointNetGPD/main_1v_gpd.py:105
 // The forward (pngpd_conv5_pool2_arg, pngpd_gpd.hip) records which of the four window positions each pooled pixel took;
-// the gradient of a stage is therefore SPARSE in the convolution's output — one position per pooled pixel — and neither
-// kernel below materialises it in HBM:
-//   * weights / bias: a workgroup owns (5 output channels, <= 5 input planes, a slice of the batch); the planes and the
-//     pooled gradients (as a list of (offset, value)) are staged in LDS, a thread owns one (plane, ky, kx) tap and
-//     walks the list.  Per-slice partial sums, reduced in a fixed order by a second launch: deterministic, no atomics.
+// the gradient of a stage is therefore SPARSE in the convolution's output — one position per pooled pixel — and no kernel
+// below materialises the dense form in HBM:
+//   * weights / bias: the pooled gradients become a list of (plane offset, value) pairs (8 bytes per pooled pixel, the only
+//     intermediate); a workgroup owns (5 output channels, <= 5 input planes, a slice of the batch), stages the planes in
+//     LDS, a lane owns one or two (plane, ky, kx) taps and its wave walks a quarter of each channel's list, read through
+//     the scalar unit.  Per-slice partial sums, reduced in a fixed order by a second launch: deterministic, no atomics.
 //   * input (the second stage only — the first stage's input is the image): a workgroup owns (sample, 4 input planes);
 //     the sparse gradient of 25 output channels is expanded into zero-padded planes in LDS and every thread evaluates
 //     the full correlation for a 1x4 strip of pixels with the 100 weights of the channel in registers.
@@ -18,8 +19,111 @@
 #define C5_CCH 5
 #define C5_ICG 4
 
+// the sparse gradient of a stage as a list: per pooled pixel (plane offset of the window position it came from, value)
+__global__ __launch_bounds__(256) void conv5_pool_list_kernel(const float *__restrict__ dout,
+                                                              const unsigned char *__restrict__ arg, int Hin, long long n,
+                                                              int2 *__restrict__ lst) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int Hp = (Hin - 4) / 2, pp = (int)(i % (Hp * Hp)), code = arg[i], py = pp / Hp, px = pp - py * Hp;
+    lst[i] = make_int2((2 * py + (code >> 1)) * Hin + 2 * px + (code & 1), __float_as_int(dout[i]));
+}
+
+// Weights / bias.  The list entries are the same for every lane of a wave (a wave owns a contiguous quarter of a channel's
+// pooled pixels, its lanes own the taps), so they arrive through the SCALAR unit — s_load from the list in global memory —
+// and the only LDS access per multiply-add is the gather from the staged plane at (tap base + entry offset).
 template <int OCG, int CCH>
 __global__ __launch_bounds__(256) void conv5_pool2_bwd_w_kernel(
+    const float *__restrict__ in, int Cin, int Hin, const int2 *__restrict__ lst, int Cout, int B, int S,
+    float *__restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int TJ = (CCH * 25 + 63) / 64;           // taps per lane
+    constexpr int RED = 4 * TJ * 64 * OCG + 4 * OCG;   // cross-wave reduction buffers (alias the planes at the end)
+    const int Hp = (Hin - 4) / 2, HP2 = Hp * Hp, HH = Hin * Hin;
+    float *plane = sm;                                 // [CCH][HH]
+    const int nchunks = (Cin + CCH - 1) / CCH;
+    const int og = blockIdx.x / nchunks, ch = blockIdx.x - og * nchunks;
+    const int s = blockIdx.y;
+    const int c0 = ch * CCH, nc = (Cin - c0) < CCH ? (Cin - c0) : CCH;
+    const int NJ = nc * 25;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int jbase[TJ];
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) {
+        const int j = lane + 64 * t;
+        const int jc = j / 25, k = j - jc * 25, ky = k / 5, kx = k - ky * 5;
+        jbase[t] = j < NJ ? jc * HH + ky * Hin + kx : 0;   // idle lanes read a valid address; their sums are dropped
+    }
+    float acc[TJ][OCG], dbq[OCG];
+#pragma unroll
+    for (int q = 0; q < OCG; ++q) {
+        dbq[q] = 0.f;
+#pragma unroll
+        for (int t = 0; t < TJ; ++t) acc[t][q] = 0.f;
+    }
+    const int per_wave = (HP2 + 3) / 4;
+    const int pp0 = wave * per_wave, pp1 = (pp0 + per_wave) < HP2 ? (pp0 + per_wave) : HP2;
+    const int b0 = (int)((long long)B * s / S), b1 = (int)((long long)B * (s + 1) / S);
+    const size_t pstride = (size_t)Cout * Cin * 25 + Cout;
+    for (int b = b0; b < b1; ++b) {
+        __syncthreads();
+        const float *inb = in + ((size_t)b * Cin + c0) * HH;
+        for (int i = tid; i < nc * HH; i += 256) plane[i] = inb[i];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < OCG; ++q) {
+            const int oc = og * OCG + q;
+            if (oc < Cout) {
+                const int2 *L = lst + ((size_t)b * Cout + oc) * HP2;
+                float dbs = 0.f;
+                // (issuing the next entries' scalar loads ahead of the gathers by hand — groups of 4, double-buffered —
+                //  measured 40-60 % slower than leaving the schedule to the compiler)
+#pragma unroll 4
+                for (int pp = pp0; pp < pp1; ++pp) {
+                    const int2 e = L[pp];
+                    const float g = __int_as_float(e.y);
+#pragma unroll
+                    for (int t = 0; t < TJ; ++t) acc[t][q] = fmaf(g, plane[jbase[t] + e.x], acc[t][q]);
+                    dbs += g;
+                }
+                dbq[q] += dbs;
+            }
+        }
+    }
+    __syncthreads();
+    float *red = plane, *dbred = plane + 4 * TJ * 64 * OCG;
+#pragma unroll
+    for (int t = 0; t < TJ; ++t)
+#pragma unroll
+        for (int q = 0; q < OCG; ++q) red[((wave * TJ + t) * 64 + lane) * OCG + q] = acc[t][q];
+    if (lane == 0)
+#pragma unroll
+        for (int q = 0; q < OCG; ++q) dbred[wave * OCG + q] = dbq[q];
+    __syncthreads();
+    float *ps_out = part + (size_t)s * pstride;
+    if (tid < NJ) {
+        const int t = tid >> 6, l = tid & 63, jc = tid / 25, k = tid - jc * 25;
+#pragma unroll
+        for (int q = 0; q < OCG; ++q) {
+            float v = 0.f;
+            for (int w = 0; w < 4; ++w) v += red[((w * TJ + t) * 64 + l) * OCG + q];
+            const int oc = og * OCG + q;
+            if (oc < Cout) ps_out[((size_t)oc * Cin + c0 + jc) * 25 + k] = v;
+        }
+    }
+    if (ch == 0 && tid < OCG) {
+        const int oc = og * OCG + tid;
+        if (oc < Cout) ps_out[(size_t)Cout * Cin * 25 + oc] = dbred[tid] + dbred[OCG + tid] + dbred[2 * OCG + tid] + dbred[3 * OCG + tid];
+    }
+    (void)RED;
+}
+
+// Few taps (the first stage on 3-channel images: 75 taps per output channel): lanes cannot all own a tap of ONE list
+// position, so this form keeps the (offset, value) lists of 5 channels in LDS and spreads the threads over (tap, list
+// slice) instead; built from `arg` / `dout` directly.
+template <int OCG, int CCH>
+__global__ __launch_bounds__(256) void conv5_pool2_bwd_w_lds_kernel(
     const float *__restrict__ in, int Cin, int Hin, const float *__restrict__ dout,
     const unsigned char *__restrict__ arg, int Cout, int B, int S, float *__restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -198,12 +302,18 @@ static int conv5_bwd_splits(int B, int Cin, int Cout, int cch) {
     return S < 1 ? 1 : S;
 }
 
+static size_t conv5_bwd_partial_bytes(int B, int Cin, int Cout) {
+    const int s2 = conv5_bwd_splits(B, Cin, Cout, 2), s5 = conv5_bwd_splits(B, Cin, Cout, C5_CCH);   // whatever Hin selects
+    const size_t bytes = (size_t)(s2 > s5 ? s2 : s5) * ((size_t)Cout * Cin * 25 + Cout) * sizeof(float);
+    return (bytes + 255) & ~(size_t)255;
+}
+
 extern "C" {
 
-size_t pngpd_conv5_pool2_bwd_workspace_bytes(int B, int Cin, int Cout) {
-    if (B <= 0 || Cin <= 0 || Cout <= 0) return 0;
-    const int s2 = conv5_bwd_splits(B, Cin, Cout, 2), s5 = conv5_bwd_splits(B, Cin, Cout, C5_CCH);   // whatever Hin selects
-    return (size_t)(s2 > s5 ? s2 : s5) * ((size_t)Cout * Cin * 25 + Cout) * sizeof(float);
+size_t pngpd_conv5_pool2_bwd_workspace_bytes(int B, int Cin, int Hin, int Cout) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || Hin < 6) return 0;
+    const int Hp = (Hin - 4) / 2;
+    return conv5_bwd_partial_bytes(B, Cin, Cout) + (size_t)B * Cout * Hp * Hp * sizeof(int2);   // partials | gradient list
 }
 
 int pngpd_conv5_pool2_bwd(const float *in, int B, int Cin, int Hin, const float *W, int Cout, const float *dout,
@@ -212,17 +322,34 @@ int pngpd_conv5_pool2_bwd(const float *in, int B, int Cin, int Hin, const float 
     if (!in || !W || !dout || !arg || !dW || !db || !workspace || B <= 0 || Cin <= 0 || Cout <= 0 || Hin < 6 ||
         ((Hin - 4) & 1))
         return PNGPD_ERR_INVALID_ARG;
-    if (workspace_bytes < pngpd_conv5_pool2_bwd_workspace_bytes(B, Cin, Cout)) return PNGPD_ERR_WORKSPACE;
+    if (workspace_bytes < pngpd_conv5_pool2_bwd_workspace_bytes(B, Cin, Hin, Cout)) return PNGPD_ERR_WORKSPACE;
     if (din && ((Hin & 3) || Hin > 32)) return PNGPD_ERR_UNSUPPORTED;   // the strip mapping of the input-gradient kernel
     hipStream_t st = (hipStream_t)stream;
     const int Hp = (Hin - 4) / 2, HP2 = Hp * Hp, HH = Hin * Hin;
-    {
-        // big images (the first stage, 60x60): 2 planes per workgroup so that two workgroups share a CU's LDS and one
-        // stages while the other computes; small ones (the second stage): 5 planes, 7 workgroups per CU either way
-        const int cch = Hin > 32 ? 2 : C5_CCH;
+    if (Cin * 25 < 100) {                      // few taps: the LDS-list form, two planes per workgroup
+        constexpr int cch = 2;
         const int S = conv5_bwd_splits(B, Cin, Cout, cch);
         const int plane_floats = cch * HH > 256 * C5_OCG ? cch * HH : 256 * C5_OCG;
         const size_t lds = ((size_t)plane_floats + 2 * (size_t)C5_OCG * HP2) * sizeof(float);
+        if (lds > 150 * 1024) return PNGPD_ERR_UNSUPPORTED;
+        int rc = pngpd_allow_lds((const void *)conv5_pool2_bwd_w_lds_kernel<C5_OCG, cch>, lds);
+        if (rc != PNGPD_OK) return rc;
+        const dim3 grid(((Cout + C5_OCG - 1) / C5_OCG) * ((Cin + cch - 1) / cch), S);
+        hipLaunchKernelGGL((conv5_pool2_bwd_w_lds_kernel<C5_OCG, cch>), grid, dim3(256), lds, st, in, Cin, Hin, dout, arg,
+                           Cout, B, S, (float *)workspace);
+        const int n = Cout * Cin * 25 + Cout;
+        hipLaunchKernelGGL(conv5_bwd_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float *)workspace, S,
+                           Cout * Cin * 25, Cout, dW, db);
+    } else {
+        const long long nl = (long long)B * Cout * HP2;
+        int2 *lst = (int2 *)((char *)workspace + conv5_bwd_partial_bytes(B, Cin, Cout));
+        hipLaunchKernelGGL(conv5_pool_list_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, st, dout, arg, Hin, nl, lst);
+        // big images (the first stage, 60x60): 2 planes per workgroup (29 KB of LDS: five workgroups per CU, one stages
+        // while the others compute); small ones (the second stage): 5 planes = 125 taps, two per lane
+        const int cch = Hin > 32 ? 2 : C5_CCH;
+        const int S = conv5_bwd_splits(B, Cin, Cout, cch);
+        const int tj = (cch * 25 + 63) / 64, red = 4 * tj * 64 * C5_OCG + 4 * C5_OCG;
+        const size_t lds = (size_t)(cch * HH > red ? cch * HH : red) * sizeof(float);
         if (lds > 150 * 1024) return PNGPD_ERR_UNSUPPORTED;
         const void *fn = cch == 2 ? (const void *)conv5_pool2_bwd_w_kernel<C5_OCG, 2>
                                   : (const void *)conv5_pool2_bwd_w_kernel<C5_OCG, C5_CCH>;
@@ -230,11 +357,11 @@ int pngpd_conv5_pool2_bwd(const float *in, int B, int Cin, int Hin, const float 
         if (rc != PNGPD_OK) return rc;
         const dim3 grid(((Cout + C5_OCG - 1) / C5_OCG) * ((Cin + cch - 1) / cch), S);
         if (cch == 2)
-            hipLaunchKernelGGL((conv5_pool2_bwd_w_kernel<C5_OCG, 2>), grid, dim3(256), lds, st, in, Cin, Hin, dout, arg,
-                               Cout, B, S, (float *)workspace);
+            hipLaunchKernelGGL((conv5_pool2_bwd_w_kernel<C5_OCG, 2>), grid, dim3(256), lds, st, in, Cin, Hin, lst, Cout, B, S,
+                               (float *)workspace);
         else
-            hipLaunchKernelGGL((conv5_pool2_bwd_w_kernel<C5_OCG, C5_CCH>), grid, dim3(256), lds, st, in, Cin, Hin, dout,
-                               arg, Cout, B, S, (float *)workspace);
+            hipLaunchKernelGGL((conv5_pool2_bwd_w_kernel<C5_OCG, C5_CCH>), grid, dim3(256), lds, st, in, Cin, Hin, lst, Cout,
+                               B, S, (float *)workspace);
         const int n = Cout * Cin * 25 + Cout;
         hipLaunchKernelGGL(conv5_bwd_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float *)workspace, S,
                            Cout * Cin * 25, Cout, dW, db);

@@ -131,8 +131,8 @@ def conv5_pool2_bwd(x, weight, dout, arg, need_input_grad):
     dW = torch.empty_like(weight)
     db = torch.empty(Cout, device=x.device, dtype=torch.float32)
     dx = torch.empty_like(x) if need_input_grad else None
-    nbytes = _lib.load().pngpd_conv5_pool2_bwd_workspace_bytes(B, Cin, Cout)
-    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+    nbytes = _lib.load().pngpd_conv5_pool2_bwd_workspace_bytes(B, Cin, H, Cout)
+    ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
     _call("pngpd_conv5_pool2_bwd", x, x, B, Cin, H, weight, Cout, dout, arg, dW, db, dx, ws, nbytes)
     return dx, dW, db
 
