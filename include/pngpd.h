@@ -640,6 +640,12 @@ int pngpd_conv5_pool2_bwd(const float *in, int B, int Cin, int Hin, const float 
                           const unsigned char *arg, float *dW, float *db, float *din, void *workspace,
                           size_t workspace_bytes, void *stream);
 int pngpd_relu_bwd(const float *y, float *g, long long n, void *stream);
+/* out = [relu](in @ W^T + bias) for a layer with FEW output tiles and a LONG contraction (gpd.py:27 fc1: 7200 -> 500):
+ * K split over workgroups, partial tiles in `workspace` summed in slice order by a second launch (deterministic).
+ * K % 8 == 0.  The sum order differs from pngpd_fc_fwd's, so the two agree to rounding, not bit for bit.           */
+size_t pngpd_fc_fwd_splitk_workspace_bytes(int B, int K, int Nout);
+int pngpd_fc_fwd_splitk(const float *in, int B, int K, const float *W, const float *bias, int Nout, int relu, float *out,
+                        void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

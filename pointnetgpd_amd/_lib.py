@@ -196,6 +196,9 @@ SIGNATURES = {
     "pngpd_conv5_pool2_bwd": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, ctypes.c_int, c_f32p,
                                              c_void, c_f32p, c_f32p, c_f32p, c_void, ctypes.c_size_t, c_void]),
     "pngpd_relu_bwd": (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_longlong, c_void]),
+    "pngpd_fc_fwd_splitk_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "pngpd_fc_fwd_splitk": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int,
+                                           c_f32p, c_void, ctypes.c_size_t, c_void]),
     "pngpd_hand_box_counts_indexed": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, ctypes.c_int, c_void,
                                                      ctypes.c_int, c_void, ctypes.c_int, c_void, c_void]),
 }

@@ -295,6 +295,74 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const float *__restrict__
     if (i < n) g[i] = y[i] > 0.f ? g[i] : 0.f;
 }
 
+// fc1 of the classifier: (B,7200) x (500,7200)^T is 32 output tiles at B = 64, each a 3,600-MFMA chain when one workgroup
+// owns a tile (pngpd_fc_fwd: 65 us).  Here K is split over KS workgroups per tile (and their four waves): partial tiles in
+// `part` (KS,B,Nout), summed in slice order with the bias / ReLU by a second launch.  Deterministic.
+__global__ __launch_bounds__(256) void fc_splitk_kernel(const float *__restrict__ in, int B, int K,
+                                                        const float *__restrict__ W, int Nout, int KS,
+                                                        float *__restrict__ part) {
+    __shared__ float red[3 * 16 * 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int rb = blockIdx.x, cb = blockIdx.y, ks = blockIdx.z;
+    int row = rb * 32 + j; row = row < B ? row : B - 1;
+    int col = cb * 32 + j; col = col < Nout ? col : Nout - 1;
+    const f32x4 *ap = (const f32x4 *)(in + (size_t)row * K) + h;
+    const f32x4 *wp = (const f32x4 *)(W + (size_t)col * K) + h;
+    const long KBall = K >> 3, U = (long)KS * 4, u = (long)ks * 4 + wave;
+    int kb = (int)(KBall * u / U);
+    const int KB = (int)(KBall * (u + 1) / U);
+    f32x16 acc = {0};
+    for (; kb + 4 <= KB; kb += 4) {
+        f32x4 a[4], w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { a[q] = ap[(kb + q) * 2]; w[q] = wp[(kb + q) * 2]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc = mfma32(a[q][t], w[q][t], acc);
+    }
+    for (; kb < KB; ++kb) {
+        const f32x4 a = ap[kb * 2], w = wp[kb * 2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = mfma32(a[t], w[t], acc);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    const int c = cb * 32 + j;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float v = acc[r] + red[r * 64 + lane] + red[(16 + r) * 64 + lane] + red[(32 + r) * 64 + lane];
+        const int orow = rb * 32 + mfma_row(r, lane);
+        if (c < Nout && orow < B) part[((size_t)ks * B + orow) * Nout + c] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void fc_splitk_finish_kernel(const float *__restrict__ part, int KS, int B, int Nout,
+                                                               const float *__restrict__ bias, int relu,
+                                                               float *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * Nout) return;
+    float v = part[i];
+    for (int s = 1; s < KS; ++s) v += part[(size_t)s * B * Nout + i];
+    v += bias[i % Nout];
+    if (relu) v = (v < 0.f) ? 0.f : v;              // NaN-propagating like F.relu
+    out[i] = v;
+}
+
+static int fc_splitk_slices(int B, int K, int Nout) {
+    const long tiles = (long)((B + 31) / 32) * ((Nout + 31) / 32);
+    long KS = (512 + tiles - 1) / tiles;            // about two workgroups per CU
+    const long most = (K >> 3) / 16;                // at least 4 eight-wide blocks per wave
+    if (KS > most) KS = most;
+    return KS < 1 ? 1 : (int)KS;
+}
+
 static int conv5_bwd_splits(int B, int Cin, int Cout, int cch) {
     const int wgs = ((Cout + C5_OCG - 1) / C5_OCG) * ((Cin + cch - 1) / cch);
     int S = (1024 + wgs - 1) / wgs;
@@ -384,6 +452,23 @@ int pngpd_conv5_pool2_bwd(const float *in, int B, int Cin, int Hin, const float 
 int pngpd_relu_bwd(const float *y, float *g, long long n, void *stream) {
     if (!y || !g || n <= 0) return PNGPD_ERR_INVALID_ARG;
     hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, g, n);
+    return pngpd_launch_status();
+}
+
+size_t pngpd_fc_fwd_splitk_workspace_bytes(int B, int K, int Nout) {
+    if (B <= 0 || K <= 0 || Nout <= 0) return 0;
+    return (size_t)fc_splitk_slices(B, K, Nout) * B * Nout * sizeof(float);
+}
+
+int pngpd_fc_fwd_splitk(const float *in, int B, int K, const float *W, const float *bias, int Nout, int relu, float *out,
+                        void *workspace, size_t workspace_bytes, void *stream) {
+    if (!in || !W || !bias || !out || !workspace || B <= 0 || K <= 0 || Nout <= 0 || (K & 7)) return PNGPD_ERR_INVALID_ARG;
+    if (workspace_bytes < pngpd_fc_fwd_splitk_workspace_bytes(B, K, Nout)) return PNGPD_ERR_WORKSPACE;
+    const int KS = fc_splitk_slices(B, K, Nout);
+    hipLaunchKernelGGL(fc_splitk_kernel, dim3((B + 31) / 32, (Nout + 31) / 32, KS), dim3(256), 0, (hipStream_t)stream, in, B, K,
+                       W, Nout, KS, (float *)workspace);
+    hipLaunchKernelGGL(fc_splitk_finish_kernel, dim3((B * Nout + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)workspace, KS, B, Nout, bias, relu, out);
     return pngpd_launch_status();
 }
 

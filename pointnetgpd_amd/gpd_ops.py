@@ -137,6 +137,18 @@ def conv5_pool2_bwd(x, weight, dout, arg, need_input_grad):
     return dx, dW, db
 
 
+def fc_fwd_splitk(x, weight, bias, relu):
+    """``[relu](x @ W^T + b)`` for a layer with few output tiles and a long contraction (fc1: 7200 -> 500): K split over
+    workgroups, deterministic two-launch reduction."""
+    B, K = x.shape
+    Nout = weight.shape[0]
+    out = torch.empty(B, Nout, device=x.device, dtype=torch.float32)
+    nbytes = _lib.load().pngpd_fc_fwd_splitk_workspace_bytes(B, K, Nout)
+    ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
+    _call("pngpd_fc_fwd_splitk", x, x, B, K, weight, bias, Nout, int(bool(relu)), out, ws, nbytes)
+    return out
+
+
 class GPDNetFn(torch.autograd.Function):
     """GPDClassifier.forward (gpd.py:22-31, dropout off) as one autograd node on libpngpd: two conv+pool stages that
     record their pooling choices, fc1 + ReLU and fc2 + log_softmax on the MFMA FC kernel; backward = log_softmax_bwd,
@@ -151,7 +163,7 @@ class GPDNetFn(torch.autograd.Function):
         p1, a1 = conv5_pool2_arg(x, w1, b1)                          # (B,20,28,28)
         p2, a2 = conv5_pool2_arg(p1, w2, b2)                         # (B,50,12,12)
         flat = p2.view(p2.shape[0], -1)
-        h1 = ops.fc_fwd(flat, fw1, fb1, ops.EPI_RELU)
+        h1 = fc_fwd_splitk(flat, fw1, fb1, True)
         logp = ops.fc_fwd(h1, fw2, fb2, ops.EPI_LOG_SOFTMAX)          # K = 500: the FC kernel's half-block tail
         ctx.save_for_backward(x, w1, p1, a1, w2, flat, a2, fw1, h1, fw2, logp)
         ctx.need_dx = ctx.needs_input_grad[0]

@@ -65,6 +65,6 @@ class GPDClassifier(nn.Module):
         x = gpd_ops.conv5_pool2(x, self.conv1.weight, self.conv1.bias)          # (B,20,28,28)
         x = gpd_ops.conv5_pool2(x, self.conv2.weight, self.conv2.bias)          # (B,50,12,12)
         x = x.view(-1, 7200)
-        x = ops.fc_fwd(x, self.fc1.weight.detach().contiguous(), self.fc1.bias.detach().contiguous(), ops.EPI_RELU)
+        x = gpd_ops.fc_fwd_splitk(x, self.fc1.weight.detach().contiguous(), self.fc1.bias.detach().contiguous(), True)
         return ops.fc_fwd(x, self.fc2.weight.detach().contiguous(), self.fc2.bias.detach().contiguous(),
                           ops.EPI_LOG_SOFTMAX)                                   # K = 500 = 8 * 62 + 4: the kernel's tail

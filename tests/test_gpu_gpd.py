@@ -210,3 +210,21 @@ def test_gpd_classifier_cuda_dropout_is_explicit(cuda_device):
     x.requires_grad_(True)
     with pytest.raises(RuntimeError, match="input images"):
         GPDClassifier(3).to(cuda_device).train()(x).sum().backward()
+
+
+def test_fc_fwd_splitk_vs_torch(cuda_device):
+    """pngpd_fc_fwd_splitk (the classifier's fc1: few output tiles, K = 7200) vs an fp64 composite; ragged B / Nout,
+    slices that do not divide K evenly, a contraction too short to split; deterministic."""
+    from pointnetgpd_amd import gpd_ops
+    g = torch.Generator().manual_seed(8)
+    for (B, K, Nout, relu) in [(1, 7200, 500, True), (37, 7200, 500, True), (64, 7200, 500, False), (200, 1000, 33, True),
+                               (5, 64, 7, False), (33, 8, 40, True)]:
+        a = torch.randn(B, K, generator=g); W = torch.randn(Nout, K, generator=g) / K ** 0.5
+        bias = torch.randn(Nout, generator=g)
+        ref = a.double() @ W.double().T + bias.double()
+        if relu:
+            ref = ref.clamp(min=0)
+        ag, Wg, bg = a.to(cuda_device), W.to(cuda_device), bias.to(cuda_device)
+        out = gpd_ops.fc_fwd_splitk(ag, Wg, bg, relu)
+        np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=2e-5, rtol=1e-5)
+        assert torch.equal(out, gpd_ops.fc_fwd_splitk(ag, Wg, bg, relu))

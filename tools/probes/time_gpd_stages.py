@@ -44,5 +44,6 @@ out = {"B": B, "C": C,
        "bwd2_w_us": t(lambda: gpd_ops.conv5_pool2_bwd(p1, w2, g2, a2, False)),
        "bwd1_w_us": t(lambda: gpd_ops.conv5_pool2_bwd(x, w1, g1, a1, False)),
        "fc1_fwd_us": t(lambda: ops.fc_fwd(flat, fw1, fb1, ops.EPI_RELU)),
+       "fc1_fwd_splitk_us": t(lambda: gpd_ops.fc_fwd_splitk(flat, fw1, fb1, True)),
        "fc1_bwd_us": t(lambda: ops.fc_bwd(gh, flat, fw1))}
 print(json.dumps(out))
