@@ -10,7 +10,7 @@
 //     the scalar unit.  Per-slice partial sums, reduced in a fixed order by a second launch: deterministic, no atomics.
 //   * input (the second stage only — the first stage's input is the image): a workgroup owns (sample, 4 input planes);
 //     the sparse gradient of 25 output channels is expanded into zero-padded planes in LDS and every thread evaluates
-//     the full correlation for a 1x4 strip of pixels with the 100 weights of the channel in registers.
+//     the full correlation for a 1x4 strip of pixels; the channel's 100 weights arrive through the scalar unit.
 // Small, latency-bound VALU kernels: the comparator is not the hot path, these exist so that a CUDA tensor
 // in train() mode has a libpngpd path instead of ATen / MIOpen.
 #include "pngpd_common.h"
@@ -232,7 +232,6 @@ __global__ __launch_bounds__(256) void conv5_pool2_bwd_x_kernel(
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int Hp = (Hin - 4) / 2, HP2 = Hp * Hp, PW = Hin + 4, PP = PW * PW;
     float *pl = sm;                                    // [OCC][PP]: d(conv output) at (y + 4, x + 4), zeros around
-    float *wl = pl + (size_t)OCC * PP;                 // [OCC][ICG][25]
     const int nicg = (Cin + ICG - 1) / ICG;
     const int b = blockIdx.x / nicg, ic0 = (blockIdx.x - b * nicg) * ICG;
     const int SW = Hin / 4, tid = threadIdx.x;
@@ -247,10 +246,6 @@ __global__ __launch_bounds__(256) void conv5_pool2_bwd_x_kernel(
         const int noc = (Cout - oc0) < OCC ? (Cout - oc0) : OCC;
         __syncthreads();
         for (int i = tid; i < noc * PP; i += 256) pl[i] = 0.f;
-        for (int i = tid; i < noc * ICG * 25; i += 256) {
-            const int q = i / (ICG * 25), r = i - q * (ICG * 25), ic = r / 25, k = r - ic * 25;
-            wl[i] = (ic0 + ic < Cin) ? W[((size_t)(oc0 + q) * Cin + ic0 + ic) * 25 + k] : 0.f;
-        }
         __syncthreads();
         for (int i = tid; i < noc * HP2; i += 256) {
             const int q = i / HP2, pp = i - q * HP2;
@@ -262,7 +257,9 @@ __global__ __launch_bounds__(256) void conv5_pool2_bwd_x_kernel(
         if (act)
             for (int q = 0; q < noc; ++q) {
                 const float *P = pl + (size_t)q * PP;
-                const float *Wq = wl + q * ICG * 25;
+                // the 100 weights of (channel, 4 planes) are the same for every thread: read from global memory at a
+                // uniform address they come through the scalar unit and cost no LDS access
+                const float *Wq = W + ((size_t)(oc0 + q) * Cin + ic0) * 25;
 #pragma unroll
                 for (int ky = 0; ky < 5; ++ky) {
                     // din[Y][X0 + d] += dconv[Y - ky][X0 + d - kx] * w[ky][kx]: padded row Y - ky + 4, columns X0 + (d - kx + 4)
@@ -273,7 +270,7 @@ __global__ __launch_bounds__(256) void conv5_pool2_bwd_x_kernel(
                     for (int kx = 0; kx < 5; ++kx)
 #pragma unroll
                         for (int ic = 0; ic < ICG; ++ic) {
-                            const float w = Wq[ic * 25 + ky * 5 + kx];
+                            const float w = Wq[(ic0 + ic < Cin ? ic : 0) * 25 + ky * 5 + kx];
 #pragma unroll
                             for (int d = 0; d < 4; ++d) acc[d][ic] = fmaf(row[d - kx + 4], w, acc[d][ic]);
                         }
@@ -436,7 +433,7 @@ int pngpd_conv5_pool2_bwd(const float *in, int B, int Cin, int Hin, const float 
     }
     if (din) {
         const int PW = Hin + 4;
-        const size_t per_oc = ((size_t)PW * PW + C5_ICG * 25) * sizeof(float);
+        const size_t per_oc = (size_t)PW * PW * sizeof(float);
         int OCC = (int)((48 * 1024) / per_oc);      // 10 channels of a 28x28 stage: three workgroups per CU overlap their staging
         if (OCC > Cout) OCC = Cout;
         if (OCC < 1) return PNGPD_ERR_UNSUPPORTED;
