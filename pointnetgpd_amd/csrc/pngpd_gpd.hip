@@ -256,7 +256,6 @@ __global__ __launch_bounds__(256) void conv5_pool2_kernel(const float *__restric
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int Hc = Hin - 4, Hp = Hc / 2;                       // conv output / pooled output size (square images)
     float *plane = sm;                                          // [CCH][Hin*Hin]
-    float *wl = plane + CCH * Hin * Hin;                        // [OCG][CCH][25]
     const int ngroups = (Cout + OCG - 1) / OCG;
     const int b = blockIdx.x / ngroups, og = blockIdx.x - b * ngroups;
     const int tid = threadIdx.x;
@@ -272,11 +271,6 @@ __global__ __launch_bounds__(256) void conv5_pool2_kernel(const float *__restric
             const int nc = (Cin - c0) < CCH ? (Cin - c0) : CCH;
             __syncthreads();
             for (int i = tid; i < nc * Hin * Hin; i += 256) plane[i] = inb[(size_t)c0 * Hin * Hin + i];
-            for (int i = tid; i < OCG * nc * 25; i += 256) {
-                const int q = i / (nc * 25), r = i - q * (nc * 25);
-                const int oc = og * OCG + q;
-                wl[(q * CCH) * 25 + r] = oc < Cout ? W[((size_t)oc * Cin + c0) * 25 + r] : 0.f;
-            }
             __syncthreads();
             if (act) {
                 for (int c = 0; c < nc; ++c) {
@@ -285,10 +279,16 @@ __global__ __launch_bounds__(256) void conv5_pool2_kernel(const float *__restric
 #pragma unroll
                     for (int yy = 0; yy < 6; ++yy)
 #pragma unroll
-                        for (int xx = 0; xx < 6; ++xx) win[yy][xx] = pl[yy * Hin + xx];
+                        for (int xx = 0; xx < 6; xx += 2) {      // 2 * px and Hin are even: 8-byte aligned pairs
+                            const float2 v = *(const float2 *)(pl + yy * Hin + xx);
+                            win[yy][xx] = v.x; win[yy][xx + 1] = v.y;
+                        }
 #pragma unroll
                     for (int q = 0; q < OCG; ++q) {
-                        const float *wq = wl + (q * CCH + c) * 25;
+                        // the filter of (output channel, input plane) is the same for every thread: read at a uniform
+                        // global address it arrives through the scalar unit, no LDS broadcast per multiply-add
+                        const int ocq = (og * OCG + q) < Cout ? (og * OCG + q) : (Cout - 1);
+                        const float *wq = W + ((size_t)ocq * Cin + c0 + c) * 25;
 #pragma unroll
                         for (int ky = 0; ky < 5; ++ky)
 #pragma unroll
@@ -379,7 +379,7 @@ static int conv5_pool2_launch(const float *in, int B, int Cin, int Hin, const fl
     if (!in || !W || !bias || !out || B <= 0 || Cin <= 0 || Cout <= 0 || Hin < 6 || ((Hin - 4) & 1))
         return PNGPD_ERR_INVALID_ARG;
     constexpr int OCG = 5, CCH = 4;
-    const size_t lds = ((size_t)CCH * Hin * Hin + (size_t)OCG * CCH * 25) * sizeof(float);
+    const size_t lds = (size_t)CCH * Hin * Hin * sizeof(float);
     if (lds > 150 * 1024) return PNGPD_ERR_UNSUPPORTED;
     int st = pngpd_allow_lds(arg ? (const void *)conv5_pool2_kernel<OCG, CCH, true>
                                  : (const void *)conv5_pool2_kernel<OCG, CCH, false>, lds);
