@@ -574,6 +574,30 @@ static int run() {
             for (float v : gw1) s1 += std::fabs(v);
             std::printf("conv5_pool2_bwd max err dW %.2e db %.2e din %.2e; stage-1 |dW| %.6e\n", ew, eb, ep, s1);
             if (ew > 2e-3 || eb > 2e-4 || ep > 2e-4 || !(s1 > 0)) { std::fprintf(stderr, "conv5_pool2_bwd mismatch\n"); return 4; }
+            // fc1 of the classifier through the split-K entry (7200 -> 37 here, ragged tiles), against a host loop
+            {
+                const int NO = 37, KF = 7200;
+                std::vector<float> wf((size_t)NO * KF), bf(NO), of((size_t)Bc * NO);
+                for (auto &v : wf) v = (float)g.next() * 0.04f;
+                for (auto &v : bf) v = (float)g.next();
+                float *dwf, *dbf, *dof, *dwsf;
+                const size_t wsf = pngpd_fc_fwd_splitk_workspace_bytes(Bc, KF, NO);
+                if (upload(wf, &dwf) || upload(bf, &dbf) || dalloc(&dof, (size_t)Bc * NO) || dalloc(&dwsf, wsf / sizeof(float) + 1)) return 2;
+                PN_OK(pngpd_fc_fwd_splitk(dt2, Bc, KF, dwf, dbf, NO, 1, dof, dwsf, wsf, st));
+                HIP_OK(hipStreamSynchronize(st));
+                if (download(dof, of)) return 2;
+                double ef = 0;
+                for (int b = 0; b < Bc; ++b)
+                    for (int o = 0; o < NO; ++o) {
+                        double a2 = bf[o];
+                        for (int k = 0; k < KF; ++k) a2 += (double)t2[(size_t)b * KF + k] * wf[(size_t)o * KF + k];
+                        ef = std::fmax(ef, std::fabs((a2 > 0 ? a2 : 0) - of[(size_t)b * NO + o]));
+                    }
+                double sf = 0;
+                for (float v : of) sf += v;
+                std::printf("fc_fwd_splitk max err %.2e (sum of outputs %.6e)\n", ef, sf);
+                if (ef > 1e-3 || !(sf > 0)) { std::fprintf(stderr, "fc_fwd_splitk mismatch\n"); return 4; }
+            }
         }
     }
     std::printf("index consumer done\n");

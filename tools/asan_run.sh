@@ -22,7 +22,7 @@ RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | he
     LD_LIBRARY_PATH=$(dirname $RT):/opt/rocm/lib HSA_XNACK=1 ASAN_OPTIONS=detect_leaks=0 timeout 200 $A/cabi_consumer_asan $args 2>&1 | grep -v "^pool\|^fc " | tail -22
     echo "exit code: ${PIPESTATUS[0]}"
   done
-  echo "== cabi_index_consumer_asan   (crop count/compact/ranges/gather/resample + indexed / one-launch crop, batch_keep_rows / stack_gather_lists / train_batch, GPG moments (+indexed) / enumerate / sweep / select / pushin / finish + the fused sweep_select / pushin_sweep, GPD projection, depth registration, conv5 stem + its training form and backward)"
+  echo "== cabi_index_consumer_asan   (crop count/compact/ranges/gather/resample + indexed / one-launch crop, batch_keep_rows / stack_gather_lists / train_batch, GPG moments (+indexed) / enumerate / sweep / select / pushin / finish + the fused sweep_select / pushin_sweep, GPD projection, depth registration, conv5 stem + its training form and backward, split-K fc1)"
   LD_LIBRARY_PATH=$(dirname $RT):/opt/rocm/lib HSA_XNACK=1 ASAN_OPTIONS=detect_leaks=0 timeout 400 $A/cabi_index_consumer_asan 2>&1 | tail -30
   echo "exit code: ${PIPESTATUS[0]}"
   echo "== python (torch) with the ASan runtime preloaded: torch's bundled HIP runtime is not instrumented"
