@@ -151,12 +151,15 @@ def fc_fwd_splitk(x, weight, bias, relu):
 
 class GPDNetFn(torch.autograd.Function):
     """GPDClassifier.forward (gpd.py:22-31, dropout off) as one autograd node on libpngpd: two conv+pool stages that
-    record their pooling choices, fc1 + ReLU and fc2 + log_softmax on the MFMA FC kernel; backward = log_softmax_bwd,
-    fc_bwd x2 (one launch each: dW, db, dx), relu_bwd and the two sparse convolution backward kernels."""
+    record their pooling choices, fc1 + ReLU on the split-K FC entry, fc2 + log_softmax on the FC kernel; backward =
+    log_softmax_bwd, fc_bwd x2 (one launch each: dW, db, dx), relu_bwd and the sparse convolution backward kernels."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, fw1, fb1, fw2, fb2):
         from . import ops
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("GPDNetFn: the gradient with respect to the input images is not implemented "
+                               "(main_1v_gpd.py trains the weights only); pass the images without requires_grad")
         x = x.float().contiguous()
         w1, b1, w2, b2 = (t.detach().contiguous() for t in (w1, b1, w2, b2))
         fw1, fb1, fw2, fb2 = (t.detach().contiguous() for t in (fw1, fb1, fw2, fb2))
@@ -166,7 +169,6 @@ class GPDNetFn(torch.autograd.Function):
         h1 = fc_fwd_splitk(flat, fw1, fb1, True)
         logp = ops.fc_fwd(h1, fw2, fb2, ops.EPI_LOG_SOFTMAX)          # K = 500: the FC kernel's half-block tail
         ctx.save_for_backward(x, w1, p1, a1, w2, flat, a2, fw1, h1, fw2, logp)
-        ctx.need_dx = ctx.needs_input_grad[0]
         return logp
 
     @staticmethod
@@ -178,8 +180,5 @@ class GPDNetFn(torch.autograd.Function):
         _call("pngpd_relu_bwd", h1, h1, dh1, h1.numel())
         dflat, dfw1, dfb1 = ops.fc_bwd(dh1, flat, fw1)
         dp1, dw2, db2 = conv5_pool2_bwd(p1, w2, dflat.view(a2.shape), a2, True)
-        if ctx.need_dx:
-            raise RuntimeError("GPDNetFn: the gradient with respect to the input images is not implemented "
-                               "(main_1v_gpd.py trains the weights only)")
         _, dw1, db1 = conv5_pool2_bwd(x, w1, dp1, a1, False)
         return None, dw1, db1, dw2, db2, dfw1, dfb1, dfw2, dfb2
