@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PNGPD_ABI_VERSION 5
+#define PNGPD_ABI_VERSION 6
 
 enum {
     PNGPD_OK = 0,
@@ -66,6 +66,33 @@ const char *pngpd_strerror(int code);
 int pngpd_fold_conv_bn(const float *W, const float *b, const float *gamma, const float *beta,
                        const float *mean, const float *var, float eps, int C, int K, int layout,
                        float *Wf, float *bf, void *stream);
+
+/*
+ * Fold EVERY layer of a model in ONE launch (round 6): the eval-mode forward re-derives its folded / packed weights
+ * from the live parameters on every call — what the reference does implicitly by reading `self.convX.weight` /
+ * `self.bnX.running_mean` in every forward (pointnet.py:29-31,35-37,144-147,191-193) — instead of trusting a cache
+ * keyed by tensor version counters, which an in-place edit through `.data` does not bump.  ~13 MB of traffic for a
+ * PointNetCls (1.6 M weights in, folded copies out): a few microseconds, no host synchronisation, graph-capturable.
+ * Per layer (the arithmetic of pngpd_fold_conv_bn, fp64): any subset of three outputs —
+ *     row   (C,K) fp32 row-major            (PNGPD_LAYOUT_ROWMAJOR)
+ *     mfma  (C,K) fp32 MFMA_B fragments     (PNGPD_LAYOUT_MFMA_B; C % 32 == 0, K % 8 == 0)
+ *     x3    2*C*K halfwords                 (pngpd_split_pack_bf16 of the folded row-major weight; C % 32 == 0, K % 16 == 0)
+ * plus the folded bias bf (C).  gamma == NULL: no BatchNorm (Wf = W, bf = b).
+ */
+#define PNGPD_FOLD_MAX_LAYERS 16
+typedef struct pngpd_fold_layer {
+    const float *W, *b, *gamma, *beta, *mean, *var;
+    float eps;
+    int C, K;
+    float *row, *mfma;
+    void *x3;
+    float *bf;
+} pngpd_fold_layer_t;
+typedef struct pngpd_fold_model {
+    int n;                                          /* layers used, 1..PNGPD_FOLD_MAX_LAYERS */
+    pngpd_fold_layer_t layer[PNGPD_FOLD_MAX_LAYERS];
+} pngpd_fold_model_t;
+int pngpd_fold_model(const pngpd_fold_model_t *m, void *stream);
 
 /*
  * Fused per-point MLP 3->64->128->1024 (BN folded, ReLU after layers 1,2 and — iff
@@ -405,7 +432,7 @@ typedef struct pngpd_head_train {
  * sink: >= 512 x CU-count floats of scratch (never written).                                                          */
 int pngpd_probe_mfma_rate(int dtype, int waves_per_simd, int iters, float *sink, long long *flops_out, void *stream);
 
-size_t pngpd_struct_bytes(int which);   /* sizeof of pngpd_trunk_train_t (0) / pngpd_head_train_t (1): FFI self-check */
+size_t pngpd_struct_bytes(int which);   /* sizeof of pngpd_trunk_train_t (0) / pngpd_head_train_t (1) / pngpd_fold_model_t (2): FFI self-check */
 size_t pngpd_head_train_save_bytes(const pngpd_head_train_t *a);        /* reads B, H1, H2 */
 size_t pngpd_head_train_scratch_bytes(const pngpd_head_train_t *a);     /* reads B, H1, H2, k */
 int pngpd_head_train_fwd(const pngpd_head_train_t *a, void *stream);

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PNGPD_LIB") or os.path.join(_HERE, "libpngpd.so")   # PNGPD_LIB: A/B builds only
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 _load_error = None
@@ -43,12 +43,27 @@ class HeadTrainArgs(ctypes.Structure):
                  ("target", _P), ("loss", _P), ("gloss", _P), ("loss_mean", _I)])
 
 
+FOLD_MAX_LAYERS = 16
+
+
+class FoldLayer(ctypes.Structure):
+    """``pngpd_fold_layer_t`` of include/pngpd.h."""
+    _fields_ = ([(n, _P) for n in ("W", "b", "gamma", "beta", "mean", "var")] + [("eps", _F), ("C", _I), ("K", _I)] +
+                [(n, _P) for n in ("row", "mfma", "x3", "bf")])
+
+
+class FoldModel(ctypes.Structure):
+    """``pngpd_fold_model_t`` of include/pngpd.h."""
+    _fields_ = [("n", _I), ("layer", FoldLayer * FOLD_MAX_LAYERS)]
+
+
 # name -> (restype, argtypes); mirrors include/pngpd.h one-to-one (checked by tests).
 SIGNATURES = {
     "pngpd_abi_version": (ctypes.c_int, []),
     "pngpd_strerror": (ctypes.c_char_p, [ctypes.c_int]),
     "pngpd_fold_conv_bn": (ctypes.c_int, [c_f32p] * 6 + [ctypes.c_float, ctypes.c_int, ctypes.c_int,
                                                        ctypes.c_int, c_f32p, c_f32p, c_void]),
+    "pngpd_fold_model": (ctypes.c_int, [c_void, c_void]),
     "pngpd_trunk_infer_splits": (ctypes.c_int, [ctypes.c_int] * 3),
     "pngpd_trunk_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
     "pngpd_trunk_fwd_infer": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, c_f32p] + [c_f32p] * 6 +

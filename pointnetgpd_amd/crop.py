@@ -154,7 +154,8 @@ def crop_resample(cloud, frames, counts, idx, num_points, mode=MODE_INFER, min_p
     The draw of grasp g depends on ``(seed, g_base + g)`` only: pass the GLOBAL index of ``frames[0]`` as ``g_base``
     and a candidate draws the same points in every sharding / batching of the candidate list.
     ``rows`` (G) int32 (``batch_keep_rows``): grasp g is written to ``out[rows[g]]``, nothing when ``rows[g] < 0``;
-    ``out`` may then be a caller-owned (>= kept, 3, N) buffer.
+    ``out`` may then be a caller-owned buffer of at least G rows (the worst-case kept count: ``rows`` lives on the
+    device, so its maximum cannot be checked here without a synchronisation, and the kernel does not bound it).
 
     ``ranges`` / ``gather``: the same per-grasp cloud description the count pass was given
     (``crop_count_compact_ranges`` / ``_gather``).  They matter only for grasps holding MORE than ``max_keep`` in-box
@@ -166,8 +167,8 @@ def crop_resample(cloud, frames, counts, idx, num_points, mode=MODE_INFER, min_p
     if out is None:
         out = torch.empty(G, 3, num_points, device=cloud.device, dtype=torch.float32)
     elif (not out.is_cuda or out.dtype != torch.float32 or not out.is_contiguous() or out.dim() != 3
-          or tuple(out.shape[1:]) != (3, num_points) or out.shape[0] < (G if rows is None else 1)):
-        raise RuntimeError("out: expected a contiguous CUDA (rows,3,N) float32 tensor")
+          or tuple(out.shape[1:]) != (3, num_points) or out.shape[0] < G):
+        raise RuntimeError("out: expected a contiguous CUDA (>= G,3,N) float32 tensor")
     valid = torch.empty(G, device=cloud.device, dtype=torch.uint8)
     if rows is not None:
         if not rows.is_cuda or rows.dtype != torch.int32 or tuple(rows.shape) != (G,):

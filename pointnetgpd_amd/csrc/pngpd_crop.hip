@@ -423,6 +423,12 @@ __device__ __forceinline__ int crop_indexed_list(const void *__restrict__ cloud,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long below = (1ull << lane) - 1ull;
     int running = 0;
+    // A world-space sphere of radius r covers [a - r |m_i|, a + r |m_i|] along frame axis i: scale by the row norms, so
+    // the cull stays conservative for ANY (G,18) frame this public entry is handed (a mesh -> cloud transform with
+    // scale, un-normalised axes), not only for the unit rows crop.py builds.
+    const double rn0 = sqrt(F.m[0] * F.m[0] + F.m[1] * F.m[1] + F.m[2] * F.m[2]) * (1.0 + 1e-9);
+    const double rn1 = sqrt(F.m[3] * F.m[3] + F.m[4] * F.m[4] + F.m[5] * F.m[5]) * (1.0 + 1e-9);
+    const double rn2 = sqrt(F.m[6] * F.m[6] + F.m[7] * F.m[7] + F.m[8] * F.m[8]) * (1.0 + 1e-9);
     for (int cbase = 0; cbase < C; cbase += 256) {
         // ---- broad phase: 256 chunks, ordered compaction of the survivors into ch_list
         const int c = cbase + tid;
@@ -432,8 +438,9 @@ __device__ __forceinline__ int crop_indexed_list(const void *__restrict__ cloud,
             double a, b, cc;
             to_frame(F, sp.x, sp.y, sp.z, a, b, cc);
             const double r = sp.w * (1.0 + 1e-9) + 1e-12;
-            pass = a + r > F.lo[0] && a - r < F.hi[0] && b + r > F.lo[1] && b - r < F.hi[1] && cc + r > F.lo[2] &&
-                   cc - r < F.hi[2];
+            const double r0 = r * rn0, r1 = r * rn1, r2 = r * rn2;
+            pass = a + r0 > F.lo[0] && a - r0 < F.hi[0] && b + r1 > F.lo[1] && b - r1 < F.hi[1] && cc + r2 > F.lo[2] &&
+                   cc - r2 < F.hi[2];
         }
         const unsigned long long pm = __ballot(pass);
         __syncthreads();                                    // (the previous round's readers of ch_list are done)

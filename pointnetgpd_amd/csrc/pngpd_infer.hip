@@ -5,6 +5,7 @@
 //   PointNetGPD/model/pointnet.py:191-194 PointNetCls head + log_softmax
 //   eval-mode bn(conv(x)) / bn(fc(x)) pairs  :29-31,35-36,144-147,191-192  (folded into the weights)
 #include "pngpd_common.h"
+#include "pngpd_bf.h"
 
 // ---------------------------------------------------------------------------------------
 // BN fold + weight layout
@@ -35,6 +36,45 @@ __global__ void fold_conv_bn_kernel(const float *__restrict__ W, const float *__
         double bb = b ? (double)b[c] : 0.0;
         if (gamma && var) bb = (bb - (double)mean[c]) * s + (double)beta[c];
         bf[c] = (float)bb;
+    }
+}
+
+// Every layer of a model in one launch (pngpd_fold_model): block -> layer by the prefix table, then the arithmetic of
+// fold_conv_bn_kernel, written to up to three layouts.  The bf16 split is split_pack_bf16_kernel's (pngpd_bf.h split2).
+struct FoldModelDev {
+    pngpd_fold_model_t m;
+    int blk0[PNGPD_FOLD_MAX_LAYERS + 1];
+};
+__global__ __launch_bounds__(256) void fold_model_kernel(const FoldModelDev A) {
+    int li = 0;
+#pragma unroll 1
+    while (li + 1 < A.m.n && (int)blockIdx.x >= A.blk0[li + 1]) ++li;
+    const pngpd_fold_layer_t &L = A.m.layer[li];
+    const int idx = ((int)blockIdx.x - A.blk0[li]) * 256 + (int)threadIdx.x;
+    const int C = L.C, K = L.K;
+    if (idx >= C * K) return;
+    const int c = idx / K, k = idx - c * K;
+    double s = 1.0;
+    if (L.gamma) s = L.var ? (double)L.gamma[c] / sqrt((double)L.var[c] + (double)L.eps) : (double)L.gamma[c];
+    const float wv = (float)((double)L.W[idx] * s);
+    if (L.row) L.row[idx] = wv;
+    if (L.mfma) {
+        const int cb = c >> 5, j = c & 31, kb = k >> 3, h = (k >> 2) & 1, t = k & 3;
+        L.mfma[(((cb * (K >> 3) + kb) * 64) + h * 32 + j) * 4 + t] = wv;
+    }
+    if (L.x3) {
+        u16 hi, lo;
+        split2(wv, hi, lo);
+        const int cb = c >> 5, j = c & 31, ks = k >> 4, h = (k >> 3) & 1, t = k & 7, KS = K >> 4;
+        const size_t base = ((size_t)(cb * KS + ks) * 2) * 64 * 8 + (size_t)(h * 32 + j) * 8 + t;
+        u16 *out = (u16 *)L.x3;
+        out[base] = hi;
+        out[base + 64 * 8] = lo;
+    }
+    if (k == 0) {
+        double bb = L.b ? (double)L.b[c] : 0.0;
+        if (L.gamma && L.var) bb = (bb - (double)L.mean[c]) * s + (double)L.beta[c];
+        L.bf[c] = (float)bb;
     }
 }
 
@@ -154,6 +194,25 @@ int pngpd_fold_conv_bn(const float *W, const float *b, const float *gamma, const
     int total = C * K;
     hipLaunchKernelGGL(fold_conv_bn_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        W, b, gamma, beta, mean, var, eps, C, K, layout, Wf, bf);
+    return pngpd_launch_status();
+}
+
+int pngpd_fold_model(const pngpd_fold_model_t *m, void *stream) {
+    if (!m || m->n <= 0 || m->n > PNGPD_FOLD_MAX_LAYERS) return PNGPD_ERR_INVALID_ARG;
+    FoldModelDev A;
+    A.m = *m;
+    int blk = 0;
+    for (int i = 0; i < m->n; ++i) {
+        const pngpd_fold_layer_t &L = m->layer[i];
+        if (!L.W || !L.bf || L.C <= 0 || L.K <= 0 || (!L.row && !L.mfma && !L.x3)) return PNGPD_ERR_INVALID_ARG;
+        if (L.gamma && L.var && (!L.beta || !L.mean)) return PNGPD_ERR_INVALID_ARG;
+        if (L.mfma && ((L.C & 31) || (L.K & 7))) return PNGPD_ERR_INVALID_ARG;
+        if (L.x3 && ((L.C & 31) || (L.K & 15))) return PNGPD_ERR_INVALID_ARG;
+        A.blk0[i] = blk;
+        blk += (L.C * L.K + 255) / 256;
+    }
+    for (int i = m->n; i <= PNGPD_FOLD_MAX_LAYERS; ++i) A.blk0[i] = blk;
+    hipLaunchKernelGGL(fold_model_kernel, dim3(blk), dim3(256), 0, (hipStream_t)stream, A);
     return pngpd_launch_status();
 }
 

@@ -118,8 +118,9 @@ bool carve_bwd(Carve &c, const TrunkDims &d, TrunkBwdScratch &w) {
 
 extern "C" {
 
-size_t pngpd_struct_bytes(int which) {   /* 0: pngpd_trunk_train_t, 1: pngpd_head_train_t — binding self-check */
-    return which == 0 ? sizeof(pngpd_trunk_train_t) : which == 1 ? sizeof(pngpd_head_train_t) : 0;
+size_t pngpd_struct_bytes(int which) {   /* 0: pngpd_trunk_train_t, 1: pngpd_head_train_t, 2: pngpd_fold_model_t — binding self-check */
+    return which == 0 ? sizeof(pngpd_trunk_train_t) : which == 1 ? sizeof(pngpd_head_train_t)
+         : which == 2 ? sizeof(pngpd_fold_model_t) : 0;
 }
 
 size_t pngpd_trunk_train_save_bytes(const pngpd_trunk_train_t *a) {

@@ -109,6 +109,10 @@ class DeviceGraspLoader:
                 chunks.append(pc)
                 off += len(pc)
             g = np.asarray(np.load(dataset.d_grasp[obj]), dtype=np.float64)[:per]
+            if len(g) < per:
+                # the reference indexes ``np.load(...)[grasp_ind]`` with grasp_ind < grasp_amount_per_file
+                # (dataset.py:421-430) and raises IndexError on a short file; so does this loader, up front
+                raise IndexError(f"{dataset.d_grasp[obj]}: {len(g)} grasps, grasp_amount_per_file = {per}")
             lab = [dataset._label(r[-2] + r[-1] * 0.01) for r in g]        # dataset.py:446-453 / :535-541, once
             self.files.append(files)
             self._frames[oi * per:oi * per + len(g)] = crop.frames_from_grasps_train(g, dataset.transform[obj][1])

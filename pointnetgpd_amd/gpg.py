@@ -99,14 +99,21 @@ def _ws_ring(dev):
 _EIG_POOL = None
 
 
+def _eig_workers():
+    from .hostbudget import threads_per_rank
+    return threads_per_rank(cap=8)
+
+
 def _batched_eig(M):
     """``np.linalg.eig`` of a (n,3,3) stack — the very LAPACK call of the reference (:1493; its eigenvector signs decide
     the sweep's enumeration order), one matrix at a time inside numpy's gufunc loop.  Each matrix is solved on its own, so
     slicing the stack over a few host threads returns the same bits (numpy releases the GIL inside the loop): 20,000
-    matrices take 28 ms on one core of the GPU box and 4.3 ms on eight."""
+    matrices take 28 ms on one core of the GPU box and 4.3 ms on eight.  The pool is this RANK's share of the node
+    (hostbudget.threads_per_rank: affinity mask and cgroup quota divided by the ranks on the node — eight ranks of a
+    config-5 run do not start 64 threads on a host that has 8 cores for all of them)."""
     global _EIG_POOL
     n = M.shape[0]
-    workers = min(8, os.cpu_count() or 1)
+    workers = _eig_workers()
     if n < 512 or workers < 2:
         return np.linalg.eig(M)
     if _EIG_POOL is None:
@@ -227,15 +234,25 @@ class CloudIndex:
         cloud = _check_cloud(cloud)
         P = cloud.shape[0]
         pts = cloud.double()
-        lo = pts.min(0).values
-        ext = (pts.max(0).values - lo).clamp_min(1e-30)
-        q = ((pts - lo) / ext * 1023.0).long().clamp_(0, 1023)
+        # A non-finite point can be inside no box (every face test is a strict comparison that NaN / Inf fail — the
+        # reference drops exactly that point, kinect2grasp.py:218-229), but it must not poison the index: it takes no
+        # part in the bounding box or in its chunk's sphere (a stand-in finite point does) and sorts to the end.  The
+        # point VALUES in ``self.cloud`` are untouched, so the narrow phase still rejects it and only it.  No host sync.
+        fin = torch.isfinite(pts).all(1)
+        anchor = pts[torch.argmax(fin.to(torch.uint8))]
+        safe = torch.where(fin[:, None], pts, anchor[None, :])
+        lo = safe.min(0).values
+        ext = (safe.max(0).values - lo).clamp_min(1e-30)
+        q = ((safe - lo) / ext * 1023.0).long().clamp_(0, 1023)
         code = _spread3(q[:, 0]) | (_spread3(q[:, 1]) << 1) | (_spread3(q[:, 2]) << 2)
-        order = torch.argsort(code)
+        code = torch.where(fin, code, torch.full_like(code, 1 << 30))
+        # stable: points with equal codes keep their input order, so the sorted cloud — and with it every keyed
+        # resampling draw downstream — is the same on every rank and in every run
+        order = torch.argsort(code, stable=True)
         self.order = order.int().contiguous()              # sorted position -> original index
         self.cloud = cloud[order].contiguous()
         C = (P + 63) // 64
-        sp = pts[order]
+        sp = safe[order]
         if C * 64 != P:                                   # pad the last chunk with its own last point
             sp = torch.cat([sp, sp[-1:].expand(C * 64 - P, 3)], 0)
         sp = sp.view(C, 64, 3)

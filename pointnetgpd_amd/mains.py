@@ -66,7 +66,9 @@ def build_parser():
     p.add_argument("--save-interval", type=int, default=1)
     # additive (defaults reproduce the reference)
     p.add_argument("--seed", type=int, default=None, help="fix numpy/torch seeds (reference: time-based)")
-    p.add_argument("--num-workers", type=int, default=32)
+    p.add_argument("--num-workers", type=int, default=32,
+                   help="DataLoader workers of the NODE (the reference's single process had 32 for all its GPUs, "
+                        "main_1v.py:124); under torchrun every rank starts num_workers / ranks-on-the-node")
     p.add_argument("--synthetic", type=int, default=0, metavar="G",
                    help="train/eval on G synthetic in-gripper clouds instead of the YCB files")
     p.add_argument("--max-batches", type=int, default=0, help="stop every epoch after this many batches")
@@ -159,7 +161,9 @@ def per_rank_batch(batch_size, world):
 def _make_loaders(cfg, args, world=1, rank=0, local_rank=0):
     from .model import dataset as ds
     args.rank_batch = per_rank_batch(args.batch_size, world)
-    common = dict(batch_size=args.rank_batch, num_workers=args.num_workers, pin_memory=True, shuffle=True,
+    from .hostbudget import workers_per_rank
+    args.rank_workers = workers_per_rank(args.num_workers) if world > 1 else args.num_workers
+    common = dict(batch_size=args.rank_batch, num_workers=args.rank_workers, pin_memory=True, shuffle=True,
                   worker_init_fn=worker_init_fn, collate_fn=my_collate)
     if args.synthetic:
         tr = SyntheticGraspDataset(args.synthetic, cfg["num_points"], cfg["k"], seed=1)
@@ -248,6 +252,12 @@ def run(variant, argv=None):
         np.random.seed(args.seed); torch.manual_seed(args.seed)
     logger = _ScalarLog(os.path.join(args.log_dir, args.tag)) if rank == 0 else None
     train_loader, test_loader, sampler = _make_loaders(cfg, args, world, rank, local_rank)
+    if os.environ.get("PNGPD_HOST_BUDGET_REPORT"):
+        # test hook: what this rank took of the node's host budget (tests/test_gpu_ddp.py sums the ranks' reports)
+        from . import hostbudget
+        with open(os.path.join(os.environ["PNGPD_HOST_BUDGET_REPORT"], f"rank{rank}.json"), "w") as f:
+            json.dump({"rank": rank, "loader_workers": args.rank_workers, "eig_threads": hostbudget.threads_per_rank(),
+                       "cpus": hostbudget.cpus(), "local_world": hostbudget.local_world()}, f)
 
     device = torch.device("cpu")
     if args.cuda:
@@ -268,10 +278,10 @@ def run(variant, argv=None):
     model = model.to(device)
     averager = ddp.GradAverager(model) if world > 1 else None
     if args.cuda:
-        from . import train as _train
-        from .model import pointnet as _pn
-        _train.set_train_precision(args.precision)
-        _pn.set_inference_precision(args.precision)
+        if hasattr(model, "set_precision"):
+            model.set_precision(args.precision)      # per model (arith.py): stored on the module, pickled with it
+        elif args.precision != "fp32":
+            raise SystemExit("--precision needs a pointnetgpd_amd model (the loaded module has no set_precision)")
     elif args.precision != "fp32":
         raise SystemExit("--precision needs --cuda (the CPU path is the plain ATen composite)")
 

@@ -70,7 +70,8 @@ class GradGroup:
             if w[i]:
                 raise RuntimeError("FlatAdam: a gradient slice was written twice before step() — the fused backward "
                                    "OVERWRITES gradients (no accumulation over micro-batches or repeated module "
-                                   "calls); use train.set_sequencing('passes') or torch.optim.Adam for accumulation")
+                                   "calls); use model.set_precision(sequencing='passes') or torch.optim.Adam for "
+                                   "accumulation")
             w[i] = 1
 
 
@@ -99,7 +100,30 @@ def grad_group(params):
     return g
 
 
+def ungroup(params):
+    """Called by the NON-fused call paths (pass-by-pass sequencing, DEBUG_STASH) at forward time: their gradients
+    arrive by autograd ACCUMULATION.  A slice a fused backward used to overwrite (``_grouped``) was exempt from
+    ``zero_grad`` and may hold a stale gradient — zero it once and hand it back to the accumulate-and-clear regime."""
+    for p in params:
+        e = _GRAD_VIEWS.get(p)
+        if e is None:
+            continue
+        view, owner, i = e
+        opt = owner()
+        if opt is not None and opt._grouped[i]:
+            opt._grouped[i] = 0
+            if not opt._written[i]:
+                view.zero_()
+    _GROUPS.pop(id(params[0]), None)
+
+
 class FlatAdam(torch.optim.Optimizer):
+    """Bias correction uses ONE step count for the whole buffer (``_step``; torch.optim.Adam keeps one per parameter).
+    They agree whenever every parameter takes part in every step — the case for a PointNetCls.  A fused piece that sat
+    out k steps (its slices are skipped, as torch skips ``grad is None``) resumes with the GLOBAL count in its bias
+    correction where torch would use its own smaller count: after the first few hundred steps the two corrections are
+    both within 1e-3 of 1, before that the resumed piece takes slightly smaller steps than torch's would."""
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False):
         params = [p for p in params]
         if not params:
@@ -156,18 +180,18 @@ class FlatAdam(torch.optim.Optimizer):
         autograd parameter next to the fused pieces, e.g. a custom head on a ``PointNetfeat`` — receives its gradient by
         autograd ACCUMULATION into the same view and is zeroed here; with pass-by-pass / ATen sequencing that is every
         parameter (one fill of the whole buffer).  A slice written twice raises (``mark_written``)."""
-        from . import train
         for p, gv in zip(self._params, self._views):
             if p.grad is not gv:
                 p.grad = gv
         self._written[:] = bytes(len(self._written))
-        if train._use_fused():
-            if any(self._grouped):
-                for i, gv in enumerate(self._views):
-                    if not self._grouped[i]:
-                        gv.zero_()
-                return
-            # no fused piece has registered yet (first step, or a model without one): clear everything
+        if any(self._grouped):
+            # ``_grouped`` is set when a fused piece registers (optim.grad_group) and cleared when the same parameters
+            # go through a non-fused call path again (optim.ungroup): no process-global sequencing flag is consulted
+            for i, gv in enumerate(self._views):
+                if not self._grouped[i]:
+                    gv.zero_()
+            return
+        # no fused piece has registered yet (first step, or a model without one): clear everything
         self.flat_g.zero_()
 
     def _settle_gradients(self):
@@ -176,8 +200,6 @@ class FlatAdam(torch.optim.Optimizer):
         to leave untouched this step: slices of a fused piece that took no part in this step's backward (an unused or
         eval-mode sub-module) hold a STALE gradient — ``torch.optim.Adam`` skips a parameter whose ``.grad`` is None,
         and so does this update (no momentum-only drift).  Plain autograd parameters always update."""
-        from . import train
-        fused = train._use_fused()
         skip = []
         for i, (p, gv) in enumerate(zip(self._params, self._views)):
             g = p.grad
@@ -187,7 +209,7 @@ class FlatAdam(torch.optim.Optimizer):
                 else:
                     gv.copy_(g)
                 p.grad = gv
-            elif fused and self._grouped[i] and not self._written[i] and any(self._written):
+            elif self._grouped[i] and not self._written[i] and any(self._written):
                 skip.append(i)
         self._written[:] = bytes(len(self._written))
         return skip

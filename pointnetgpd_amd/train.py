@@ -25,49 +25,33 @@ import ctypes
 
 import torch
 
-from . import _lib, ops
+from . import _lib, arith, ops
 from .ops import _call
 
 F64 = torch.float64
-# Arithmetic of the trunk's matrix contractions: "fp32" exact (default); "bf16x3" opt-in 3-term split-bf16 products
-# (same parity bars as fp32); "bf16" opt-in plain bf16 operands (BASELINE configs[2]; errors measured in
-# tests/test_gpu_bf16.py).  In the two opt-in modes EVERY pass contracts on the bf16 matrix cores — pass C
-# (trunk_fwd_train_x3_kernel) and the side passes B / gather / D / E (the NT variants of the fp32 kernels: fp32 LDS
-# tiles, operands converted when they are read).  ``fp32_side_passes=True`` keeps B / gather / D / E on the exact
-# fp32 kernels (round 2's first bf16 mode).  BatchNorm statistics, masks, every accumulator and the parameter-sized
-# algebra between the passes stay fp32 / fp64 in all modes.
-_TRAIN_PRECISION = "fp32"
-_FP32_SIDE_PASSES = False
+# Arithmetic of the trunk's matrix contractions (per model, arith.py): "fp32" exact (default); "bf16x3" opt-in 3-term
+# split-bf16 products (same parity bars as fp32); "bf16" opt-in plain bf16 operands (BASELINE configs[2]; errors measured
+# in tests/test_gpu_bf16.py).  In the two opt-in modes EVERY pass contracts on the bf16 matrix cores — pass C
+# (trunk_fwd_train_x3_kernel) and the side passes B / gather / D / E.  ``fp32_side_passes=True`` keeps B / gather / D / E
+# on the exact fp32 kernels (round 2's first bf16 mode).  BatchNorm statistics, masks, every accumulator and the
+# parameter-sized algebra between the passes stay fp32 / fp64 in all modes.
+# ``refine_pool`` (reduced-precision modes only): re-evaluate the pooled maxima in exact fp32 at the arg-max points the
+# bf16 / bf16x3 pass C chose (pngpd_trunk_pool_refine).  0 off (round 3's behaviour), 1 on the fp32 matrix pipe, 2 on the
+# VALU.  The pooled values are single numbers that carried the full bf16 product error into the FC stacks'
+# batch-statistics BatchNorms; after the refinement the matrix pass contributes only the CHOICE of the point.
 _NTERMS = {"bf16x3": 3, "bf16": 1}
-# Reduced-precision modes only: re-evaluate the pooled maxima in exact fp32 at the arg-max points the bf16 / bf16x3
-# pass C chose (pngpd_trunk_pool_refine).  0 off (round 3's behaviour), 1 on the fp32 matrix pipe, 2 on the VALU.
-# The pooled values are single numbers that carried the full bf16 product error into the FC stacks' batch-statistics
-# BatchNorms; after the refinement the matrix pass contributes only the CHOICE of the point.
-_REFINE_POOL = 2
 _REFINE_VALU_VARIANT = 1      # == PNGPD_REFINE_VALU_VARIANT (pngpd_internal.h)
 
 
 def set_train_precision(mode, fp32_side_passes=False, refine_pool=None):
-    global _TRAIN_PRECISION, _FP32_SIDE_PASSES, _REFINE_POOL
-    if mode not in ("fp32", "bf16x3", "bf16"):
-        raise ValueError("precision must be 'fp32', 'bf16x3' or 'bf16'")
-    _TRAIN_PRECISION = mode
-    _FP32_SIDE_PASSES = bool(fp32_side_passes)
-    if refine_pool is not None:
-        if int(refine_pool) not in (0, 1, 2):
-            raise ValueError("refine_pool must be 0 (off), 1 (matrix pipe) or 2 (VALU)")
-        _REFINE_POOL = int(refine_pool)
-
-
-_SEQUENCING = "fused"
+    """Deprecated shim (rounds 1-5): edits the PROCESS DEFAULT; ``model.set_precision(...)`` is per model."""
+    arith.set_default(train=mode, fp32_side_passes=bool(fp32_side_passes), refine_pool=refine_pool)
 
 
 def set_sequencing(mode):
-    """"fused": one C-ABI call per trunk / head direction (default); "passes": pass-by-pass from Python."""
-    global _SEQUENCING
-    if mode not in ("fused", "passes"):
-        raise ValueError("sequencing must be 'fused' or 'passes'")
-    _SEQUENCING = mode
+    """Deprecated shim: process default of "fused" (one C-ABI call per trunk / head direction) | "passes" (pass by pass
+    from Python); per model: ``model.set_precision(sequencing=...)``."""
+    arith.set_default(sequencing=mode)
 
 
 DEBUG_STASH = None   # set to a dict to capture backward intermediates (tests/test_gpu_train.py::test_trunk_backward_intermediates)
@@ -117,8 +101,9 @@ class TrunkTrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, trans, W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, g3, be3, relu_last, eps,
-                momentum, bufs1, bufs2, bufs3):
+                momentum, bufs1, bufs2, bufs3, cfg):
         B, _, N = x.shape
+        precision, fp32_side, refine_pool = cfg.train, cfg.fp32_side_passes, cfg.refine_pool
         dev = x.device
         x = x.contiguous()
         T = trans.detach().contiguous() if trans is not None else None
@@ -140,8 +125,8 @@ class TrunkTrainFn(torch.autograd.Function):
         # ---- pass B + BN2
         w2p = ops.pack_mfma_b(w2)
         # z2 = W2 h1 is computed once, here, and handed to passes C / D / E (512 B per point; 256 B in plain-bf16 mode)
-        nt = 0 if _TRAIN_PRECISION == "fp32" else _NTERMS[_TRAIN_PRECISION]
-        nt_side = 0 if _FP32_SIDE_PASSES else nt      # arithmetic of passes B / gather / D / E
+        nt = 0 if precision == "fp32" else _NTERMS[precision]
+        nt_side = 0 if fp32_side else nt      # arithmetic of passes B / gather / D / E
         w2x = ops.split_pack_bf16(w2) if nt else None
         if nt_side:
             # z2 is computed once, here, and read back by passes C / D / E: fp32 tiles in bf16x3 mode, bf16 tiles (half
@@ -162,7 +147,7 @@ class TrunkTrainFn(torch.autograd.Function):
         # ---- pass C + BN3 + pool
         sgn = torch.where(g3c >= 0, *_pm_one(dev))        # cached 0-dim +1 / -1: no per-step scalar fills
         Sc = S
-        if _TRAIN_PRECISION != "fp32":
+        if precision != "fp32":
             w3s = (w3 * sgn[:, None]).contiguous()
             pmax, parg, psum, psh, Sc = ops.trunk_fwd_train_bf(x, T, w1, b1c, s1c, t1c, w2x, s2c,
                                                                t2c, ops.split_pack_bf16(w3s), S, nterms=nt,
@@ -179,9 +164,9 @@ class TrunkTrainFn(torch.autograd.Function):
         pooled, idx, zhat = _e(dev, B, 1024), _e(dev, B, 1024, dtype=torch.int32), _e(dev, B, 1024)
         _call("pngpd_pool_finalize", x, pmax, parg, B, Sc, stats3, g3c, be3c, float(eps), int(relu_last), pooled,
               idx, zhat)
-        if nt and _REFINE_POOL:
+        if nt and refine_pool:
             # the reduced-precision pass chose the points; their values are re-evaluated in exact fp32
-            if _REFINE_POOL == 1:
+            if refine_pool == 1:
                 zex = ops.trunk_pool_refine(x, T, w1, b1c, s1c, t1c, w2p, s2c, t2c, idx,
                                             w3sp=ops.pack_mfma_b(w3, scale=sgn), variant=0)
             else:
@@ -259,7 +244,7 @@ class TrunkTrainFn(torch.autograd.Function):
                 dW1.view(64, 3, 1), z(64), dg1, dbe1,
                 dW2.view(128, 64, 1), z(128), dg2, dbe2,
                 dW3.view(1024, 128, 1), z(1024), dg3, dbe3,
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
 def _s2_full(S2c, dev):
@@ -382,7 +367,7 @@ class FusedTrunkFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, trans, W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, g3, be3, relu_last, eps, momentum,
-                bufs1, bufs2, bufs3, grad_outs):
+                bufs1, bufs2, bufs3, grad_outs, cfg):
         B, _, N = x.shape
         dev = x.device
         x = x.contiguous()
@@ -395,9 +380,9 @@ class FusedTrunkFn(torch.autograd.Function):
         a.x, a.trans, a.B, a.N = x.data_ptr(), _dp(T), B, N
         a.S = ops.train_splits(B, N)
         a.relu_last = int(bool(relu_last))
-        a.precision = _PREC_CODE[_TRAIN_PRECISION]
-        a.fp32_side = int(_FP32_SIDE_PASSES)
-        a.refine = _REFINE_POOL if a.precision else 0
+        a.precision = _PREC_CODE[cfg.train]
+        a.fp32_side = int(cfg.fp32_side_passes)
+        a.refine = cfg.refine_pool if a.precision else 0
         need_bwd = any(ctx.needs_input_grad) or grad_outs is not None
         a.need_bwd = int(need_bwd)
         a.eps, a.momentum = float(eps), float(momentum)
@@ -464,7 +449,7 @@ class FusedTrunkFn(torch.autograd.Function):
             v = views
             grads = (v[0].view(64, 3, 1), v[1], v[2], v[3], v[4].view(128, 64, 1), v[5], v[6], v[7],
                      v[8].view(1024, 128, 1), v[9], v[10], v[11])
-        return (None, dT) + grads + (None,) * 7
+        return (None, dT) + grads + (None,) * 8
 
 
 class FusedHeadFn(torch.autograd.Function):
@@ -558,8 +543,8 @@ def _bufs(bn):
     return (bn.running_mean, bn.running_var, bn.num_batches_tracked) if bn.track_running_stats else None
 
 
-def _use_fused():
-    return _SEQUENCING == "fused" and DEBUG_STASH is None
+def _use_fused(cfg=None):
+    return (cfg.sequencing if cfg is not None else arith.default("sequencing")) == "fused" and DEBUG_STASH is None
 
 
 def _grad_outs(params):
@@ -568,21 +553,30 @@ def _grad_outs(params):
     return grad_group(params)
 
 
+def _ungroup(params):
+    """Non-fused call path: the parameters' gradients arrive by autograd accumulation (optim.ungroup)."""
+    from .optim import ungroup
+    ungroup(params)
+
+
 def trunk_train(mod, x, trans, relu_last):
     """Train-mode trunk of a module holding conv1..3 / bn1..3."""
     mom = mod.bn1.momentum if mod.bn1.momentum is not None else 0.1
-    if _use_fused():
+    cfg = arith.resolve(mod)
+    if _use_fused(cfg):
         params = (mod.conv1.weight, mod.conv1.bias, mod.bn1.weight, mod.bn1.bias,
                   mod.conv2.weight, mod.conv2.bias, mod.bn2.weight, mod.bn2.bias,
                   mod.conv3.weight, mod.conv3.bias, mod.bn3.weight, mod.bn3.bias)
         return FusedTrunkFn.apply(x, trans, *params, bool(relu_last), float(mod.bn1.eps), float(mom),
-                                  _bufs(mod.bn1), _bufs(mod.bn2), _bufs(mod.bn3), _grad_outs(params))
+                                  _bufs(mod.bn1), _bufs(mod.bn2), _bufs(mod.bn3), _grad_outs(params), cfg)
+    _ungroup((mod.conv1.weight, mod.conv1.bias, mod.bn1.weight, mod.bn1.bias, mod.conv2.weight, mod.conv2.bias,
+              mod.bn2.weight, mod.bn2.bias, mod.conv3.weight, mod.conv3.bias, mod.bn3.weight, mod.bn3.bias))
     return TrunkTrainFn.apply(x, trans,
                               mod.conv1.weight, mod.conv1.bias, mod.bn1.weight, mod.bn1.bias,
                               mod.conv2.weight, mod.conv2.bias, mod.bn2.weight, mod.bn2.bias,
                               mod.conv3.weight, mod.conv3.bias, mod.bn3.weight, mod.bn3.bias,
                               bool(relu_last), float(mod.bn1.eps), float(mom),
-                              _bufs(mod.bn1), _bufs(mod.bn2), _bufs(mod.bn3))
+                              _bufs(mod.bn1), _bufs(mod.bn2), _bufs(mod.bn3), cfg)
 
 
 def fc_bn_relu_train(lin, bn, inp):
@@ -594,18 +588,20 @@ def fc_epilogue_train(lin, inp, epilogue):
     return LinearEpiFn.apply(inp, lin.weight, lin.bias, epilogue)
 
 
-def head_train(fc1, bn1, fc2, bn2, fc3, inp, epilogue, target=None, reduction="mean"):
+def head_train(fc1, bn1, fc2, bn2, fc3, inp, epilogue, target=None, reduction="mean", cfg=None):
     """relu(bn1(fc1(inp))) -> relu(bn2(fc2(.))) -> fc3 + tail, train mode (pointnet.py:35-43, :191-194).
     ``target`` (B,) int64: also returns ``F.nll_loss(out, target, reduction=reduction)`` (main_1v.py:74) -> (out, loss);
     in fused sequencing the loss and its backward run inside the head's own two foreign calls."""
     if reduction not in ("mean", "sum"):
         raise ValueError("reduction must be 'mean' or 'sum'")
-    if _use_fused():
+    if _use_fused(cfg):
         mom = bn1.momentum if bn1.momentum is not None else 0.1
         params = (fc1.weight, fc1.bias, bn1.weight, bn1.bias, fc2.weight, fc2.bias, bn2.weight, bn2.bias,
                   fc3.weight, fc3.bias)
         return FusedHeadFn.apply(inp, *params, int(epilogue), float(bn1.eps), float(mom), _bufs(bn1), _bufs(bn2),
                                  _grad_outs(params), target, reduction == "mean")
+    _ungroup((fc1.weight, fc1.bias, bn1.weight, bn1.bias, fc2.weight, fc2.bias, bn2.weight, bn2.bias,
+              fc3.weight, fc3.bias))
     g = fc_bn_relu_train(fc1, bn1, inp)
     g = fc_bn_relu_train(fc2, bn2, g)
     out = fc_epilogue_train(fc3, g, epilogue)

@@ -93,6 +93,7 @@ def test_missing_library_fails_loudly(monkeypatch):
 def test_argument_validation_of_every_family():
     """Each entry family rejects bad arguments with a status code BEFORE any launch (testable without a GPU).
     Non-null dummy addresses are never dereferenced on these paths."""
+    import ctypes
     from pointnetgpd_amd import _lib
     lib = _lib.load()
     p = 0x1000                                             # dummy non-null "device pointer"
@@ -118,6 +119,16 @@ def test_argument_validation_of_every_family():
     assert lib.pngpd_reduce_partials4(*([None, 0, 0, 0, None] * 4), None) == INV                   # no segment
     assert lib.pngpd_reduce_partials4(p, 1, 0, 8, p, *([None, 0, 0, 0, None] * 3), None) == INV    # R == 0
     assert lib.pngpd_fold_conv_bn(p, p, None, None, None, None, 1e-5, 30, 8, 1, p, p, None) == INV      # MFMA_B needs C % 32 == 0
+    fm = _lib.FoldModel()
+    assert lib.pngpd_fold_model(None, None) == INV
+    assert lib.pngpd_fold_model(ctypes.addressof(fm), None) == INV                                 # n == 0
+    fm.n = 1
+    fm.layer[0].W, fm.layer[0].bf, fm.layer[0].C, fm.layer[0].K = 64, 64, 30, 8
+    assert lib.pngpd_fold_model(ctypes.addressof(fm), None) == INV                                 # no output requested
+    fm.layer[0].mfma = 64
+    assert lib.pngpd_fold_model(ctypes.addressof(fm), None) == INV                                 # MFMA_B needs C % 32 == 0
+    fm.layer[0].mfma, fm.layer[0].x3, fm.layer[0].C = None, 64, 32
+    assert lib.pngpd_fold_model(ctypes.addressof(fm), None) == INV                                 # split-bf16 needs K % 16 == 0
     assert lib.pngpd_fc_fwd(p, 4, 10, p, p, 3, 0, p, None) == INV                                  # K % 4 != 0
     assert lib.pngpd_fc_fwd(p, 4, 16, p, p, 40, 3, p, None) == INV                                 # log_softmax needs Nout <= 32
     assert lib.pngpd_strerror(UNSUP) == b"unsupported configuration"
@@ -134,13 +145,15 @@ def _header_struct_fields(name):
         if not decl:
             continue
         # "const float *w1, *b1, *g1, *be1" / "int B, N" / "void *save" / "size_t save_bytes" / "long long *nbt1"
+        decl = re.sub(r"\[[^\]]*\]", "", decl)          # array extents are not field names
         first, *rest = decl.split(",")
         fields.append(re.findall(r"[A-Za-z_][A-Za-z0-9_]*", first)[-1])
         fields += [re.findall(r"[A-Za-z_][A-Za-z0-9_]*", r)[-1] for r in rest]
     return fields
 
 
-@pytest.mark.parametrize("cname,which,cls", [("pngpd_trunk_train", 0, "TrunkTrainArgs"), ("pngpd_head_train", 1, "HeadTrainArgs")])
+@pytest.mark.parametrize("cname,which,cls", [("pngpd_trunk_train", 0, "TrunkTrainArgs"), ("pngpd_head_train", 1, "HeadTrainArgs"),
+                                             ("pngpd_fold_layer", None, "FoldLayer"), ("pngpd_fold_model", 2, "FoldModel")])
 def test_argument_structs_mirror_the_header(cname, which, cls):
     """The ctypes.Structure mirrors of the two training-entry argument structs: same fields in the same order as the
     header, and the same size as the compiled library's sizeof (no compute call)."""
@@ -148,7 +161,8 @@ def test_argument_structs_mirror_the_header(cname, which, cls):
     from pointnetgpd_amd import _lib
     st = getattr(_lib, cls)
     assert [f[0] for f in st._fields_] == _header_struct_fields(cname)
-    assert _lib.load().pngpd_struct_bytes(which) == ctypes.sizeof(st)
+    if which is not None:
+        assert _lib.load().pngpd_struct_bytes(which) == ctypes.sizeof(st)
 
 
 def test_training_entries_validate_arguments():

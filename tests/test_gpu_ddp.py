@@ -248,12 +248,14 @@ def test_cli_eight_ranks_configs2_command_on_one_gpu(tmp_path, cuda_device):
     DistributedSampler, the flat-buffer gradient all-reduce in two buckets, eval with rank 0's statistics, rank 0's
     checkpoint — every rank on cuda:0 over gloo (debug switch), so that the first real 8-GPU launch is boring."""
     import time
-    env = dict(os.environ, PNGPD_BENCH_DEBUG_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    (tmp_path / "budget").mkdir()
+    env = dict(os.environ, PNGPD_BENCH_DEBUG_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               PNGPD_HOST_BUDGET_REPORT=str(tmp_path / "budget"))
     env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "pointnetgpd_amd", "main_1v_mc.py"), "--mode", "train",
            "--epoch", "1", "--batch-size", "4096", "--cuda", "--precision", "bf16x3", "--synthetic", str(8 * 700),
-           "--num-workers", "0", "--model-path", str(tmp_path / "m"), "--log-dir", str(tmp_path / "l"), "--seed", "1",
+           "--num-workers", "16", "--model-path", str(tmp_path / "m"), "--log-dir", str(tmp_path / "l"), "--seed", "1",
            "--tag", "c2"]
     t0 = time.perf_counter()
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
@@ -268,3 +270,10 @@ def test_cli_eight_ranks_configs2_command_on_one_gpu(tmp_path, cuda_device):
     m = torch.load(ckpt, map_location="cpu", weights_only=False)
     assert m.fc3.out_features == 3 and int(m.feat.bn3.num_batches_tracked) == 2   # 512 + 188 per rank: two steps
     assert all(torch.isfinite(p).all() for p in m.parameters())
+    assert m.get_precision().train == "bf16x3"                                  # the arithmetic travels in the pickle
+    # node-level host budget: --num-workers is the NODE total, the eig pool a share of the node's CPUs
+    import json
+    reps = [json.load(open(tmp_path / "budget" / f"rank{r}.json")) for r in range(8)]
+    assert all(r["local_world"] == 8 for r in reps)
+    assert sum(r["loader_workers"] for r in reps) == 16 and all(r["loader_workers"] == 2 for r in reps)
+    assert sum(r["eig_threads"] for r in reps) <= max(reps[0]["cpus"], 8)       # at most one thread per rank beyond the CPUs

@@ -1,6 +1,7 @@
 # Evidence of a round (GPU box): full GPU suite, smoke, default bench, per-config / scoring / sampler / loader benches,
 # kernel traces and PMC passes.  usage: bash tools/final_round.sh TAG     Every profiler call is bounded by a timeout.
-TAG=${1:-r05}
+TAG=${1:-r06}
+FAILED=""
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -27,7 +28,10 @@ bash tools/trace_train.sh ${TAG} bf16 > /tmp/tr.log 2>&1; grep "rc=" /tmp/tr.log
 bash tools/trace_train.sh ${TAG} bf16x3 > /tmp/tr.log 2>&1; grep "rc=" /tmp/tr.log
 bash tools/pmc_round.sh ${TAG} hbm > /tmp/pmc.log 2>&1; grep "rc=" /tmp/pmc.log
 bash tools/pmc_train.sh ${TAG} > /tmp/pmct.log 2>&1; grep "rc=" /tmp/pmct.log
-timeout 300 python tools/bench_strong.py 2>/dev/null > gpurun_out/${TAG}_bench_strong.jsonl
+# the strong-scaling table: stderr is KEPT (RCCL's banner goes there; r05 swallowed a failure and committed an empty table)
+timeout 400 python tools/bench_strong.py > gpurun_out/${TAG}_bench_strong.jsonl 2> gpurun_out/${TAG}_bench_strong.err; rc=$?
+echo "bench_strong rc=$rc rows=$(grep -c step_ms gpurun_out/${TAG}_bench_strong.jsonl)"
+if [ $rc -ne 0 ] || ! grep -q projection gpurun_out/${TAG}_bench_strong.jsonl; then echo "FAILED: bench_strong (see gpurun_out/${TAG}_bench_strong.err)"; tail -5 gpurun_out/${TAG}_bench_strong.err; FAILED="$FAILED bench_strong"; fi
 timeout 120 ./examples/cabi_index_consumer > gpurun_out/${TAG}_index_consumer.txt 2>&1
 [ -x pointnetgpd_amd/csrc/build/asan/cabi_index_consumer_asan ] && bash tools/asan_run.sh ${TAG} > /dev/null 2>&1
 PNGPD_GATE_DIAG=1 timeout 1200 python -m pytest tests/test_gpu_grad_gate.py -m gpu -q -s 2>&1 | grep "gate B=\|passed\|failed" | cut -c1-6000 > gpurun_out/${TAG}_gate_diag.txt
@@ -41,3 +45,7 @@ for f in trace_small_train trace_small_eval; do rm -rf /tmp/pst; ( cd /tmp && ti
 # per-phase wave-cycle accounting of passes C / D / E (a -DPNGPD_TIMING build of the library in build_probe/)
 [ -f build_probe/lib_tm.so ] && PNGPD_LIB=$GRAFT_REPO_ROOT/build_probe/lib_tm.so timeout 200 python tools/phase_times.py 2>/dev/null | grep -v "^B " > gpurun_out/${TAG}_phase_times.txt
 ls gpurun_out | grep ${TAG}
+# every evidence file must be non-trivial: an empty / banner-only file is reported, never silently committed
+for f in gpurun_out/${TAG}_*; do [ $(wc -c < $f) -lt 64 ] && { echo "SUSPICIOUS (under 64 bytes): $f"; FAILED="$FAILED $f"; }; done
+[ -n "$FAILED" ] && { echo "final_round: FAILED STEPS:$FAILED"; exit 1; }
+echo "final_round: all steps produced evidence"
