@@ -629,6 +629,84 @@ def train_pass_rooflines(B, N, dev, reps=None):
             "trunk_passes_frac": round(tot_gf / tot_ms / PEAK_FP32_MFMA_TFLOPS, 4)}
 
 
+def train_pass_rooflines_bf(B, N, dev, nterms, reps=None, checksums=False):
+    """Per-pass rooflines of the reduced-precision training step's trunk kernels (nterms 1 = plain bf16, BASELINE
+    configs[2]'s arithmetic; 3 = bf16x3), timed NOW with HIP events on the launch stream, on synthetic but valid
+    operands of the step's shape.  For every pass: the matrix GFLOP it EXECUTES on the bf16 pipe (nterms x the fp32
+    pass's FLOPs: each product is nterms instructions) against the 2.5 PFLOP/s dense bf16 peak, AND the HBM bytes it
+    must move (the z2 / g2 tiles it reads or writes: 256 B per point and tensor in bf16 storage, 512 B in fp32
+    storage, plus its other operands) against 8 TB/s — the side passes of these modes are bounded by the latter, which
+    is why both fractions are printed and the larger one is named as the bound."""
+    import torch
+    from pointnetgpd_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = synth_clouds(B, N, 1, dev)
+    T = (torch.eye(3)[None] + 0.1 * torch.randn(B, 3, 3, generator=g)).to(dev).contiguous()
+    r = lambda *sh: torch.randn(*sh, generator=g).to(dev)
+    w1, b1 = r(64, 3), r(64) * 0.1
+    s1c, t1c = (torch.rand(64, generator=g) + 0.5).to(dev) * 30, r(64) * 0.1
+    w2 = r(128, 64) / 8; w3 = r(1024, 128) / 11
+    w2p = ops.pack_mfma_b(w2)
+    w2x, w3x, w2tx = ops.split_pack_bf16(w2), ops.split_pack_bf16(w3), ops.split_pack_bf16(w2.t().contiguous())
+    s2c, t2c = (torch.rand(128, generator=g) + 0.5).to(dev), r(128) * 0.1
+    is2, nm2, is1, nm1 = s2c.clone(), t2c.clone(), s1c.clone(), t1c.clone()
+    idx = torch.randint(0, N, (B, 1024), generator=g, dtype=torch.int32).to(dev)
+    coef = r(B, 1024) * 1e-3
+    A = r(128, 128) * 1e-3; Ax = ops.split_pack_bf16(((A + A.t()) / 2).contiguous()); cvec = r(128) * 1e-3
+    ev = r(3, 128)
+    g3 = (torch.rand(1024, generator=g) + 0.5).to(dev)
+    S = ops.train_splits(B, N)
+    reps = reps or (10 if B * N >= 512 * 1024 else 50)
+
+    def timeit(fn):
+        out = fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            out = fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps, out
+
+    tile_b = 256 if nterms == 1 else 512          # bytes per point of one z2 / g2 tile tensor
+    M = B * N
+    res, outs = {}, {}
+    ms, (part, z2t) = timeit(lambda: ops.trunk_bn2_stats_bf(x, T, w1, b1, s1c, t1c, w2x, S, nterms))
+    res["B bn2 stats (+ z2 store)"] = (ms, 12 * M + tile_b * M); outs["B.part"] = part; outs["B.z2t"] = z2t
+    ms, o = timeit(lambda: ops.trunk_fwd_train_bf(x, T, w1, b1, s1c, t1c, w2x, s2c, t2c, w3x, S, nterms=nterms, z2t=z2t))
+    res["C forward"] = (ms, tile_b * M + 16 * B * 1024); outs["C.pmax"], outs["C.parg"], outs["C.psum"], outs["C.psh"] = o[:4]
+    ms, Gp = timeit(lambda: ops.trunk_bwd_gather_bf(x, T, w1, b1, s1c, t1c, w2x, s2c, t2c, idx, coef, nterms))
+    res["gather"] = (ms, 8 * B * 1024 + 64 * B * 1024 + Gp.numel() * 4); outs["gather.Gp"] = Gp
+    ms, (g2t, pa, ps2) = timeit(lambda: ops.trunk_bwd_d_bf(x, s2c, t2c, is2, nm2, Ax, cvec, w3, idx, coef, S, z2t, nterms))
+    res["D"] = (ms, 2 * tile_b * M + 8 * B * 1024 + ps2.numel() * 4); outs["D.g2t"], outs["D.pa"], outs["D.ps2"] = g2t, pa, ps2
+    ms, o = timeit(lambda: ops.trunk_bwd_e_bf(x, T, w1, b1, s1c, t1c, is1, nm1, is2, nm2, ev[0], ev[1], ev[2], w2tx, g2t, S,
+                                              z2t, nterms))
+    res["E"] = (ms, 2 * tile_b * M + 12 * M + o[2].numel() * 4); outs["E.pc"], outs["E.pR"], outs["E.pW2"] = o
+    ms, zex = timeit(lambda: ops.trunk_pool_refine(x, T, w1, b1, s1c, t1c, w2p, s2c, t2c, idx, w3=w3, g3=g3, variant=1))
+    res["pool refine (exact fp32 at the arg-max points)"] = (ms, 64 * B * 1024 + 8 * B * 1024); outs["refine.zex"] = zex
+    out, tot_ms = {}, 0.0
+    for name, (ms, nbytes) in res.items():
+        gf = B * N * EXEC_FLOP_PER_POINT_TRUNK.get(name, 0) * nterms / 1e9
+        if name.startswith("pool refine"):
+            gf = B * 1024 * (2 * (3 * 64 + 64 * 128) + 2 * 128) / 1e9         # layers 1-2 + one 128-long dot per point, fp32
+        tf = gf / ms
+        gbs = nbytes / ms / 1e6
+        fm, fh = tf / PEAK_BF16_MFMA_TFLOPS, gbs / HBM_PEAK_GBS
+        out[name] = {"gflop_bf16_pipe": round(gf, 2), "hbm_mb": round(nbytes / 1e6, 1), "avg_ms": round(ms, 4),
+                     "tflops": round(tf, 1), "frac_of_bf16_mfma_peak": round(fm, 4), "hbm_gbs": round(gbs, 1),
+                     "frac_of_hbm_peak": round(fh, 4), "bound": "hbm" if fh >= fm else "mfma"}
+        tot_ms += ms
+    blk = {"nterms": nterms, "peak_mfma": PEAK_BF16_MFMA_TFLOPS, "peak_hbm": HBM_PEAK_GBS, "splits": S, "reps": reps,
+           "tile_bytes_per_point": tile_b,
+           "timing": "HIP events on the launch stream around `reps` launches of each pass entry, in this run",
+           "passes": out, "trunk_passes_ms_x2": round(2 * tot_ms, 4)}
+    if checksums:
+        blk["checksums"] = {k: (float(v.double().sum().item()) if v.dtype != torch.int16 else
+                                float(v.to(torch.int64).sum().item()),
+                                float(v.double().abs().sum().item()) if v.dtype != torch.int16 else
+                                float(v.to(torch.int64).abs().sum().item())) for k, v in outs.items()}
+    return blk
+
+
 def configs_block(dev, budget_reps=(6, 3)):
     """BASELINE configs[2]'s per-GPU share (B 512, N 1024, k 3 — its own bf16 arithmetic, bf16x3 and exact fp32) and
     configs[3] (B 512, N 4096, k 2) on THIS GPU: eval forward and training step (forward_loss + backward + FlatAdam, no
@@ -1024,6 +1102,12 @@ def main():
             pass_roof = train_pass_rooflines(B, N, dev)
         except Exception as e:      # noqa: BLE001  a diagnostic block: never fail the bench over it
             pass_roof = {"error": repr(e)}
+    pass_roof_bf = None
+    if not args.no_train and not args.no_fast:
+        try:
+            pass_roof_bf = {"bf16": train_pass_rooflines_bf(B, N, dev, 1), "bf16x3": train_pass_rooflines_bf(B, N, dev, 3)}
+        except Exception as e:      # noqa: BLE001
+            pass_roof_bf = {"error": repr(e)}
     traffic, traffic_src = None, None
     if world == 1 and env_world == 0 and not args.no_pmc:
         # the driver's line is self-contained: two counter passes (rocprofv3 child processes of THIS run) over
@@ -1096,6 +1180,8 @@ def main():
             if pass_roof is not None:
                 pass_roof["step_ms"] = train_res.get("ms_per_step")
                 res["roofline_train"] = pass_roof
+            if pass_roof_bf is not None:
+                res["roofline_train_bf16"] = pass_roof_bf
             res["value_train"] = train_res["value"]
             res["value_train_is"] = "training-step leg (fwd + nll_loss + bwd + Adam, exact fp32), grasps/s, same batch"
         if c5 is not None:

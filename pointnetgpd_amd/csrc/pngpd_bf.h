@@ -22,17 +22,30 @@ __device__ __forceinline__ f32x16 mfma_bf(const f32x4 &a, const f32x4 &b, f32x16
                                                    c, 0, 0, 0);
 }
 
+// Two fp32 values -> one dword of two bf16 (element 0 in the low half): ONE v_cvt_pk_bf16_f32.  (Round 6: the scalar
+// form — (__bf16)x per value, halves merged with shifts and ors — compiled to one v_cvt_pk_bf16_f32 PER VALUE plus a
+// v_lshlrev / v_or_b32_sdwa pair per dword: 3.5 VALU instructions per packed pair, 272 + 120 + 152 of the 1,270 VALU
+// instructions of a pass-D tile in plain-bf16 mode.  Same instruction, same round-to-nearest-even: results unchanged.)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned bf_pk2(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+// hi dword as above and the dword of the two residuals x - float(hi) (the bf16x3 split of a pair: 5 instructions)
+__device__ __forceinline__ void bf_split_pk2(float a, float b, unsigned &hi, unsigned &lo) {
+    hi = bf_pk2(a, b);
+    const f32x2 r = f32x2{a, b} - f32x2{__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+    lo = bf_pk2(r[0], r[1]);
+}
+
 // Eight fp32 values (k order v[0..7]) -> the hi operand quad and, for NT == 3, the residual quad.
 template <int NT>
 __device__ __forceinline__ void bf_pack8(const float (&v)[8], f32x4 &hi, f32x4 &lo) {
     unsigned hw[4], lw[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        u16 h0, h1, l0 = 0, l1 = 0;
-        if (NT == 3) { split2(v[2 * p], h0, l0); split2(v[2 * p + 1], h1, l1); }
-        else { h0 = bf16_bits(v[2 * p]); h1 = bf16_bits(v[2 * p + 1]); }
-        hw[p] = (unsigned)h0 | ((unsigned)h1 << 16);
-        lw[p] = (unsigned)l0 | ((unsigned)l1 << 16);
+        if (NT == 3) bf_split_pk2(v[2 * p], v[2 * p + 1], hw[p], lw[p]);
+        else { hw[p] = bf_pk2(v[2 * p], v[2 * p + 1]); lw[p] = 0u; }
     }
     hi = f32x4{__uint_as_float(hw[0]), __uint_as_float(hw[1]), __uint_as_float(hw[2]), __uint_as_float(hw[3])};
     lo = f32x4{__uint_as_float(lw[0]), __uint_as_float(lw[1]), __uint_as_float(lw[2]), __uint_as_float(lw[3])};
@@ -67,10 +80,10 @@ __device__ __forceinline__ void bf_wfrag(const u16 *__restrict__ wx, int KS, int
 // accesses per lane instead of eight.
 __device__ __forceinline__ uint4 bf_tile_pack(const float (&v)[8]) {
     uint4 o;
-    o.x = (unsigned)bf16_bits(v[0]) | ((unsigned)bf16_bits(v[1]) << 16);
-    o.y = (unsigned)bf16_bits(v[2]) | ((unsigned)bf16_bits(v[3]) << 16);
-    o.z = (unsigned)bf16_bits(v[4]) | ((unsigned)bf16_bits(v[5]) << 16);
-    o.w = (unsigned)bf16_bits(v[6]) | ((unsigned)bf16_bits(v[7]) << 16);
+    o.x = bf_pk2(v[0], v[1]);
+    o.y = bf_pk2(v[2], v[3]);
+    o.z = bf_pk2(v[4], v[5]);
+    o.w = bf_pk2(v[6], v[7]);
     return o;
 }
 __device__ __forceinline__ void bf_tile_unpack(const uint4 &q, float (&v)[8]) {

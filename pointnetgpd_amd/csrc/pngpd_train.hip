@@ -1245,6 +1245,8 @@ __global__ __launch_bounds__(256, 2) void trunk_bwd_e_kernel(
     }
 }
 
+#include "pngpd_bwd_bf.h"   // round 6: passes D / E of the bf16 modes, own structure
+
 // ---------------------------------------------------------------------------------------
 // BatchNorm1d over the batch (FC stacks) — train forward / backward, optional fused ReLU.
 // block = 16 channels x 64 row lanes (1024 threads); thread (cx, ry) owns rows ry, ry+64, ...  With REG (B <= 1024)
@@ -1837,10 +1839,24 @@ int pngpd_trunk_bwd_d_bf(const float *x, int B, int N, const float *s2c, const f
     TrainChan P = make_chan(nullptr, nullptr, nullptr, nullptr, nullptr, s2c, t2c);   // z2 is read back: layers 1-2 unused
     BwdDParams D; D.is2 = is2; D.nm2 = nm2; D.Ap = nullptr; D.Ax = (const u16 *)Ax; D.cvec = cvec; D.w3 = w3;
     D.idx = idx; D.coef = coef;
-    const size_t lds = (BWD_D_LDS_FLOATS - TP * H1S) * sizeof(float);
     const dim3 grid((unsigned)B * S);
+#ifdef PNGPD_BF_LEGACY_D      // the inherited kernel (fp32 LDS tiles, operands converted at every read): A/B builds only
+    const size_t lds = (BWD_D_LDS_FLOATS - TP * H1S) * sizeof(float);
     return nterms == 1 ? launch_bwd_d<true, 1>(grid, lds, (hipStream_t)stream, x, N, nullptr, P, D, T, S, z2t, g2t, pa, ps2)
                        : launch_bwd_d<true, 3>(grid, lds, (hipStream_t)stream, x, N, nullptr, P, D, T, S, z2t, g2t, pa, ps2);
+#else
+    const size_t lds = nterms == 1 ? DBF_LDS_BYTES(1) : DBF_LDS_BYTES(3);
+    const void *fn = nterms == 1 ? (const void *)trunk_bwd_d_bf_kernel<1> : (const void *)trunk_bwd_d_bf_kernel<3>;
+    int st = pngpd_allow_lds(fn, lds);
+    if (st != PNGPD_OK) return st;
+    if (nterms == 1)
+        hipLaunchKernelGGL(trunk_bwd_d_bf_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, N, P, D, T, S,
+                           (const f32x4 *)z2t, (f32x4 *)g2t, pa, ps2);
+    else
+        hipLaunchKernelGGL(trunk_bwd_d_bf_kernel<3>, grid, dim3(256), lds, (hipStream_t)stream, N, P, D, T, S,
+                           (const f32x4 *)z2t, (f32x4 *)g2t, pa, ps2);
+    return pngpd_launch_status();
+#endif
 }
 
 int pngpd_trunk_bwd_e(const float *x, int B, int N, const float *trans,
@@ -1884,8 +1900,29 @@ int pngpd_bwd_e_impl(const float *x, int B, int N, const float *trans, const flo
     const size_t lds = (BWD_E_LDS_FLOATS + K128_LDS_FLOATS) * sizeof(float);   // 79 KB: two workgroups per CU still fit
     const dim3 grid((unsigned)B * S);
     hipStream_t sm = (hipStream_t)stream;
+#ifdef PNGPD_BF_LEGACY_E     // the inherited kernel (fp32 LDS tiles, operands converted at every read): A/B builds only
     if (nterms == 1) return launch_bwd_e<true, 1>(grid, lds, sm, x, N, trans, P, E, T, S, z2t, g2t, pc, pR, pW2, tail);
     if (nterms == 3) return launch_bwd_e<true, 3>(grid, lds, sm, x, N, trans, P, E, T, S, z2t, g2t, pc, pR, pW2, tail);
+#else
+    if (nterms) {
+        const size_t ldsb = nterms == 1 ? EBF_LDS_BYTES(1) : EBF_LDS_BYTES(3);
+        static_assert(EBF_LDS_BYTES(1) >= DW3_LDS_DOUBLES * sizeof(double) && EBF_LDS_BYTES(3) <= 81920, "pass E (bf) LDS");
+        const void *fn = nterms == 1 ? (const void *)trunk_bwd_e_bf_kernel<1> : (const void *)trunk_bwd_e_bf_kernel<3>;
+        int st = pngpd_allow_lds(fn, ldsb);
+        if (st != PNGPD_OK) return st;
+        dim3 g = grid;
+        const int n_main = (int)g.x;
+        if (tail) g.x += 1024 / DW3_CPB;
+        const DW3Args WT = tail ? *tail : DW3Args{};
+        if (nterms == 1)
+            hipLaunchKernelGGL(trunk_bwd_e_bf_kernel<1>, g, dim3(256), ldsb, sm, x, N, trans, P, E, T, S, (const f32x4 *)z2t,
+                               (const f32x4 *)g2t, pc, pR, pW2, WT, n_main);
+        else
+            hipLaunchKernelGGL(trunk_bwd_e_bf_kernel<3>, g, dim3(256), ldsb, sm, x, N, trans, P, E, T, S, (const f32x4 *)z2t,
+                               (const f32x4 *)g2t, pc, pR, pW2, WT, n_main);
+        return pngpd_launch_status();
+    }
+#endif
     return z2t ? launch_bwd_e<true, 0>(grid, lds, sm, x, N, trans, P, E, T, S, z2t, g2t, pc, pR, pW2, tail)
                : launch_bwd_e<false, 0>(grid, lds, sm, x, N, trans, P, E, T, S, nullptr, g2t, pc, pR, pW2, tail);
 }

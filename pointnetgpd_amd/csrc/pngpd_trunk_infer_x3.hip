@@ -143,21 +143,25 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
         {   // layer 1 (fp32 VALU): thread = (point p = tid & 127, 16-channel group g = tid >> 7 = wave >> 1)
             const int p = tid & 127, g = wave >> 1;
             const float x0 = xs[p], x1 = xs[XP + p], x2 = xs[2 * XP + p];
-            u16 hv[16], lv[16];
+            float zv[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int c = g * 16 + e;   // wave-uniform -> scalar loads
-                const float z = fmaxf(fmaf(w1[c * 3 + 2], x2, fmaf(w1[c * 3 + 1], x1, fmaf(w1[c * 3], x0, b1[c]))), 0.f);
-                split2(z, hv[e], lv[e]);
+                zv[e] = fmaxf(fmaf(w1[c * 3 + 2], x2, fmaf(w1[c * 3 + 1], x1, fmaf(w1[c * 3], x0, b1[c]))), 0.f);
             }
             uint4 *dh = (uint4 *)(h1h + p * X1S + g * 16), *dl = (uint4 *)(h1l + p * X1S + g * 16);
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                uint4 vh, vl;
-                vh.x = hv[q * 8 + 0] | ((unsigned)hv[q * 8 + 1] << 16); vh.y = hv[q * 8 + 2] | ((unsigned)hv[q * 8 + 3] << 16);
-                vh.z = hv[q * 8 + 4] | ((unsigned)hv[q * 8 + 5] << 16); vh.w = hv[q * 8 + 6] | ((unsigned)hv[q * 8 + 7] << 16);
-                vl.x = lv[q * 8 + 0] | ((unsigned)lv[q * 8 + 1] << 16); vl.y = lv[q * 8 + 2] | ((unsigned)lv[q * 8 + 3] << 16);
-                vl.z = lv[q * 8 + 4] | ((unsigned)lv[q * 8 + 5] << 16); vl.w = lv[q * 8 + 6] | ((unsigned)lv[q * 8 + 7] << 16);
+                // channel pairs through ONE v_cvt_pk_bf16_f32 each (pngpd_bf.h bf_pk2 / bf_split_pk2): same bits as the
+                // per-value split2 this replaced, a third of its instructions
+                uint4 vh, vl = {0u, 0u, 0u, 0u};
+                if (NT == 3) {
+                    bf_split_pk2(zv[q * 8 + 0], zv[q * 8 + 1], vh.x, vl.x); bf_split_pk2(zv[q * 8 + 2], zv[q * 8 + 3], vh.y, vl.y);
+                    bf_split_pk2(zv[q * 8 + 4], zv[q * 8 + 5], vh.z, vl.z); bf_split_pk2(zv[q * 8 + 6], zv[q * 8 + 7], vh.w, vl.w);
+                } else {
+                    vh.x = bf_pk2(zv[q * 8 + 0], zv[q * 8 + 1]); vh.y = bf_pk2(zv[q * 8 + 2], zv[q * 8 + 3]);
+                    vh.z = bf_pk2(zv[q * 8 + 4], zv[q * 8 + 5]); vh.w = bf_pk2(zv[q * 8 + 6], zv[q * 8 + 7]);
+                }
                 dh[q] = vh;
                 if (NT == 3) dl[q] = vl;
             }
@@ -185,13 +189,15 @@ __global__ __launch_bounds__(512, 2) void trunk_infer_x3_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mfma_row(r, lane);
-                u16 hi, lo;
-                split2(fmaxf(a0[r] + bias, 0.f), hi, lo);
-                h2h[(pb0 * 32 + row) * X2S + cb * 32 + j] = hi;
-                if (NT == 3) h2l[(pb0 * 32 + row) * X2S + cb * 32 + j] = lo;
-                split2(fmaxf(a1[r] + bias, 0.f), hi, lo);
-                h2h[((pb0 + 1) * 32 + row) * X2S + cb * 32 + j] = hi;
-                if (NT == 3) h2l[((pb0 + 1) * 32 + row) * X2S + cb * 32 + j] = lo;
+                unsigned hi, lo = 0u;   // the register's two values (point blocks pb0, pb0 + 1) converted as a pair
+                const float v0 = fmaxf(a0[r] + bias, 0.f), v1 = fmaxf(a1[r] + bias, 0.f);
+                if (NT == 3) bf_split_pk2(v0, v1, hi, lo); else hi = bf_pk2(v0, v1);
+                h2h[(pb0 * 32 + row) * X2S + cb * 32 + j] = (u16)hi;
+                h2h[((pb0 + 1) * 32 + row) * X2S + cb * 32 + j] = (u16)(hi >> 16);
+                if (NT == 3) {
+                    h2l[(pb0 * 32 + row) * X2S + cb * 32 + j] = (u16)lo;
+                    h2l[((pb0 + 1) * 32 + row) * X2S + cb * 32 + j] = (u16)(lo >> 16);
+                }
             }
         }
         TM(5)
@@ -378,22 +384,26 @@ __global__ __launch_bounds__(512, 2) void trunk_fwd_train_x3_kernel(
         {
             const int p = tid & 127, g = wave >> 1;
             const float x0 = xs[p], x1 = xs[XP + p], x2 = xs[2 * XP + p];
-            u16 hv[16], lv[16];
+            float zv[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int c = g * 16 + e;
-                float z = fmaf(w1[c * 3 + 2], x2, fmaf(w1[c * 3 + 1], x1, fmaf(w1[c * 3], x0, b1[c])));
-                z = fmaxf(fmaf(z, s1c[c], t1c[c]), 0.f);
-                split2(z, hv[e], lv[e]);
+                const float z = fmaf(w1[c * 3 + 2], x2, fmaf(w1[c * 3 + 1], x1, fmaf(w1[c * 3], x0, b1[c])));
+                zv[e] = fmaxf(fmaf(z, s1c[c], t1c[c]), 0.f);
             }
             uint4 *dh = (uint4 *)(h1h + p * X1S + g * 16), *dl = (uint4 *)(h1l + p * X1S + g * 16);
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                uint4 vh, vl;
-                vh.x = hv[q * 8 + 0] | ((unsigned)hv[q * 8 + 1] << 16); vh.y = hv[q * 8 + 2] | ((unsigned)hv[q * 8 + 3] << 16);
-                vh.z = hv[q * 8 + 4] | ((unsigned)hv[q * 8 + 5] << 16); vh.w = hv[q * 8 + 6] | ((unsigned)hv[q * 8 + 7] << 16);
-                vl.x = lv[q * 8 + 0] | ((unsigned)lv[q * 8 + 1] << 16); vl.y = lv[q * 8 + 2] | ((unsigned)lv[q * 8 + 3] << 16);
-                vl.z = lv[q * 8 + 4] | ((unsigned)lv[q * 8 + 5] << 16); vl.w = lv[q * 8 + 6] | ((unsigned)lv[q * 8 + 7] << 16);
+                // channel pairs through ONE v_cvt_pk_bf16_f32 each (pngpd_bf.h bf_pk2 / bf_split_pk2): same bits as the
+                // per-value split2 this replaced, a third of its instructions
+                uint4 vh, vl = {0u, 0u, 0u, 0u};
+                if (NT == 3) {
+                    bf_split_pk2(zv[q * 8 + 0], zv[q * 8 + 1], vh.x, vl.x); bf_split_pk2(zv[q * 8 + 2], zv[q * 8 + 3], vh.y, vl.y);
+                    bf_split_pk2(zv[q * 8 + 4], zv[q * 8 + 5], vh.z, vl.z); bf_split_pk2(zv[q * 8 + 6], zv[q * 8 + 7], vh.w, vl.w);
+                } else {
+                    vh.x = bf_pk2(zv[q * 8 + 0], zv[q * 8 + 1]); vh.y = bf_pk2(zv[q * 8 + 2], zv[q * 8 + 3]);
+                    vh.z = bf_pk2(zv[q * 8 + 4], zv[q * 8 + 5]); vh.w = bf_pk2(zv[q * 8 + 6], zv[q * 8 + 7]);
+                }
                 dh[q] = vh;
                 if (NT == 3) dl[q] = vl;
             }
@@ -437,14 +447,15 @@ __global__ __launch_bounds__(512, 2) void trunk_fwd_train_x3_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mfma_row(r, lane);
-                u16 hi, lo;
+                unsigned hi, lo = 0u;
                 const float v0 = fmaxf(fmaf(a0[r], sc, sh), 0.f), v1 = fmaxf(fmaf(a1[r], sc, sh), 0.f);
-                split2(v0, hi, lo);
-                h2h[(pb0 * 32 + row) * X2S + cb * 32 + j] = hi;
-                if (NT == 3) h2l[(pb0 * 32 + row) * X2S + cb * 32 + j] = lo;
-                split2(v1, hi, lo);
-                h2h[((pb0 + 1) * 32 + row) * X2S + cb * 32 + j] = hi;
-                if (NT == 3) h2l[((pb0 + 1) * 32 + row) * X2S + cb * 32 + j] = lo;
+                if (NT == 3) bf_split_pk2(v0, v1, hi, lo); else hi = bf_pk2(v0, v1);
+                h2h[(pb0 * 32 + row) * X2S + cb * 32 + j] = (u16)hi;
+                h2h[((pb0 + 1) * 32 + row) * X2S + cb * 32 + j] = (u16)(hi >> 16);
+                if (NT == 3) {
+                    h2l[(pb0 * 32 + row) * X2S + cb * 32 + j] = (u16)lo;
+                    h2l[((pb0 + 1) * 32 + row) * X2S + cb * 32 + j] = (u16)(lo >> 16);
+                }
                 if (nbase + XP <= N) {
                     hs2 += f32x2{v0, v1};
                 } else {
