@@ -223,14 +223,34 @@ def config5_gpg_leg(dev, dist, world, rank, samples=172000, P=50000, N=1024, k=3
         if dist is not None:
             out = [torch.empty_like(packed) for _ in range(world)]
             dist.all_gather(out, packed)
-        return sum(counts), t_s, float(res["valid"].float().mean().item()) if len(grasps) else 0.0
+        return sum(counts), t_s, float(res["valid"].float().mean().item()) if len(grasps) else 0.0, res
 
-    once()                                                            # warm-up at full size: allocator + pinned pools
-    times, ts = [], []
+    def once_pipelined():
+        """One process, one GPU: the sampler's rounds feed the scorer as they complete (scoring.GraspScorer.score_chunks
+        over gpg.GpgGraspSamplerPcl.iter_rounds) — scoring on a side stream under the next round's sampler kernels and
+        its host eig.  (More than one rank: a rank's global candidate offset, which keys its resampling draws, is known
+        only when the ranks below it have finished sampling — that leg stays serial.)"""
+        rounds = sampler.iter_rounds(cloud, pfs, nrm, 10 ** 9, len(mine), sample_indices=mine)
+        res = scorer.score_chunks(cloud, scoring.on_priority_stream(rounds, dev))
+        n = int(res["score"].shape[0])
+        return n, 0.0, float(res["valid"].float().mean().item()) if n else 0.0, res
+
+    pipelined = dist is None
+    run = once_pipelined if pipelined else once
+    identical = None
+    ref = once()                                                      # warm-up at full size: allocator + pinned pools
+    if pipelined:
+        got = once_pipelined()                                        # warm-up of the side stream's pools, and the check:
+        identical = bool(np.array_equal(ref[3]["grasps"] if "grasps" in ref[3] else None, got[3]["grasps"]) and
+                         torch.equal(ref[3]["score"], got[3]["score"]) and torch.equal(ref[3]["pred"], got[3]["pred"]) and
+                         torch.equal(ref[3]["valid"], got[3]["valid"]))
+        del got
+    del ref
+    times, ts, serial_times = [], [], []
     for _ in range(reps):
         sync()
         t0 = time.perf_counter()
-        total, t_s, vf = once()
+        total, t_s, vf, _ = run()
         sync()
         t = time.perf_counter() - t0
         if dist is not None:
@@ -238,12 +258,25 @@ def config5_gpg_leg(dev, dist, world, rank, samples=172000, P=50000, N=1024, k=3
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             t, t_s = tt[0].item(), tt[1].item()
         times.append(t); ts.append(t_s)
+    if pipelined:                                                     # the serial schedule next to it, same run
+        for _ in range(reps):
+            sync()
+            t0 = time.perf_counter()
+            _, t_s, _, _ = once()
+            sync()
+            serial_times.append(time.perf_counter() - t0); ts.append(t_s)
+        ts = ts[reps:]
     t, t_s = statistics.median(times), statistics.median(ts)
     return {"workload": f"BASELINE configs[4] with sampled candidates: GPG sampler on {samples} sample points of a "
                         f"{P}-point scene -> {total} candidates -> crop + resample to N={N} + {k}-class PointNet scoring",
             "value": round(total / t, 1), "unit": "grasps/s", "seconds": round(t, 4), "candidates": total,
             "sample_points": samples, "sample_points_per_gpu": per, "scaling": "strong", "dtype": "f32",
-            "sampler_seconds": round(t_s, 4), "sampler_candidates_per_s": round(total / t_s, 1),
+            "schedule": ("pipelined: sampler rounds -> crop + scoring on a side stream (one process)" if pipelined else
+                         "serial per rank: sample, all_gather of the counts, score"),
+            **({"serial_schedule": {"seconds": round(statistics.median(serial_times), 4),
+                                    "value": round(total / statistics.median(serial_times), 1)},
+                "pipelined_identical_to_serial": identical} if pipelined else {}),
+            "sampler_seconds": round(t_s, 4), "sampler_candidates_per_s": round(total / t_s, 1) if t_s else None,
             "sampler_note": "host part of the sampler (np.linalg.eig per sample point, LAPACK as in the reference) runs "
                             "under the device chain of the previous round; sampler_seconds = max over ranks",
             "valid_frac": round(vf, 4), "reps": reps}

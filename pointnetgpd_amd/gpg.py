@@ -560,6 +560,20 @@ class GpgGraspSamplerPcl:
     def sample_grasps(self, point_cloud, points_for_sample, all_normal, num_grasps=20, max_num_samples=200,
                       show_final_grasp=False, sample_indices=None, seed=None, as_array=False, scene_index=None,
                       **kwargs):
+        chunks = list(self.iter_rounds(point_cloud, points_for_sample, all_normal, num_grasps, max_num_samples,
+                                       sample_indices=sample_indices, seed=seed, scene_index=scene_index))
+        out = np.concatenate(chunks, 0) if chunks else np.zeros((0, 5, 3))
+        if as_array:
+            return out
+        return [[v.copy() for v in gr] for gr in out]
+
+    def iter_rounds(self, point_cloud, points_for_sample, all_normal, num_grasps=20, max_num_samples=200,
+                    sample_indices=None, seed=None, scene_index=None):
+        """``sample_grasps`` as a generator: yields the kept grasps of every round, (n,5,3) float64 in draw order, as
+        soon as the round's packed result has been downloaded — while the device already works on the next round's
+        chain (the rounds' own pipeline below).  A consumer that enqueues each chunk's crop + scoring on ANOTHER
+        stream (``scoring.GraspScorer.score_chunks``) overlaps scoring with sampling (kinect2grasp.py:141-150 feeding
+        :443-514); concatenating the chunks is exactly ``sample_grasps(..., as_array=True)``."""
         g = _gripper_dict(self.gripper)
         self.last_stats = {"draws": 0, "sampled": 0, "potential": 0}
         if isinstance(point_cloud, torch.Tensor):
@@ -578,9 +592,8 @@ class GpgGraspSamplerPcl:
                          dtype=np.float64).reshape(-1, 3)
         normals_d = torch.from_numpy(np.ascontiguousarray(all_normal)).to(dev)
         scene = {"index": scene_index if self.use_index else None}       # CloudIndex: built once per scene, lazily
-        chunks = []
         if num_grasps <= 0 or max_num_samples <= 0 or pfs.shape[0] == 0:                       # :1432 loop never entered
-            return np.zeros((0, 5, 3)) if as_array else []
+            return
         rng = np.random.default_rng(seed)
         explicit = None if sample_indices is None else np.asarray(sample_indices, dtype=np.int64).reshape(-1)
         # Rounds of up to ``batch_samples`` draws run as a three-stage pipeline on ONE stream, two rounds ahead:
@@ -618,39 +631,50 @@ class GpgGraspSamplerPcl:
             rd = issue()
             if rd is not None:
                 pending.append(rd)
-        while (pending or chained) and not done:
-            if pending:
-                rd = pending.popleft()
-                self._stage_chain(rd, g, cloud_d, scene)
-                chained.append(rd)
-            if len(chained) > (1 if pending and lookahead else 0):
-                rd = chained.popleft()
-                m_zero, counts, grasps = self._stage_collect(rd, dev)
-                # the reference's loop over the draws (:1486-1489, :1639), without a Python iteration per draw: a draw
-                # whose M is zero consumes a draw but is not counted; stop behind the first counted draw at which
-                # num_grasps grasps have been found or max_num_samples sample points have been processed
-                st["credit"] -= rd["K"]
-                live_cum = sampled + np.cumsum(~m_zero)
-                found_cum = found + np.cumsum(counts)
-                stop = np.nonzero(~m_zero & ((found_cum >= num_grasps) | (live_cum >= max_num_samples)))[0]
-                last = int(stop[0]) if stop.size else rd["K"] - 1
-                keep = int(found_cum[last] - found)
-                chunks.append(grasps[:keep])
-                self.last_stats["draws"] += last + 1
-                sampled, found = int(live_cum[last]), int(found_cum[last])
-                done = bool(stop.size)
-            if not done:
-                rd = issue()
-                if rd is not None:
-                    pending.append(rd)
-        if pending or chained:
-            # rounds in flight were abandoned by the stop rule: their copies must land before the buffers are reused
-            torch.cuda.current_stream(dev).synchronize()
-            for rd in list(pending) + list(chained):
-                for key in ("M_h", "host_t", "q_h", "up_h"):
-                    self._unpin(rd.get(key))
-        out = np.concatenate(chunks, 0) if chunks else np.zeros((0, 5, 3))
-        self.last_stats["sampled"] = sampled
-        if as_array:
-            return out
-        return [[v.copy() for v in gr] for gr in out]
+        try:
+            while (pending or chained) and not done:
+                issued_here = False
+                if pending:
+                    rd = pending.popleft()
+                    self._stage_chain(rd, g, cloud_d, scene)
+                    chained.append(rd)
+                if len(chained) > (1 if pending and lookahead else 0):
+                    rd = chained.popleft()
+                    m_zero, counts, grasps = self._stage_collect(rd, dev)
+                    # the reference's loop over the draws (:1486-1489, :1639), without a Python iteration per draw: a draw
+                    # whose M is zero consumes a draw but is not counted; stop behind the first counted draw at which
+                    # num_grasps grasps have been found or max_num_samples sample points have been processed
+                    st["credit"] -= rd["K"]
+                    live_cum = sampled + np.cumsum(~m_zero)
+                    found_cum = found + np.cumsum(counts)
+                    stop = np.nonzero(~m_zero & ((found_cum >= num_grasps) | (live_cum >= max_num_samples)))[0]
+                    last = int(stop[0]) if stop.size else rd["K"] - 1
+                    keep = int(found_cum[last] - found)
+                    self.last_stats["draws"] += last + 1
+                    sampled, found = int(live_cum[last]), int(found_cum[last])
+                    done = bool(stop.size)
+                    self.last_stats["sampled"] = sampled
+                    if not done:
+                        # the next round is issued BEFORE the consumer sees this one: its moments kernel is queued while
+                        # the consumer enqueues the chunk's scoring
+                        rd2 = issue()
+                        if rd2 is not None:
+                            pending.append(rd2)
+                        issued_here = True
+                    if keep:
+                        yield grasps[:keep]
+                    if not done and issued_here:
+                        continue
+                if not done:
+                    rd = issue()
+                    if rd is not None:
+                        pending.append(rd)
+        finally:
+            # (also when the consumer closes the generator early)
+            if pending or chained:
+                # rounds in flight were abandoned by the stop rule: their copies must land before the buffers are reused
+                torch.cuda.current_stream(dev).synchronize()
+                for rd in list(pending) + list(chained):
+                    for key in ("M_h", "host_t", "q_h", "up_h"):
+                        self._unpin(rd.get(key))
+            self.last_stats["sampled"] = sampled

@@ -198,6 +198,40 @@ def test_detect_grasps_chain(cuda_device):
     assert res0["grasps"].shape == (0, 5, 3) and res0["order"].numel() == 0
 
 
+def test_pipelined_sampler_to_scorer_equals_the_serial_schedule(cuda_device):
+    """Sampler rounds feeding the scorer as they complete (scoring on a side stream under the next round's sampler
+    kernels and host eig: ``GraspScorer.score_chunks`` over ``GpgGraspSamplerPcl.iter_rounds``) against the serial
+    schedule (sample everything, then score): identical candidates, identical scores — bit for bit — with rounds and
+    scoring batches deliberately misaligned (small sampler rounds, a batch that divides neither a round nor the total)
+    and with vote repeats.  Reference: kinect2grasp.py:141-150 feeding :443-514, strictly serial there."""
+    from pointnetgpd_amd import gpg
+    from pointnetgpd_amd.scoring import GraspScorer, detect_grasps
+    from tests.helpers import build_model
+    pts, nrm = go.synth_scene("ellipsoid", 6000, 45)
+    pts32 = pts.astype(np.float32)
+    m = build_model(64, 3, 38, 4705).eval().to(cuda_device)
+    sampler = gpg.GpgGraspSamplerPcl(device=cuda_device, batch_samples=96)       # many small rounds
+    for repeat, batch in ((1, 37), (3, 64)):
+        scorer = GraspScorer(m, num_points=64, repeat=repeat, batch=batch, seed=11)
+        a = detect_grasps(pts32, nrm, scorer, sampler=sampler, num_grasps=10 ** 6, max_num_samples=700, seed=3,
+                          pipelined=True)
+        b = detect_grasps(pts32, nrm, scorer, sampler=sampler, num_grasps=10 ** 6, max_num_samples=700, seed=3,
+                          pipelined=False)
+        assert a["grasps"].shape[0] > 3 * batch and np.array_equal(a["grasps"], b["grasps"])
+        for k_ in ("pred", "score", "counts", "valid", "good", "order", "probs"):
+            assert torch.equal(a[k_], b[k_]), (k_, repeat, batch)
+    # the generator is the list: chunks concatenate to sample_grasps' array, and closing it early leaves nothing behind
+    pfs = pts32[pts32[:, 2] > 0.010]
+    whole = sampler.sample_grasps(pts32, pfs, nrm, 10 ** 6, 700, seed=3, as_array=True)
+    chunks = list(sampler.iter_rounds(pts32, pfs, nrm, 10 ** 6, 700, seed=3))
+    assert len(chunks) > 3 and np.array_equal(np.concatenate(chunks, 0), whole)
+    it = sampler.iter_rounds(pts32, pfs, nrm, 10 ** 6, 700, seed=3)
+    first = next(it)
+    it.close()
+    assert np.array_equal(first, chunks[0])
+    assert np.array_equal(sampler.sample_grasps(pts32, pfs, nrm, 10 ** 6, 700, seed=3, as_array=True), whole)
+
+
 @pytest.mark.parametrize("dtype,P,Q,kind", [(np.float32, 5000, 900, "box"), (np.float64, 1025, 37, "cylinder"),
                                             (np.float32, 64, 5, "box"), (np.float64, 20000, 2000, "ellipsoid")])
 def test_indexed_counts_identical_to_brute_force(dtype, P, Q, kind, cuda_device):
