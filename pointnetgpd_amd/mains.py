@@ -182,7 +182,11 @@ def _make_loaders(cfg, args, world=1, rank=0, local_rank=0):
         common_tr = dict(common, shuffle=False, sampler=sampler)
     else:
         common_tr = common
-    if getattr(args, "device_data", False) and args.cuda and not args.synthetic:
+    if getattr(args, "device_data", False) and args.synthetic:
+        raise SystemExit("--device-data keeps the YCB files' clouds resident in HBM and crops on the GPU; --synthetic "
+                         "clouds are generated already cropped, per item, on the host: there is nothing to keep resident "
+                         "(use one or the other)")
+    if getattr(args, "device_data", False) and args.cuda:
         # HBM-resident data layer: under torchrun every rank walks its strided share of the epoch's permutation
         from .device_loader import DeviceGraspLoader
         dev = torch.device("cuda", local_rank if world > 1 else (args.gpu if args.gpu != -1 else 0))
@@ -224,7 +228,10 @@ def save_model(model, path, world=1):
     exception here would strand the other ranks in their next collective, so the failure is reported and returned
     (False) — ``run()`` broadcasts the flag and every rank aborts together."""
     try:
-        torch.save(model, path, pickle_module=_RefPathPickleModule)   # _HipModule.__getstate__ drops the fold cache
+        torch.save(model, path, pickle_module=_RefPathPickleModule)   # _HipModule.__getstate__ drops the fold plans
+        # sidecar: the plain state_dict (tensors only, loads with weights_only=True on any torch and into the reference's
+        # own PointNetCls) next to the whole-module pickle the reference's scripts expect (main_1v.py:177-178)
+        torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, path + ".state_dict")
         return True
     except Exception as e:      # noqa: BLE001
         if world <= 1:
@@ -336,6 +343,7 @@ def run(variant, argv=None):
         # per-batch ``.cpu()`` (main_1v.py:78), which serialises host and device every step
         correct, dataset_size = torch.zeros((), dtype=torch.long, device=device), 0
         loss = None
+        t_epoch = time.perf_counter()
         for batch_idx, batch in enumerate(train_loader):
             if args.max_batches and batch_idx >= args.max_batches:
                 break
@@ -383,7 +391,11 @@ def run(variant, argv=None):
                 print(f"Train Epoch: {epoch} [{batch_idx * args.batch_size}/{len(train_loader.dataset)} "
                       f"({percentage}%)]\tLoss: {loss.item()}\t{args.tag}")
                 logger.add_scalar("train_loss", loss.cpu().item(), batch_idx + epoch * len(train_loader))
-        return float(correct.item()) / float(max(dataset_size, 1))
+        acc = float(correct.item()) / float(max(dataset_size, 1))      # (the .item() also drains the device queue)
+        if rank == 0 and logger is not None and dataset_size:
+            # training throughput of the epoch, loader included: this rank's samples x ranks / wall time
+            logger.add_scalar("train_grasps_per_s", dataset_size * world / max(time.perf_counter() - t_epoch, 1e-9), epoch)
+        return acc
 
     def test():
         if averager is not None:

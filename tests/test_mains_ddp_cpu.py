@@ -29,6 +29,17 @@ def test_cli_train_then_test_cpu(tmp_path):
     assert type(m).__module__ == "pointnetgpd_amd.model.pointnet"
     assert len(list(m.named_parameters())) == 44
     assert len([k for k in m.state_dict() if "running_" in k or "num_batches" in k]) == 30
+    # the state_dict sidecar: tensors only (weights_only=True), the keys / values of the pickled module
+    sd = torch.load(str(ckpt) + ".state_dict", weights_only=True)
+    assert list(sd) == list(m.state_dict()) and all(torch.equal(sd[k], v) for k, v in m.state_dict().items())
+    # the grasps/s scalar of the epoch next to the reference's four scalars (JSONL sink when tensorboard is absent)
+    import glob, json
+    files = glob.glob(str(tmp_path / "log" / "t" / "scalars.jsonl"))
+    if files:
+        tags = {json.loads(l)["tag"] for l in open(files[0])}
+        assert {"train_loss", "train_acc", "test_acc", "test_loss", "train_grasps_per_s"} <= tags
+    with pytest.raises(SystemExit, match="--device-data"):
+        mains.run("1v", ["--mode", "train", "--epoch", "1", "--device-data", "--cuda"] + common)
 
 
 @pytest.mark.parametrize("variant,k,n", [("1v_mc", 3, 750), ("fullv", 2, 1000), ("fullv_mc", 3, 1000)])
