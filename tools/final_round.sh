@@ -44,6 +44,17 @@ for f in trace_small_train trace_small_eval; do rm -rf /tmp/pst; ( cd /tmp && ti
 ( for v in 0 1 4 8 9; do [ -x build_probe/mvo$v ] && timeout 60 ./build_probe/mvo$v; done ) > gpurun_out/${TAG}_probe_mfma_valu.txt 2>&1
 # per-phase wave-cycle accounting of passes C / D / E (a -DPNGPD_TIMING build of the library in build_probe/)
 [ -f build_probe/lib_tm.so ] && PNGPD_LIB=$GRAFT_REPO_ROOT/build_probe/lib_tm.so timeout 200 python tools/phase_times.py 2>/dev/null | grep -v "^B " > gpurun_out/${TAG}_phase_times.txt
+# round 6: the bf16-mode passes — per-pass times + rooflines, A/B against the round-5 library when one was shipped
+# (build_probe/lib_base.so: the library at the commit before pngpd_bwd_bf.h / pair conversion), phase stamps, tr probe
+timeout 200 python tools/bench_pass_bf.py 2>/dev/null > gpurun_out/${TAG}_bench_pass_bf.jsonl
+if [ -f build_probe/lib_base.so ]; then
+  ( for i in 1 2; do
+      echo "== round-5 kernels (build_probe/lib_base.so), run $i"; PNGPD_LIB=$GRAFT_REPO_ROOT/build_probe/lib_base.so timeout 200 python tools/bench_pass_bf.py 2>/dev/null | python -c "import sys,json; [print(d['nterms'], d['ms']) for d in map(json.loads, sys.stdin)]"
+      echo "== this tree, run $i"; timeout 200 python tools/bench_pass_bf.py 2>/dev/null | python -c "import sys,json; [print(d['nterms'], d['ms']) for d in map(json.loads, sys.stdin)]"
+    done ) > gpurun_out/${TAG}_ab_passes.txt 2>&1
+fi
+[ -f build_probe/lib_tm.so ] && PNGPD_LIB=$GRAFT_REPO_ROOT/build_probe/lib_tm.so timeout 200 python tools/phase_times_bf.py 2>/dev/null > gpurun_out/${TAG}_phase_times_bf.txt
+[ -x build_probe/ds_tr_probe ] && ./build_probe/ds_tr_probe 16 0 > gpurun_out/${TAG}_ds_tr_probe.txt 2>&1
 ls gpurun_out | grep ${TAG}
 # every evidence file must be non-trivial: an empty / banner-only file is reported, never silently committed
 for f in gpurun_out/${TAG}_*; do [ $(wc -c < $f) -lt 64 ] && { echo "SUSPICIOUS (under 64 bytes): $f"; FAILED="$FAILED $f"; }; done
