@@ -13,6 +13,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <vector>
 
@@ -102,6 +103,34 @@ static int run(int argc, char **argv) {
         HIP_OK(hipMalloc((void **)&dbf[l], C[l + 1] * sizeof(float)));
         PN_OK(pngpd_fold_conv_bn(dW[l], db[l], dg[l], dbe[l], dmu[l], dva[l], 1e-5f, C[l + 1], C[l],
                                  l == 0 ? PNGPD_LAYOUT_ROWMAJOR : PNGPD_LAYOUT_MFMA_B, dWf[l], dbf[l], st));
+    }
+    {   // ABI v6: the same three layers folded by ONE launch (pngpd_fold_model) must equal the per-layer entry bit for bit
+        pngpd_fold_model_t fm = {};
+        float *cW[3], *cb[3];
+        fm.n = 3;
+        for (int l = 0; l < 3; ++l) {
+            HIP_OK(hipMalloc((void **)&cW[l], W[l].size() * sizeof(float)));
+            HIP_OK(hipMalloc((void **)&cb[l], C[l + 1] * sizeof(float)));
+            pngpd_fold_layer_t &L = fm.layer[l];
+            L.W = dW[l]; L.b = db[l]; L.gamma = dg[l]; L.beta = dbe[l]; L.mean = dmu[l]; L.var = dva[l];
+            L.eps = 1e-5f; L.C = C[l + 1]; L.K = C[l];
+            (l == 0 ? L.row : L.mfma) = cW[l];
+            L.bf = cb[l];
+        }
+        if (pngpd_struct_bytes(2) != sizeof(fm)) { std::fprintf(stderr, "pngpd_fold_model_t size mismatch\n"); return 6; }
+        PN_OK(pngpd_fold_model(&fm, st));
+        HIP_OK(hipStreamSynchronize(st));
+        for (int l = 0; l < 3; ++l) {
+            std::vector<float> a(W[l].size()), b2(W[l].size()), c(C[l + 1]), d(C[l + 1]);
+            HIP_OK(hipMemcpy(a.data(), dWf[l], a.size() * sizeof(float), hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(b2.data(), cW[l], b2.size() * sizeof(float), hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(c.data(), dbf[l], c.size() * sizeof(float), hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(d.data(), cb[l], d.size() * sizeof(float), hipMemcpyDeviceToHost));
+            if (std::memcmp(a.data(), b2.data(), a.size() * sizeof(float)) || std::memcmp(c.data(), d.data(), c.size() * sizeof(float))) {
+                std::fprintf(stderr, "pngpd_fold_model != pngpd_fold_conv_bn (layer %d)\n", l); return 6;
+            }
+            HIP_OK(hipFree(cW[l])); HIP_OK(hipFree(cb[l]));
+        }
     }
     HIP_OK(hipMalloc((void **)&dpool, (size_t)B * 1024 * sizeof(float)));
     HIP_OK(hipMalloc((void **)&dout, (size_t)B * 9 * sizeof(float)));
