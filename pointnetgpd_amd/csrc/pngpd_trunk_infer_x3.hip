@@ -363,11 +363,13 @@ __global__ __launch_bounds__(512, 2) void trunk_fwd_train_x3_kernel(
         }
     };
     if (LOADZ) fetch_z(t0);
-
+    TM_DECL
     for (int tile = t0; tile < t1; ++tile) {
         const int nbase = tile * XP;
+        TM(0)
         if (LOADZ) {
             if (tile > t0) __syncthreads();   // every wave is done reading the previous tile's h2
+            TM(1)
         } else {
         if (tid < XP) {
             int n = nbase + tid; n = n < N ? n : N - 1;
@@ -468,12 +470,18 @@ __global__ __launch_bounds__(512, 2) void trunk_fwd_train_x3_kernel(
             hsum += (double)(hs2[0] + hs2[1]);
             asm volatile("" : "+v"(hsum));
         }
+        TM(2)
         __syncthreads();
+        TM(3)
         const bool full = nbase + XP <= N;
 #pragma unroll 1
         for (int ci = 0; ci < 4; ++ci) {
             const int cb = wave + 8 * ci;
             load_wx<8, NT>(wah, wal, w3x, cb, lane);
+#ifdef PNGPD_TIMING
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            TM(4)
+#endif
             float m = -INFINITY, su = 0.f, qu = 0.f;
             int am = 0;
             // all four point blocks at once: 4 independent accumulator chains, A fragments of k-step ks+1 in flight
@@ -510,6 +518,7 @@ __global__ __launch_bounds__(512, 2) void trunk_fwd_train_x3_kernel(
                     for (int q = 0; q < 4; ++q) { ah[q] = nh[q]; al[q] = nl[q]; }
                 }
             }
+            TM(5)
             if (full) {
                 // lane_max_moments (pngpd_tile.h): exact first maximum + both moments of 32 values without compares;
                 // the two halves of the 128-point tile are merged with "earlier rows win ties"
@@ -549,8 +558,10 @@ __global__ __launch_bounds__(512, 2) void trunk_fwd_train_x3_kernel(
                 if (m > rm[c]) { rm[c] = m; const int n = nbase + am; ri[c] = n < N ? n : N - 1; }
                 ss[c] += su; sq[c] += qu;
             }
+            TM(6)
         }
     }
+    TM_END_TO(pngpd_tm_x3)
     hsum += __shfl_xor(hsum, 32);
     if (h == 0) {
         psh[((size_t)blockIdx.x * 2 + (wave >> 2)) * 128 + (wave & 3) * 32 + j] = (float)hsum;
