@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PNGPD_ABI_VERSION 6
+#define PNGPD_ABI_VERSION 7
 
 enum {
     PNGPD_OK = 0,
@@ -577,8 +577,22 @@ int pngpd_hand_box_counts_indexed_n(const void *cloud_sorted, int cloud_is_f64, 
                                     const double *poses, int Q, const double *boxes, int num_boxes,
                                     const int *valid_units, int per_unit, int *counts, void *stream);
 
-/* ---- selection logic of the sampler on the device (grasp_sampler.py:1524-1650); only the 3x3 eigen-decomposition of
- * :1493 stays on the host (LAPACK's eigenvector signs decide the enumeration order).  prm: gripper / sweep constants
+/* grasp_sampler.py:1486-1506  local frames of K sample points on the device: M (K,3,3) f64 from
+ * pngpd_gpg_normal_moments, normals_at (K,3) f64 = all_normal[ind], points (K,3) f64 = the sample points ->
+ * frames (K,12) f64 = minor_pc, new_normal (flipped against normals_at, the minor axis with it), major_pc, sample
+ * point — the input of pngpd_gpg_enumerate.  `np.linalg.eig(M)` (:1493) is evaluated as numpy evaluates it: LAPACK's
+ * DGEEV('N','V') restated for a symmetric 3x3 matrix (csrc/pngpd_gpg_eig3.h: DGEBAL, DGEHD2, DORGHR, DLAHQR + DLANV2,
+ * DTREVC3, DGEBAK, 1/DNRM2 — same eigenvalue order, same eigenvector signs; bit-identical to OpenBLAS 0.3.29 on
+ * 99.9 % of moment matrices, a few ulp on the rest), because the signs LAPACK returns decide the sweep's enumeration
+ * order.  flags (K) int32: 1 = sum(sum(M)) == 0 (:1486 `continue`; the point gets the frame of a hand 1e6 m away, which
+ * yields no grasp), 2 = LAPACK would report a complex pair (a double eigenvalue split by rounding; the pair is taken
+ * as the double real eigenvalue it is), 4 = no convergence in 30 * 10 QR sweeps, 8 = max|M| outside DGEEV's unscaled
+ * range.                                                                                                            */
+int pngpd_gpg_frames(const double *M, const double *normals_at, const double *points, int K, double *frames,
+                     int *flags, void *stream);
+
+/* ---- selection logic of the sampler on the device (grasp_sampler.py:1524-1650); the 3x3 eigen-decomposition of
+ * :1493 runs in pngpd_gpg_frames (or on the host through LAPACK itself: gpg.py eig="lapack").  prm: gripper / sweep constants
  * (layout in pngpd_gpg.hip, built by pointnetgpd_amd/gpg.py).  L live sample points, R rotations, D lateral offsets,
  * S push-in steps; capacity of the per-pose buffers = L*R potential grasps. ---- */
 /* :1524-1541  frames (L,12) = minor, normal, major, sample point -> poses (L,R,D,12), ab (L,R,6) = approach, binormal */

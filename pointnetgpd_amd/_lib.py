@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PNGPD_LIB") or os.path.join(_HERE, "libpngpd.so")   # PNGPD_LIB: A/B builds only
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _lib = None
 _load_error = None
@@ -184,6 +184,7 @@ SIGNATURES = {
     "pngpd_hand_box_counts_indexed_n": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, c_void, ctypes.c_int, c_void,
                                                        ctypes.c_int, c_void, ctypes.c_int, c_void, ctypes.c_int, c_void,
                                                        c_void]),
+    "pngpd_gpg_frames": (ctypes.c_int, [c_void, c_void, c_void, ctypes.c_int, c_void, c_void, c_void]),
     "pngpd_gpg_enumerate": (ctypes.c_int, [c_void, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void, c_void, c_void, c_void]),
     "pngpd_gpg_select": (ctypes.c_int, [c_void, c_void, c_void, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void, c_void,
                                         c_void, c_void, c_void, c_void]),

@@ -547,7 +547,37 @@ __global__ __launch_bounds__(256) void gpg_pack_kernel(const int *__restrict__ o
 #include "pngpd_gpg_moments.h"
 #include "pngpd_gpg_pushin.h"
 
+// ---- local frames of the sample points (:1486-1506) ---------------------------------------------------------------------
+// One thread per sample point: np.linalg.eig(M) as LAPACK evaluates it, then the reference's frame construction with
+// numpy's roundings — all of it in pngpd_gpg_eig3.h, which the CPU tests compile for the host (same source, contraction
+// off in both builds: the kernel's output equals the host build's bit for bit).  frames (K,12) = minor, normal, major,
+// sample point — the input of gpg_enumerate_kernel.
+#include "pngpd_gpg_eig3.h"
+
+__global__ __launch_bounds__(64) void gpg_frames_kernel(const double *__restrict__ M, const double *__restrict__ nat,
+                                                         const double *__restrict__ pts, int K,
+                                                         double *__restrict__ frames, int *__restrict__ flags) {
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= K) return;
+    double m[9], na[3], pt[3], f[12];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) m[i] = M[(size_t)s * 9 + i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { na[i] = nat[(size_t)s * 3 + i]; pt[i] = pts[(size_t)s * 3 + i]; }
+    flags[s] = pn_gpg_local_frame(m, na, pt, f);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) frames[(size_t)s * 12 + i] = f[i];
+}
+
 extern "C" {
+
+int pngpd_gpg_frames(const double *M, const double *normals_at, const double *points, int K, double *frames,
+                     int *flags, void *stream) {
+    if (!M || !normals_at || !points || !frames || !flags || K <= 0) return PNGPD_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(gpg_frames_kernel, dim3((K + 63) / 64), dim3(64), 0, (hipStream_t)stream, M, normals_at, points,
+                       K, frames, flags);
+    return pngpd_launch_status();
+}
 
 int pngpd_gpg_normal_moments(const void *cloud, int cloud_is_f64, const double *normals, int P,
                              const double *queries, int K, double radius, int max_nn, double *M_out,

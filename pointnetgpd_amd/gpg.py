@@ -215,6 +215,22 @@ def normal_moments(cloud, normals, queries, radius, max_nn=MAX_NN, index=None):
     return M, nsel
 
 
+def local_frames(M, normals_at, points):
+    """grasp_sampler.py:1486-1506 on the device (``pngpd_gpg_frames``): M (K,3,3), normals_at (K,3), points (K,3) CUDA f64
+    -> frames (K,12) f64 = minor, normal, major, sample point; flags (K,) int32 (1 = zero moment matrix: the point is
+    skipped, 2 = LAPACK's complex-pair case, 4 / 8 = not converged / out of range).  ``np.linalg.eig`` is evaluated as
+    LAPACK's DGEEV evaluates it (same eigenvalue order and eigenvector signs: csrc/pngpd_gpg_eig3.h)."""
+    for name, t, shp in (("M", M, (3, 3)), ("normals_at", normals_at, (3,)), ("points", points, (3,))):
+        if not t.is_cuda or t.dtype != torch.float64 or tuple(t.shape[1:]) != shp or t.shape[0] != M.shape[0]:
+            raise RuntimeError(f"{name}: expected a CUDA (K,{','.join(map(str, shp))}) float64 tensor")
+    K = M.shape[0]
+    frames = torch.empty(K, 12, device=M.device, dtype=torch.float64)
+    flags = torch.empty(K, device=M.device, dtype=torch.int32)
+    if K:
+        _call("pngpd_gpg_frames", M, M.contiguous(), normals_at.contiguous(), points.contiguous(), K, frames, flags)
+    return frames, flags
+
+
 def _spread3(v):
     """10-bit integers -> bits spread to every third position (Morton interleave helper), int64 tensors."""
     v = v & 0x3FF
@@ -353,7 +369,8 @@ class GpgGraspSamplerPcl:
     init_bite (default: robotiq_85).  ``config`` is accepted for signature compatibility and unused, as in the
     Pcl sampler."""
 
-    def __init__(self, gripper=None, config=None, device=None, use_index=True, batch_samples=4096, fused_sweep=True):
+    def __init__(self, gripper=None, config=None, device=None, use_index=True, batch_samples=4096, fused_sweep=True,
+                 eig="device"):
         # sphere-culled collision kernel (identical counts).  False = brute force (debugging): it cannot skip the unused
         # tail of the capacity-sized push-in buffer and is slower even on 3,000-point clouds (3.4 vs 2.6 ms per scene).
         self.use_index = bool(use_index)
@@ -361,11 +378,18 @@ class GpgGraspSamplerPcl:
         # False = one wave per pose (pngpd_hand_box_counts_indexed) + pngpd_gpg_select: same flag / dsel, ~5x the work.
         self.fused_sweep = bool(fused_sweep) and self.use_index
         self.batch_samples = int(batch_samples)   # sample points per device round (399 poses each; bounds host memory)
+        # where np.linalg.eig(M) (:1493) runs.  "device" (default): pngpd_gpg_frames — LAPACK's DGEEV restated for 3x3
+        # (same eigenvalue order and eigenvector signs), a round is then ONE uninterrupted device chain: no download of
+        # M, no host thread pool, no upload of the frames.  "lapack": the library call itself on the host, as rounds 1-5.
+        if eig not in ("device", "lapack"):
+            raise ValueError("eig: 'device' or 'lapack'")
+        self.eig = eig
         self.gripper = gripper if gripper is not None else ROBOTIQ_85
         self.config = config
         self.device = torch.device(device) if device is not None else None
         self.last_stats = {}
         self._const_cache = {}
+        self._prm_dev = {}                        # the sweep parameter block on the device (eig="device": nothing is uploaded per round)
         self.sweep_stats = None                   # a CUDA int64 (4,) tensor: pngpd_gpg_sweep_select adds its diagnostics
         self.pushin_stats = None                  # the same for pngpd_gpg_pushin_sweep
         self.profile = None                       # set to {} to collect per-stage times (synchronising; diagnostics only)
@@ -379,6 +403,7 @@ class GpgGraspSamplerPcl:
         if c is None:
             prm, R, D, S = self._params(g)
             c = self._const_cache[key] = (torch.from_numpy(hand_boxes(g)).to(dev), prm, R, D, S)
+            self._prm_dev[key] = torch.from_numpy(prm).to(dev)
         return c
 
     def _tick(self, name, dev):
@@ -443,11 +468,20 @@ class GpgGraspSamplerPcl:
         r_ball = max(g["hand_outer_diameter"] - fw, hd, g["hand_height"] / 2.0)                  # :1464
         # uploads go through pinned staging buffers: a pageable copy would block the host until the device has drained
         # everything queued before it — i.e. the previous round's whole chain — and serialise the pipeline
-        q_h = self._pinned(K * 3)
+        dev_eig = self.eig == "device"
+        nq = K * (6 if dev_eig else 3)
+        q_h = self._pinned(nq)
         q_h.numpy()[:K * 3] = np.ascontiguousarray(sel_pts).reshape(-1)      # numpy's memcpy: see _stage_chain's upload
-        q_d = torch.empty(K, 3, device=dev, dtype=torch.float64)
-        q_d.view(-1).copy_(q_h[:K * 3], non_blocking=True)
+        if dev_eig:
+            q_h.numpy()[K * 3:K * 6] = np.ascontiguousarray(normals_at_ind).reshape(-1)
+        q2_d = torch.empty(nq // 3, 3, device=dev, dtype=torch.float64)
+        q2_d.view(-1).copy_(q_h[:nq], non_blocking=True)
+        q_d = q2_d[:K]
         M_d, _ = normal_moments(cloud_d, normals_d, q_d, r_ball, MAX_NN, index=index)
+        if dev_eig:
+            # :1486-1506 on the device: the round stays one device chain (no M download, no host eig, no frame upload)
+            frames_d, flags_d = local_frames(M_d, q2_d[K:], q_d)
+            return dict(K=K, sel_pts=sel_pts, normals_at_ind=normals_at_ind, q_h=q_h, frames_d=frames_d, flags_d=flags_d)
         M_h = self._pinned(K * 9)
         M_h[:K * 9].copy_(M_d.view(-1), non_blocking=True)                                      # download 1: K x 9 doubles
         ev = torch.cuda.Event()
@@ -464,6 +498,15 @@ class GpgGraspSamplerPcl:
         if self.use_index and scene.get("index") is None:
             scene["index"] = CloudIndex(cloud_d)          # enqueued behind the first moments kernel; the host does not wait
         index = scene.get("index")
+        if self.eig == "device":
+            tick("moments+frames", dev)
+            L = K
+            rd["live"], rd["L"], rd["m_zero"] = np.arange(K), K, None      # the flags arrive with the packed result
+            frames_d = rd["frames_d"].view(-1)
+            up_d = frames_d
+            prm_d = self._prm_dev[(tuple(sorted(g.items())), str(dev))]
+            self._chain_device(rd, up_d, frames_d, prm_d, L, R, D, S, boxes_d, index, cloud_d, dev)
+            return
         rd["ev_m"].synchronize()
         tick("moments+download", dev)
         M = rd["M_h"][:K * 9].numpy().reshape(K, 3, 3).copy()
@@ -498,11 +541,18 @@ class GpgGraspSamplerPcl:
         up_d.copy_(up_h[:up.size], non_blocking=True)                                           # upload: frames + constants
         rd["up_h"] = up_h
         frames_d, prm_d = up_d[:L * 12], up_d[L * 12:]
+        self._chain_device(rd, up_d, frames_d, prm_d, L, R, D, S, boxes_d, index, cloud_d, dev)
+
+    def _chain_device(self, rd, up_d, frames_d, prm_d, L, R, D, S, boxes_d, index, cloud_d, dev):
+        """[device] pose enumeration -> lateral sweep + selection -> push-in -> packed result and its download."""
+        tick = self._tick
+        K = rd["K"]
+        nflag = K if self.eig == "device" else 0
         cap = L * R
         f64, i32 = torch.float64, torch.int32
         nres = 1 + L + cap * 15 + 1
         ws = _ws_ring(dev)[rd["slot"] % 4]
-        ws.reset(dev, 8 * (cap * D * 12 + cap * 6 + cap * S * 2 * 12 + 2 * cap * S * 3 + nres) + 4 * 2 * (3 * cap + 1) + 4096)
+        ws.reset(dev, 8 * (cap * D * 12 + cap * 6 + cap * S * 2 * 12 + 2 * cap * S * 3 + nres + nflag) + 4 * 2 * (3 * cap + 1) + 4096)
         poses = ws.take((cap * D, 12), f64)
         ab = ws.take((cap, 6), f64)
         _call("pngpd_gpg_enumerate", up_d, frames_d, L, R, D, prm_d, poses, ab)
@@ -528,12 +578,14 @@ class GpgGraspSamplerPcl:
         else:
             cnt2 = hand_box_counts(cloud_d, poses2, boxes_d, index=index, valid_units=total, per_unit=2 * S)
         tick("pushin+sweep2", dev)
-        out = ws.take((nres,), f64)
+        out = ws.take((nres + nflag,), f64)
         _call("pngpd_gpg_finish", up_d, cnt2, plist, total, ab, frames_d, back, mod, L, R, S, MIN_OPEN_POINTS, found,
               sfirst, olist, ototal, out)
-        out[-1:].copy_(total)               # the potential-grasp count rides in the same download (it was a third sync)
-        host_t = self._pinned(nres)
-        host_t[:nres].copy_(out, non_blocking=True)                                             # download 2: packed result
+        out[nres - 1:nres].copy_(total)     # the potential-grasp count rides in the same download (it was a third sync)
+        if nflag:
+            out[nres:].copy_(rd["flags_d"])  # eig="device": so do the per-point flags (zero moment matrix, complex pair)
+        host_t = self._pinned(nres + nflag)
+        host_t[:nres + nflag].copy_(out, non_blocking=True)                                     # download 2: packed result
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
         rd.update(host_t=host_t, nres=nres, out_d=out, ev_r=ev)
@@ -549,12 +601,20 @@ class GpgGraspSamplerPcl:
         self._tick("finish+download", dev)
         L, live = rd["L"], rd["live"]
         host = rd["host_t"][:rd["nres"]].numpy()
+        if m_zero is None:                                      # eig="device": the frame flags came with the result
+            fl = rd["host_t"][rd["nres"]:rd["nres"] + K].numpy().astype(np.int64)
+            m_zero = (fl & 1) != 0
+            if (fl & 12).any():
+                raise RuntimeError(f"pngpd_gpg_frames: {int(((fl & 4) != 0).sum())} moment matrices did not converge, "
+                                   f"{int(((fl & 8) != 0).sum())} are outside DGEEV's unscaled range; use eig='lapack'")
+            self.last_stats["eig_complex_pairs"] = self.last_stats.get("eig_complex_pairs", 0) + int(((fl & 2) != 0).sum())
+            rd.pop("frames_d", None); rd.pop("flags_d", None); self._unpin(rd.pop("q_h", None))
         self.last_stats["potential"] = self.last_stats.get("potential", 0) + int(host[-1])
         n = int(host[0])
         counts[live] = host[1:1 + L].astype(np.int64)
         # rows are packed in (live sample point, rotation) order = draw order: no per-draw regrouping needed
         grasps = host[1 + L:1 + L + n * 15].reshape(n, 5, 3).copy()
-        self._unpin(rd.pop("host_t")); rd.pop("out_d"); self._unpin(rd.pop("up_h"))
+        self._unpin(rd.pop("host_t")); rd.pop("out_d"); self._unpin(rd.pop("up_h", None))
         return m_zero, counts, grasps
 
     def sample_grasps(self, point_cloud, points_for_sample, all_normal, num_grasps=20, max_num_samples=200,

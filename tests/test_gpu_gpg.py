@@ -399,3 +399,92 @@ def test_fused_pushin_sweep_equals_counts_then_first_accept(dtype, P, kind, L, c
               sfirst1, olist, ototal, out1)
         nf = int(out0[0].item())                     # the packed result: [n_found, per-sample-point counts, rows]
         assert nf == int(found0[:n].sum()) and torch.equal(out1[:1 + L + nf * 15], out0[:1 + L + nf * 15])
+
+
+# ---- np.linalg.eig(M) on the device (pngpd_gpg_frames, csrc/pngpd_gpg_eig3.h) ------------------------------------------------
+def _host_frames(M, nat, pts):
+    """The HOST build of the header the kernel compiles (g++, contraction off): frames + flags."""
+    import ctypes, os, subprocess, tempfile
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = os.path.join(tempfile.mkdtemp(prefix="eig3"), "libeig3_host.so")
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-I",
+                    os.path.join(here, "..", "pointnetgpd_amd", "csrc"),
+                    os.path.join(here, "helpers_src", "eig3_host.cpp"), "-o", out], check=True)
+    lib = ctypes.CDLL(out)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    M, nat, pts = (np.ascontiguousarray(a, dtype=np.float64) for a in (M, nat, pts))
+    frames, flags = np.empty((len(M), 12)), np.empty(len(M), dtype=np.int32)
+    lib.eig3_frames(p(M), p(nat), p(pts), ctypes.c_long(len(M)), p(frames), p(flags))
+    return frames, flags
+
+
+def test_frames_kernel_bit_identical_to_host_build_and_to_numpy_frames(cuda_device):
+    """The kernel == the host build of the same header, bit for bit (so tests/test_gpg_eig3.py speaks for the device), and
+    == the frames the host path builds from np.linalg.eig itself (same signs, 1e-12), incl. a zero and a rank-1 matrix."""
+    from pointnetgpd_amd import gpg
+    from tests.test_gpg_eig3 import moment_matrices
+    rng = np.random.default_rng(5)
+    M = np.concatenate([moment_matrices(rng, 3000, noise=0.05), moment_matrices(rng, 1000, noise=0.3),
+                        np.zeros((1, 3, 3)), moment_matrices(rng, 3, kmin=1, kmax=1)])
+    K = len(M)
+    nat = rng.normal(size=(K, 3))
+    pts = rng.normal(size=(K, 3)) * 0.1
+    dev = torch.device(cuda_device)
+    fr, fl = gpg.local_frames(*(torch.from_numpy(a).to(dev) for a in (M, nat, pts)))
+    fr, fl = fr.cpu().numpy(), fl.cpu().numpy()
+    hf, hfl = _host_frames(M, nat, pts)
+    np.testing.assert_array_equal(fl, hfl)
+    np.testing.assert_array_equal(fr, hf)
+    assert fl[4000] == 1 and (fl[4001:] == 2).all() and not fl[:4000].any()
+    assert np.array_equal(fr[4000], [1, 0, 0, 0, 1, 0, 0, 0, 1, 1e6, 1e6, 1e6])
+    assert np.isfinite(fr).all()
+    # against numpy's LAPACK + the frame construction of the host path (gpg._stage_chain)
+    live = np.arange(4000)
+    w, v = np.linalg.eig(M[live])
+    w, v = np.real(w), np.real(v)
+    ar = np.arange(len(live))
+    unit = lambda x: x / np.linalg.norm(x, axis=-1, keepdims=True)
+    minor, normal = unit(v[ar, :, np.argmin(w, 1)]), unit(v[ar, :, np.argmax(w, 1)])
+    major = unit(np.cross(minor, normal))
+    flip = (nat[live] * normal).sum(1) < 0
+    normal, minor = np.where(flip[:, None], -normal, normal), np.where(flip[:, None], -minor, minor)
+    ref = np.concatenate([minor, normal, major, pts[live]], 1)
+    bad = np.abs(fr[live] - ref).max(1) > 1e-11
+    assert bad.sum() <= 2, f"{bad.sum()} frames differ from the LAPACK-built ones"      # rounding-decided QR sweeps
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_sampler_device_eig_equals_lapack_eig(tag, cuda_device):
+    """Both placements of :1493 reproduce the executed reference; the device one without touching the host in a round."""
+    from pointnetgpd_amd import gpg
+    fx, pts, pfs, nrm = load_case(tag)
+    out = {}
+    for eig in ("device", "lapack"):
+        s = gpg.GpgGraspSamplerPcl(device=cuda_device, eig=eig)
+        out[eig] = s.sample_grasps(pts, pfs, nrm, int(fx["num_grasps"]), int(fx["max_num_samples"]),
+                                   sample_indices=fx["draws"], as_array=True)
+        np.testing.assert_allclose(out[eig], fx["grasps"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(out["device"], out["lapack"], rtol=0, atol=1e-12)
+
+
+def test_sampler_device_eig_at_scale_and_zero_moments(cuda_device):
+    """2,000 sample points over several rounds, some of them isolated (M == 0 -> skipped, not counted): the device-eig
+    sampler and the LAPACK one agree on the candidates (up to the rounding-decided frames: identical here) and on the
+    bookkeeping (draws, sampled)."""
+    from pointnetgpd_amd import gpg
+    pts, nrm = go.synth_scene("cylinder", 12000, 41)
+    far = np.array([[5.0, 5.0, 5.0], [6.0, -5.0, 5.0], [-7.0, 5.0, 5.0]])                # no neighbour within r_ball
+    pts2 = np.concatenate([pts, far]); nrm2 = np.concatenate([nrm, np.ones((3, 3))])
+    pfs = np.concatenate([pts[pts[:, 2] > 0.01][:3000], far])
+    draws = np.random.default_rng(9).integers(0, len(pfs), 2000)
+    draws[[5, 700, 1500]] = [len(pfs) - 1, len(pfs) - 2, len(pfs) - 3]
+    res = {}
+    for eig in ("device", "lapack"):
+        s = gpg.GpgGraspSamplerPcl(device=cuda_device, eig=eig, batch_samples=512)
+        res[eig] = (s.sample_grasps(pts2, pfs, nrm2, 10 ** 9, 2000, sample_indices=draws, as_array=True), dict(s.last_stats))
+    a, b = res["device"][0], res["lapack"][0]
+    assert a.shape == b.shape and len(a) > 500
+    np.testing.assert_allclose(a, b, rtol=0, atol=1e-11)
+    for k in ("draws", "sampled", "potential"):
+        assert res["device"][1][k] == res["lapack"][1][k]
+    assert res["device"][1]["sampled"] == 1997
