@@ -323,3 +323,79 @@ def test_indexed_crop_equals_plain_crop(dtype, P, G, max_keep, N, cuda_device):
     for g in np.nonzero(v.cpu().numpy())[0][:10]:
         lo, hi = f[g, 12:15], f[g, 15:18]
         assert (o[g] > lo[:, None] - 1e-6).all() and (o[g] < hi[:, None] + 1e-6).all()
+
+
+def _dense_scene(G, P, seed):
+    """A small object inside the hand's reach (as a table-top object is): most of the cloud lies in every hand's box."""
+    pc, grasps = _scene(G, P, seed)
+    pc = pc * np.array([0.2, 0.2, 0.3])                      # 6 x 6 x 6 cm blob
+    grasps = grasps.copy()
+    grasps[:, 0] = pc[np.random.default_rng(seed + 1).integers(0, P, G)] - 0.05 * grasps[:, 1]
+    grasps[:, 4] = grasps[:, 0]
+    return pc, grasps
+
+
+@pytest.mark.parametrize("dtype,P,N,mode_name", [(np.float32, 50000, 1024, "infer"), (np.float64, 20001, 750, "train"),
+                                                 (np.float32, 9000, 64, "infer")])
+def test_one_scan_overflow_path_equals_the_radix_path(dtype, P, N, mode_name, cuda_device):
+    """Hands that hold more in-box points than ``max_keep`` (every hand on a dense table-top scene): the one-scan path
+    (in-box bitmask in LDS + ~N + 8 sqrt(N) candidate keys, round 6) must pick the very subset the radix path picks —
+    forced here by a ``max_keep`` whose scratch cannot hold the bitmask — in the same column order, bit for bit; with
+    ``ranges`` (a grasp's own sub-cloud) as well."""
+    from pointnetgpd_amd import crop
+    G = 96
+    pc, grasps = _dense_scene(G, P, 91)
+    mode = crop.MODE_INFER if mode_name == "infer" else crop.MODE_TRAIN
+    cloud = torch.from_numpy(pc.astype(dtype)).to(cuda_device)
+    frames = torch.from_numpy(crop.frames_from_grasps_infer(grasps)).to(cuda_device)
+    big, small = 8192, max(N, 256)
+    cb, ib = crop.crop_count_compact(cloud, frames, max_keep=big)
+    cs, is_ = crop.crop_count_compact(cloud, frames, max_keep=small)
+    assert torch.equal(cb, cs)
+    over = cb > big
+    assert int(over.sum()) >= (G // 2 if P > 10000 else 0) and int((cb > small).sum()) >= G // 2
+    ob, vb = crop.crop_resample(cloud, frames, cb, ib, N, mode, 20, seed=99, g_base=5000)
+    os_, vs = crop.crop_resample(cloud, frames, cs, is_, N, mode, 20, seed=99, g_base=5000)
+    assert torch.equal(vb, vs)
+    # identical wherever both runs re-scan the cloud (count > both list sizes); elsewhere the big list is used as is,
+    # which the radix re-scan of the small run must reproduce too (same keys, same ranks)
+    assert torch.equal(ob, os_)
+    # a grasp's own sub-cloud through `ranges`
+    half = P // 2
+    ranges = torch.tensor([[0, half] if g % 2 == 0 else [half, P - half] for g in range(G)], dtype=torch.int32,
+                          device=cuda_device)
+    c2, i2 = crop.crop_count_compact_ranges(cloud, frames, ranges, max_keep=big) if hasattr(crop, "crop_count_compact_ranges") else (None, None)
+    if c2 is not None:
+        c3, i3 = crop.crop_count_compact_ranges(cloud, frames, ranges, max_keep=small)
+        o2, _ = crop.crop_resample(cloud, frames, c2, i2, N, mode, 20, seed=7, ranges=ranges)
+        o3, _ = crop.crop_resample(cloud, frames, c3, i3, N, mode, 20, seed=7, ranges=ranges)
+        assert torch.equal(o2, o3)
+
+
+def test_one_scan_overflow_path_is_a_uniform_subset(cuda_device):
+    """Statistics of the one-scan path itself: 3,000 identical hands holding m > max_keep points, N = 64 drawn without
+    replacement: distinct, ascending, every in-box point with frequency N / m (5.5 sigma), beyond the list as within."""
+    from pointnetgpd_amd import crop
+    pc, grasps = _dense_scene(1, 12000, 17)
+    pc32 = pc.astype(np.float32)
+    G, N, max_keep = 3000, 64, 4096
+    frames = torch.from_numpy(np.repeat(crop.frames_from_grasps_infer(grasps), G, 0)).to(cuda_device)
+    cloud = torch.from_numpy(pc32).to(cuda_device)
+    counts, idx = crop.crop_count_compact(cloud, frames, max_keep=max_keep)
+    m = int(counts[0])
+    assert m > max_keep, m
+    out, valid = crop.crop_resample(cloud, frames, counts, idx, N, crop.MODE_INFER, 1, seed=4321)
+    assert bool(valid.all())
+    ind_ref, pts_ref = co.collect_pc_infer(grasps, pc32)
+    assert len(ind_ref[0]) == m
+    ref32 = torch.from_numpy(pts_ref[0].astype(np.float32)).to(cuda_device)
+    rank = torch.empty(G, N, dtype=torch.long, device=cuda_device)
+    for s in range(0, G, 100):
+        d = (out[s:s + 100].permute(0, 2, 1).unsqueeze(2) - ref32.view(1, 1, m, 3)).abs().amax(3)
+        assert float(d.amin(2).max()) <= 1e-8
+        rank[s:s + 100] = d.argmin(2)
+    assert bool((rank[:, 1:] > rank[:, :-1]).all())
+    freq = torch.bincount(rank.reshape(-1), minlength=m).double() / G
+    p = N / m
+    assert float((freq - p).abs().max()) < 5.5 * np.sqrt(p * (1 - p) / G)
+    assert abs(float(freq[max_keep:].mean()) / float(freq[:max_keep].mean()) - 1.0) < 0.05

