@@ -556,6 +556,127 @@ __global__ __launch_bounds__(256, 2) void trunk_pool_refine_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
+// pool refinement over the DISTINCT arg-max points of a cloud (round 6; the VALU variants 1 / 2 when the caller has the
+// sign-folded MFMA_B weights at hand).  The 1,024 pooled channels of a cloud pick few different points — 53..98 of 1,024
+// on the headline's iid clouds, 33..606 (mean 150) on diverse ones (profiles/r06_probe_unique_args.json) — but the
+// kernel above evaluates the fp32 layers 1-2 at all B x 1,024 (cloud, channel) pairs: 17.6 GFLOP on the fp32 matrix
+// pipe per launch, 0.18-0.22 ms, 10-16 % of a bf16-mode training step.  Here one workgroup owns a CLOUD: the arg-max
+// points are marked in an N-bit LDS bitmap, a popcount scan numbers the distinct ones (ascending point index), layers
+// 1-2 run on 64-point chunks of THAT list (the same layer1_tile / layer2_compute, so every h2 row has the bits the
+// kernel above and the fp32 pass C give it), and each channel contracts its sign-folded weight row with the h2 row
+// of its point on the VALU in the matrix instruction's order (VARIANT 1: k then k + 4; 2: k + 4 then k) — the weight
+// row read from the MFMA_B fragments, where 32 consecutive channels' k-quads are contiguous (coalesced for lane =
+// channel; the row-major weight the kernel above reads is not).  Same zex, bit for bit.
+// ---------------------------------------------------------------------------------------
+#define REFINE_DEDUP_LDS_FLOATS(W32) (TP * H1S + TP * H2S + 4 * TP + 2 * (W32) + 1024)
+
+template <int VARIANT>
+__global__ __launch_bounds__(256, 2) void trunk_pool_refine_dedup_kernel(
+    const float *__restrict__ x, int B, int N, const float *__restrict__ trans, TrainChan P,
+    const float *__restrict__ w3sp, const int *__restrict__ idx, int W32, float *__restrict__ zex) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *h1 = smem;                                  // [TP][H1S]
+    float *h2 = h1 + TP * H1S;                         // [TP][H2S]
+    float *xs = h2 + TP * H2S;                         // [3][TP] (+ TP spare)
+    unsigned *bitmap = (unsigned *)(xs + 4 * TP);      // [W32] bit n: point n is some channel's arg-max
+    int *pre = (int *)(bitmap + W32);                  // [W32] distinct points before word w
+    int *ulist = pre + W32;                            // [<= 1024] the distinct points, ascending
+    __shared__ int shw[4];
+    const Lane L;
+    const bool has_t = trans != nullptr;
+    const int c2 = L.wave * 32 + L.j;
+    const float sc = P.s2c[c2], sh = P.t2c[c2];
+    f32x4 w2f[8];
+    load_w2frag(w2f, P.w2p, L.wave, L);
+    const L1C l1c = load_l1c(P.w1, P.b1, P.s1c, P.t1c, L);
+    const int Wt = (W32 + 255) >> 8;
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();                               // the previous cloud's lists are no longer read
+        for (int w = L.tid; w < W32; w += 256) bitmap[w] = 0u;
+        __syncthreads();
+        int nq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            nq[q] = idx[(size_t)b * 1024 + L.tid + 256 * q];
+            atomicOr(&bitmap[nq[q] >> 5], 1u << (nq[q] & 31));
+        }
+        __syncthreads();
+        int loc = 0;
+        for (int q = 0; q < Wt; ++q) { const int w = L.tid * Wt + q; if (w < W32) loc += __popc(bitmap[w]); }
+        int incl = loc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (L.lane >= d) incl += t; }
+        if (L.lane == 63) shw[L.wave] = incl;
+        __syncthreads();
+        int run = incl - loc, U = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { if (w < L.wave) run += shw[w]; U += shw[w]; }
+        for (int q = 0; q < Wt; ++q) {
+            const int w = L.tid * Wt + q;
+            if (w < W32) {
+                pre[w] = run;
+                unsigned m = bitmap[w];
+                while (m) { const int bit = __ffs(m) - 1; ulist[run++] = w * 32 + bit; m &= m - 1u; }
+            }
+        }
+        __syncthreads();
+        int slot[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            slot[q] = pre[nq[q] >> 5] + __popc(bitmap[nq[q] >> 5] & ((1u << (nq[q] & 31)) - 1u));
+        const float *xb = x + (size_t)b * 3 * N;
+        const int nch = (U + TP - 1) / TP;
+        for (int ch = 0; ch < nch; ++ch) {
+            if (L.tid < TP) {
+                int u = ch * TP + L.tid; u = u < U ? u : U - 1;
+                const int n = ulist[u];
+                float x0 = xb[n], x1 = xb[N + n], x2 = xb[2 * N + n];
+                if (has_t) {
+                    const float *tm = trans + (size_t)b * 9;
+                    const float y0 = fmaf(x2, tm[6], fmaf(x1, tm[3], x0 * tm[0]));
+                    const float y1 = fmaf(x2, tm[7], fmaf(x1, tm[4], x0 * tm[1]));
+                    const float y2 = fmaf(x2, tm[8], fmaf(x1, tm[5], x0 * tm[2]));
+                    x0 = y0; x1 = y1; x2 = y2;
+                }
+                xs[L.tid] = x0; xs[TP + L.tid] = x1; xs[2 * TP + L.tid] = x2;
+            }
+            __syncthreads();   // points staged; every thread is done with the previous chunk's h1 / h2
+            layer1_tile(xs, l1c, h1, L);
+            __syncthreads();
+            f32x16 a0, a1;
+            layer2_compute(h1, w2f, L, a0, a1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mfma_row(r, L.lane);
+                h2[row * H2S + c2] = fmaxf(fmaf(a0[r], sc, sh), 0.f);
+                h2[(32 + row) * H2S + c2] = fmaxf(fmaf(a1[r], sc, sh), 0.f);
+            }
+            __syncthreads();   // h2 complete
+#pragma unroll 1
+            for (int q = 0; q < 4; ++q) {
+                if ((slot[q] >> 6) != ch) continue;
+                const int c = L.tid + 256 * q;
+                const float *hr = h2 + (slot[q] & 63) * H2S;
+                // channel c's row in the MFMA_B fragments: quad (kb, h) of channel block c >> 5 at lane h * 32 + (c & 31)
+                const f32x4 *wr = (const f32x4 *)w3sp + (size_t)((c >> 5) * 16) * 64 + (c & 31);
+                float acc = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < 16; ++kb) {
+                    const f32x4 alo = *(const f32x4 *)(hr + kb * 8), ahi = *(const f32x4 *)(hr + kb * 8 + 4);
+                    const f32x4 wlo = wr[kb * 64], whi = wr[kb * 64 + 32];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (VARIANT == 1) { acc = fmaf(alo[t], wlo[t], acc); acc = fmaf(ahi[t], whi[t], acc); }
+                        else { acc = fmaf(ahi[t], whi[t], acc); acc = fmaf(alo[t], wlo[t], acc); }
+                    }
+                }
+                zex[(size_t)b * 1024 + c] = acc;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // backward pass D: g2 = dL/d(bn2 output) per point; also the 128x128 second moments of h2 (the old separate
 // "h-moments" pass: h2 is in LDS here anyway and this pass has idle MFMA slots).
 //   dh2[point][k] = cvec[k] - (h2 A)[point][k] + sum_{c: idx[b][c]==point} coef[b][c] W3[c][k]
@@ -1782,10 +1903,29 @@ int pngpd_trunk_pool_refine(const float *x, int B, int N, const float *trans,
                             const float *w3sp, const float *w3, const float *g3, const int *idx,
                             int clouds_per_range, int variant, float *zex, void *stream) {
     if (!x || !w1 || !b1 || (!s1c != !t1c) || !w2p || !s2c || !t2c || !idx || !zex || B <= 0 || N <= 0 ||
-        clouds_per_range <= 0 || variant < 0 || variant > 3 || (variant == 0 ? !w3sp : (!w3 || !g3)))
+        clouds_per_range <= 0 || variant < 0 || variant > 3 ||
+        (variant == 0 ? !w3sp : ((variant == 3 || !w3sp) && (!w3 || !g3))))
         return PNGPD_ERR_INVALID_ARG;
     const int R = (B + clouds_per_range - 1) / clouds_per_range;
     TrainChan P = make_chan(w1, b1, s1c, t1c, w2p, s2c, t2c);
+    if ((variant == 1 || variant == 2) && w3sp && N <= 65536) {
+        // the VALU variants with the sign-folded MFMA_B weights at hand: layers 1-2 at the DISTINCT arg-max points only
+        const int W32 = (N + 31) / 32;
+        const size_t lds = (size_t)REFINE_DEDUP_LDS_FLOATS(W32) * sizeof(float);
+        const void *fn = variant == 1 ? (const void *)trunk_pool_refine_dedup_kernel<1>
+                                      : (const void *)trunk_pool_refine_dedup_kernel<2>;
+        int st = pngpd_allow_lds(fn, lds);
+        if (st != PNGPD_OK) return st;
+        const dim3 grid((unsigned)(B < 2048 ? B : 2048));
+        if (variant == 1)
+            hipLaunchKernelGGL(trunk_pool_refine_dedup_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, x, B, N, trans,
+                               P, w3sp, idx, W32, zex);
+        else
+            hipLaunchKernelGGL(trunk_pool_refine_dedup_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, x, B, N, trans,
+                               P, w3sp, idx, W32, zex);
+        return pngpd_launch_status();
+    }
+    if (variant != 0 && (!w3 || !g3)) return PNGPD_ERR_INVALID_ARG;
     const size_t lds = REFINE_LDS_FLOATS * sizeof(float);
     const void *fn = variant == 0 ? (const void *)trunk_pool_refine_kernel<0>
                    : variant == 1 ? (const void *)trunk_pool_refine_kernel<1>

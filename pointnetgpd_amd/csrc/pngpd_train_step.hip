@@ -164,7 +164,7 @@ int pngpd_trunk_train_fwd(const pngpd_trunk_train_t *a, void *stream) {
             P.job[n++] = PackJob{a->w2, nullptr, s.w2x, 128, 64, 0, 0, 1};
             P.job[n++] = PackJob{a->w3, a->g3, f.w3sx, 1024, 128, 0, 0, 1};
             if (d.nt_side && a->need_bwd) P.job[n++] = PackJob{a->w2, nullptr, s.w2tx, 64, 128, 1, 0, 1};
-            if (a->refine == 1) P.job[n++] = PackJob{a->w3, a->g3, f.w3sp, 1024, 128, 0, 0, 0};
+            if (a->refine) P.job[n++] = PackJob{a->w3, a->g3, f.w3sp, 1024, 128, 0, 0, 0};   // (2: the VALU variant reads its rows from the fragments)
         } else {
             P.job[n++] = PackJob{a->w3, a->g3, f.w3sp, 1024, 128, 0, 0, 0};
         }
@@ -216,7 +216,7 @@ int pngpd_trunk_train_fwd(const pngpd_trunk_train_t *a, void *stream) {
         // the reduced-precision pass C chose the points; their values are re-evaluated in exact fp32 (layers 1-2 for
         // the B*1024 arg-max points + one 128-long contraction each) and the pooled outputs rebuilt from those
         CHK(pngpd_trunk_pool_refine(x, B, N, T, a->w1, a->b1, s1c, t1c, s.w2p, s2c, t2c,
-                                    a->refine == 1 ? f.w3sp : nullptr, a->w3, a->g3, a->idx, d.cpr,
+                                    f.w3sp, a->w3, a->g3, a->idx, d.cpr,
                                     a->refine == 1 ? 0 : PNGPD_REFINE_VALU_VARIANT, f.zex, stream));
         CHK(pngpd_pool_finalize(f.zex, a->idx, B, 1, s.stats3, a->g3, a->be3, a->eps, a->relu_last, a->pooled, a->idx,
                                 a->zhat, stream));

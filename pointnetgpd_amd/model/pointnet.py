@@ -72,7 +72,8 @@ def _trunk_infer(mod, x, trans, relu_last, folded=None):
             # unit vectors standing in for the train-mode layer-2 scale / the sign of gamma3 (both folded into the weights)
             ones = folded["ones"] = (torch.ones(128, device=x.device), torch.ones(1024, device=x.device))
         zex = ops.trunk_pool_refine(x.float() if x.dtype == torch.bfloat16 else x, trans, l1["row"], l1["bf"], None,
-                                    None, l2["mfma"], ones[0], l2["bf"], arg, w3=l3["row"], g3=ones[1], variant=1)
+                                    None, l2["mfma"], ones[0], l2["bf"], arg, w3=l3["row"], g3=ones[1], w3sp=l3["mfma"],
+                                    variant=1)      # w3sp given: layers 1-2 at the DISTINCT arg-max points only
         pooled = zex + l3["bf"]
         if relu_last:
             pooled = torch.where(pooled < 0, torch.zeros_like(pooled), pooled)
@@ -198,7 +199,7 @@ def _trunk_wants(cfg):
     if cfg.infer == "fp32":
         return (("row",), ("mfma",), ("mfma",))
     if cfg.infer_refine:
-        return (("row",), ("mfma", "x3"), ("row", "x3"))
+        return (("row",), ("mfma", "x3"), ("row", "mfma", "x3"))
     return (("row",), ("x3",), ("x3",))
 
 

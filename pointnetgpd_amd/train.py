@@ -171,7 +171,7 @@ class TrunkTrainFn(torch.autograd.Function):
                                             w3sp=ops.pack_mfma_b(w3, scale=sgn), variant=0)
             else:
                 zex = ops.trunk_pool_refine(x, T, w1, b1c, s1c, t1c, w2p, s2c, t2c, idx, w3=w3, g3=g3c,
-                                            variant=_REFINE_VALU_VARIANT)
+                                            w3sp=ops.pack_mfma_b(w3, scale=sgn), variant=_REFINE_VALU_VARIANT)
             _call("pngpd_pool_finalize", x, zex, idx, B, 1, stats3, g3c, be3c, float(eps), int(relu_last), pooled,
                   idx, zhat)
         ctx.relu_last, ctx.eps, ctx.has_t, ctx.S = relu_last, eps, T is not None, S

@@ -95,6 +95,15 @@ def test_refine_reproduces_fp32_pass_c_bitwise(B, N, kind, modes, cuda_device):
         for v in (1, 2, 3):
             zv = ops.trunk_pool_refine(xx, T, w1, b1, s1c, t1c, w2p, s2c, t2c, i32.contiguous(), w3=w3, g3=g3, variant=v)
             hits[v] = int((zv != m32).sum().item())
+            if v in (1, 2):
+                # the same variant over the DISTINCT arg-max points (w3sp given: trunk_pool_refine_dedup_kernel): same bits
+                zd = ops.trunk_pool_refine(xx, T, w1, b1, s1c, t1c, w2p, s2c, t2c, i32.contiguous(), w3=w3, g3=g3,
+                                           w3sp=w3sp, variant=v)
+                assert torch.equal(zd, zv), (which, v, (zd - zv).abs().max().item())
+                zd2 = ops.trunk_pool_refine(xx, T, w1, b1, s1c, t1c, w2p, s2c, t2c, idx_bf.contiguous(), w3=w3, g3=g3,
+                                            w3sp=w3sp, variant=v)
+                zl2 = ops.trunk_pool_refine(xx, T, w1, b1, s1c, t1c, w2p, s2c, t2c, idx_bf.contiguous(), w3=w3, g3=g3, variant=v)
+                assert torch.equal(zd2, zl2)
         print(f"[refine B={B} N={N} trunk {which}] entries differing from the matrix pipe: VALU order (k, k+4) {hits[1]}, "
               f"(k+4, k) {hits[2]}, one rounding per instruction {hits[3]}  of {m32.numel()}")
         assert hits[train._REFINE_VALU_VARIANT] == 0, hits
@@ -203,3 +212,37 @@ def test_eval_mode_refinement(B, N, kind, cuda_device):
         assert d_ref <= max(d_raw, 1e-6) and d_ref < 1e-3
     assert torch.isfinite(lp_st).all() and (lp_st - lp32).abs().max().item() < 5e-2
     assert torch.isnan(lp_nan[1]).all() and torch.isfinite(lp_nan[0]).all() and torch.isfinite(lp_nan[2:]).all()
+
+
+@pytest.mark.parametrize("B,N,spread", [(5, 4096, "all"), (3, 33, "one"), (9, 1000, "few"), (2, 70000, "few")])
+def test_refine_over_distinct_points_equals_the_per_channel_kernel(B, N, spread, cuda_device):
+    """trunk_pool_refine_dedup_kernel against the per-(cloud, channel) kernel on constructed arg-max tables: every point
+    distinct (1,024 of them: 16 chunks), all channels on ONE point, a few points with repeats, and N too large for the
+    bitmap (falls back to the per-channel kernel) — bit-identical, with and without the input transform / layer-1 affine."""
+    from pointnetgpd_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    dev = cuda_device
+    x = (torch.rand(B, 3, N, generator=g) - 0.5).mul(0.1).to(dev)
+    w1, b1 = torch.randn(64, 3, generator=g).to(dev), (torch.randn(64, generator=g) * 0.1).to(dev)
+    s1c, t1c = (torch.rand(64, generator=g) + 0.5).to(dev), (torch.randn(64, generator=g) * 0.1).to(dev)
+    w2 = (torch.randn(128, 64, generator=g) * 0.2).to(dev)
+    s2c, t2c = (torch.rand(128, generator=g) + 0.5).to(dev), (torch.randn(128, generator=g) * 0.1).to(dev)
+    w3 = (torch.randn(1024, 128, generator=g) * 0.1).to(dev)
+    g3 = torch.randn(1024, generator=g).to(dev)
+    sgn = torch.where(g3 >= 0, 1.0, -1.0)
+    w2p, w3sp = ops.pack_mfma_b(w2), ops.pack_mfma_b(w3, scale=sgn)
+    trans = (torch.eye(3).repeat(B, 1, 1) + 0.1 * torch.randn(B, 3, 3, generator=g)).to(dev)
+    if spread == "all":
+        idx = torch.stack([torch.randperm(N, generator=g)[:1024] for _ in range(B)])
+    elif spread == "one":
+        idx = torch.randint(0, N, (B, 1), generator=g).repeat(1, 1024)
+    else:
+        pool = torch.randint(0, N, (B, 90), generator=g)
+        idx = torch.gather(pool, 1, torch.randint(0, 90, (B, 1024), generator=g))
+    idx = idx.to(torch.int32).to(dev).contiguous()
+    for T in (None, trans):
+        for aff in ((None, None), (s1c, t1c)):
+            for v in (1, 2):
+                ref = ops.trunk_pool_refine(x, T, w1, b1, aff[0], aff[1], w2p, s2c, t2c, idx, w3=w3, g3=g3, variant=v)
+                got = ops.trunk_pool_refine(x, T, w1, b1, aff[0], aff[1], w2p, s2c, t2c, idx, w3=w3, g3=g3, w3sp=w3sp, variant=v)
+                assert torch.equal(got, ref), (v, (got - ref).abs().max().item())

@@ -19,4 +19,4 @@ for nt in (1, 3):
     print(json.dumps({"nterms": nt, "B": B, "N": N, "ms": {k: v["avg_ms"] for k, v in r["passes"].items()},
                       "hbm_frac": {k: v["frac_of_hbm_peak"] for k, v in r["passes"].items()},
                       "mfma_frac": {k: v["frac_of_bf16_mfma_peak"] for k, v in r["passes"].items()},
-                      "x2_ms": r["trunk_passes_ms_x2"], "checksums": r["checksums"]}))
+                      "x2_ms": r["trunk_passes_ms_x2"], "pool_refine": r.get("pool_refine"), "checksums": r["checksums"]}))
