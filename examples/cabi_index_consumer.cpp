@@ -19,6 +19,10 @@
 #include <vector>
 
 #include "pngpd.h"
+// the sampler's 3x3 eigen-decomposition + frame construction, compiled for the HOST here (same source as the kernel; its
+// arithmetic must not be contracted: the pragma below and the one in pngpd_gpg.hip make both builds round alike)
+#pragma clang fp contract(off)
+#include "../pointnetgpd_amd/csrc/pngpd_gpg_eig3.h"
 
 #define HIP_OK(e)                                                                        \
     do {                                                                                 \
@@ -319,6 +323,28 @@ static int run() {
         std::vector<int> ns(K);
         if (download(dns, ns)) return 2;
         std::printf("gpg_moments nsel %d %d %d\n", ns[0], ns[1], ns[K - 1]);
+        // ABI v7: local frames on the device (np.linalg.eig as LAPACK's DGEEV evaluates it) == the host build of the same
+        // header, bit for bit; the query with the empty ball (M == 0) is flagged and parked
+        std::vector<double> Mh((size_t)K * 9), na((size_t)K * 3);
+        if (download(dM, Mh)) return 2;
+        for (auto &v : na) v = g.next();
+        double *dna, *dfr; int *dfl;
+        if (upload(na, &dna) || dalloc(&dfr, (size_t)K * 12) || dalloc(&dfl, K)) return 2;
+        PN_OK(pngpd_gpg_frames(dM, dna, dq, K, dfr, dfl, st));
+        HIP_OK(hipStreamSynchronize(st));
+        std::vector<double> fr((size_t)K * 12); std::vector<int> fl(K);
+        if (download(dfr, fr) || download(dfl, fl)) return 2;
+        int bad = 0;
+        for (int i = 0; i < K; ++i) {
+            double f[12];
+            const int flag = pn_gpg_local_frame(&Mh[(size_t)i * 9], &na[(size_t)i * 3], &q[(size_t)i * 3], f);
+            bad += flag != fl[i];
+            for (int k = 0; k < 12; ++k) bad += !(f[k] == fr[(size_t)i * 12 + k]);
+        }
+        std::printf("gpg_frames == host build of pngpd_gpg_eig3.h: %s (flags %d %d, mismatches %d)\n", bad ? "NO" : "yes",
+                    fl[0], fl[1], bad);
+        if (bad || fl[0] != 1) return 4;
+        hipFree(dna); hipFree(dfr); hipFree(dfl);
     }
     // hand boxes in the grasp frame (the four boxes of check_collision_square, coarse but valid bounds)
     std::vector<double> boxes = {0.0, HD, -OW / 2, OW / 2, -HH / 2, HH / 2,              // open region

@@ -196,3 +196,5 @@ def test_cabi_index_consumer_cross_checks(cuda_device):
         assert tag in out.stdout, (tag, out.stdout[-1500:])
     line = [l for l in out.stdout.splitlines() if l.startswith("gpg_chain")][0]
     assert "indexed_vs_bruteforce_mismatches 0" in line and int(line.split("potential")[1].split()[0]) > 0
+    # ABI v7: pngpd_gpg_frames (np.linalg.eig as LAPACK evaluates it, on the device) == the host build of the same header
+    assert "gpg_frames == host build of pngpd_gpg_eig3.h: yes" in out.stdout, out.stdout[-1500:]
