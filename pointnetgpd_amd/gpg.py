@@ -605,8 +605,10 @@ class GpgGraspSamplerPcl:
             fl = rd["host_t"][rd["nres"]:rd["nres"] + K].numpy().astype(np.int64)
             m_zero = (fl & 1) != 0
             if (fl & 12).any():
-                raise RuntimeError(f"pngpd_gpg_frames: {int(((fl & 4) != 0).sum())} moment matrices did not converge, "
-                                   f"{int(((fl & 8) != 0).sum())} are outside DGEEV's unscaled range; use eig='lapack'")
+                # (np.linalg.eig raises LinAlgError on non-finite input too; DGEEV's rescaling / DLAQR0 paths are not restated)
+                raise RuntimeError(f"pngpd_gpg_frames: {int(((fl & 8) != 0).sum())} moment matrices are non-finite (NaN "
+                                   f"normals?) or outside DGEEV's unscaled range, {int(((fl & 4) != 0).sum())} did not "
+                                   f"converge in 300 QR sweeps; eig='lapack' runs the library itself")
             self.last_stats["eig_complex_pairs"] = self.last_stats.get("eig_complex_pairs", 0) + int(((fl & 2) != 0).sum())
             rd.pop("frames_d", None); rd.pop("flags_d", None); self._unpin(rd.pop("q_h", None))
         self.last_stats["potential"] = self.last_stats.get("potential", 0) + int(host[-1])
