@@ -107,48 +107,6 @@ __device__ __forceinline__ void lane_max_moments(const f32x16 &a0, const f32x16 
 }
 
 
-// The same for the REDUCED-PRECISION passes (bf16 / bf16x3 products: the matrix pass only CHOOSES the point there, its value is
-// re-evaluated in fp32 by the pool refinement): the row of the maximum comes out of a second v_max3 tree over the values with
-// their low 6 mantissa bits replaced by (63 - row code) — 32 v_and_or + 16 v_max3 instead of 16 packed subtracts (two
-// issue slots each), 32 v_and_or and 16 v_min3: 32 slots fewer per call, 64 of the ~330 a channel block's epilogue
-// issues (HISTORY 9: that epilogue's instruction count is what bounds pass C of these modes).  The row is the FIRST
-// maximum up to differences in the replaced bits: among values equal in their upper 26 bits (2^-17 relative — below the
-// products' own error) the lowest row wins for positive maxima, the highest for negative ones.  m itself is exact.
-__device__ __forceinline__ void lane_max_moments_keyed(const f32x16 &a0, const f32x16 &a1, float &m, int &row,
-                                                       float &su, float &qu) {
-    float v[32];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { v[r] = a0[r]; v[16 + r] = a1[r]; }
-    float t[11];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) t[i] = max3f(v[3 * i], v[3 * i + 1], v[3 * i + 2]);
-    t[10] = __builtin_fmaxf(v[30], v[31]);
-    m = max3f(max3f(t[0], t[1], t[2]), max3f(t[3], t[4], t[5]), max3f(max3f(t[6], t[7], t[8]), t[9], t[10]));
-    f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
-    float k[32];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const f32x2 p = {v[2 * i], v[2 * i + 1]};
-        s2 += p;
-        q2 = __builtin_elementwise_fma(p, p, q2);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int r = 2 * i + e;
-            const unsigned code = (unsigned)(((r & 15) & 3) + 8 * ((r & 15) >> 2) + 32 * (r >> 4));
-            k[r] = __uint_as_float((__float_as_uint(v[r]) & 0xffffffc0u) | (63u - code));
-        }
-    }
-    float u[11];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) u[i] = max3f(k[3 * i], k[3 * i + 1], k[3 * i + 2]);
-    u[10] = __builtin_fmaxf(k[30], k[31]);
-    const float mk = max3f(max3f(u[0], u[1], u[2]), max3f(u[3], u[4], u[5]), max3f(max3f(u[6], u[7], u[8]), u[9], u[10]));
-    row = 63 - (int)(__float_as_uint(mk) & 63u);
-    su = s2[0] + s2[1];
-    qu = q2[0] + q2[1];
-}
-
-
 // Dynamic LDS above 48 KB needs a per-kernel opt-in.  Idempotent and checked on every call: no "already set"
 // flag to race on, and a failure is reported instead of surfacing later as a launch error.
 static inline int pngpd_allow_lds(const void *fn, size_t bytes) {

@@ -523,8 +523,8 @@ __global__ __launch_bounds__(512, 2) void trunk_fwd_train_x3_kernel(
                 // lane_max_moments (pngpd_tile.h): exact first maximum + both moments of 32 values without compares;
                 // the two halves of the 128-point tile are merged with "earlier rows win ties"
                 float m1, s1, q1; int r1;
-                lane_max_moments_keyed(c0, c1, m, am, su, qu);
-                lane_max_moments_keyed(c2, c3, m1, r1, s1, q1);
+                lane_max_moments(c0, c1, m, am, su, qu);
+                lane_max_moments(c2, c3, m1, r1, s1, q1);
                 if (m1 > m) { m = m1; am = 64 + r1; }
                 am += 4 * h;
                 su += s1; qu += q1;
