@@ -211,7 +211,7 @@ class GraphedForward:
                     self.model(self.x)          # warm-up: builds the fold cache outside the capture
             torch.cuda.current_stream(dev).wait_stream(side)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):   # (see train.GraphedTrainStep)
                 self.logp, self.trans = self.model(self.x)
 
     @torch.no_grad()

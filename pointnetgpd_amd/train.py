@@ -686,7 +686,9 @@ class GraphedTrainStep:
         torch.cuda.synchronize(dev)
         optimizer.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: the capture must not be invalidated by another thread's event query — torch.distributed's RCCL
+        # watchdog polls the completed collectives of earlier steps (bench_strong aborted on exactly that, once in three runs)
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.loss, self.logp = one_step()
         # undo warm-up + capture-time side effects, in place (the graph holds these addresses)
         with torch.no_grad():
