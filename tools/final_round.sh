@@ -55,6 +55,7 @@ fi
 [ -f build_probe/lib_tm.so ] && PNGPD_LIB=$GRAFT_REPO_ROOT/build_probe/lib_tm.so timeout 200 python tools/phase_times_c_x3.py 2>/dev/null > gpurun_out/${TAG}_phase_times_c_x3.txt
 [ -x build_probe/ds_tr_probe ] && ./build_probe/ds_tr_probe 16 0 > gpurun_out/${TAG}_ds_tr_probe.txt 2>&1
 # round 6: in-box counts / crop kernel times on the dense (sampled-candidates) scene; distinct arg-max points per cloud
+timeout 200 python tools/bench_small_graph.py 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_small_graph.json
 timeout 200 python tools/probe_crop_counts.py 2>/dev/null | tail -1 > gpurun_out/${TAG}_probe_crop_counts.json
 timeout 200 python tools/probe_unique_args.py 2>/dev/null | tail -1 > gpurun_out/${TAG}_probe_unique_args.json
 ls gpurun_out | grep ${TAG}
