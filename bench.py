@@ -228,7 +228,7 @@ def config5_gpg_leg(dev, dist, world, rank, samples=172000, P=50000, N=1024, k=3
     def once_pipelined():
         """One process, one GPU: the sampler's rounds feed the scorer as they complete (scoring.GraspScorer.score_chunks
         over gpg.GpgGraspSamplerPcl.iter_rounds) — scoring on a side stream under the next round's sampler kernels and
-        its host eig.  (More than one rank: a rank's global candidate offset, which keys its resampling draws, is known
+        its host work.  (More than one rank: a rank's global candidate offset, which keys its resampling draws, is known
         only when the ranks below it have finished sampling — that leg stays serial.)"""
         rounds = sampler.iter_rounds(cloud, pfs, nrm, 10 ** 9, len(mine), sample_indices=mine)
         res = scorer.score_chunks(cloud, scoring.on_priority_stream(rounds, dev))

@@ -551,8 +551,8 @@ int pngpd_gpg_normal_moments(const void *cloud, int cloud_is_f64, const double *
  * pngpd_hand_box_counts_indexed): the chunk spheres bound the max_nn-th nearest distance, only the chunks that can hold
  * a selected point are scanned (a handful on a dense cloud instead of all P points, 11 times).  order (P) int32: sorted
  * position -> ORIGINAL index (ties at the cut go to the lower original index; normals stay in original order).
- * Same selected set as pngpd_gpg_normal_moments and the same order of additions: M is bit-identical (LAPACK's
- * eigenvector signs on the host can flip on a last-bit change).  max_nn <= 1024, else PNGPD_ERR_UNSUPPORTED.         */
+ * Same selected set as pngpd_gpg_normal_moments and the same order of additions: M is bit-identical (the eigenvector
+ * signs of the decomposition that follows can flip on a last-bit change).  max_nn <= 1024, else PNGPD_ERR_UNSUPPORTED.         */
 int pngpd_gpg_normal_moments_indexed(const void *cloud_sorted, int cloud_is_f64, const int *order,
                                      const double *normals, int P, const double *spheres, int C,
                                      const double *queries, int K, double radius, int max_nn, double *M_out,

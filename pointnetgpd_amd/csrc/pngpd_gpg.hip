@@ -316,8 +316,8 @@ __global__ __launch_bounds__(256) void hand_box_counts_indexed_kernel(
 // =======================================================================================================
 // Selection logic of the sampler on the device (grasp_sampler.py:1524-1650): pose enumeration, the middle admissible
 // offset per rotation, the 30-degree rule, push-in poses with the table back-off, the first accepted push-in step and
-// the packing of the result.  Only the 3x3 eigen-decomposition stays on the host (LAPACK's arbitrary eigenvector signs
-// decide the enumeration order and cannot be restated).  Every expression keeps numpy's operation order.
+// the packing of the result.  (The 3x3 eigen-decomposition ahead of it — whose eigenvector signs decide the enumeration
+// order — is gpg_frames_kernel, round 6: LAPACK's DGEEV restated.)  Every expression keeps numpy's operation order.
 //   prm (doubles): [0] init_bite [1] hand_depth [2] hand_depth*0.5 [3] APPROACH_STEP [4] TABLE_CLEARANCE
 //                  [5] hh*0.5 [6] -(hh*0.5) [7] -(ow*0.5) [8] ow*0.5 [9] -fw [10] fw [11] -hh [12] APPROACH_STEP*3 factor
 //                  [16..16+R) dtheta (rad)   [48..48+D) lateral offsets dy   [80..80+S) push-in step numbers

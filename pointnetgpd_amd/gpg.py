@@ -658,7 +658,9 @@ class GpgGraspSamplerPcl:
             return
         rng = np.random.default_rng(seed)
         explicit = None if sample_indices is None else np.asarray(sample_indices, dtype=np.int64).reshape(-1)
-        # Rounds of up to ``batch_samples`` draws run as a three-stage pipeline on ONE stream, two rounds ahead:
+        # Rounds of up to ``batch_samples`` draws run as a three-stage pipeline on ONE stream, two rounds ahead
+        # (eig="lapack"; with eig="device" the host's eig(k) slot is empty — frames(k) runs right behind mom(k) on the
+        # device — and the same schedule simply keeps two rounds of device work queued ahead of the host's collect):
         #     device:  mom(0) mom(1) | chain(0) mom(2) | chain(1) mom(3) | ...
         #     host:                    eig(0)          | eig(1) collect(0) | eig(2) collect(1) | ...
         # The moments of round k+2 are enqueued behind chain(k), so their download is complete when the host turns to

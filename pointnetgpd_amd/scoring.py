@@ -71,7 +71,7 @@ class GraspScorer:
         """``score`` over candidates that ARRIVE in chunks — an iterable of (n,5,3) float64 arrays in candidate order,
         e.g. ``GpgGraspSamplerPcl.iter_rounds`` — with the crop + resample + PointNet work of every full batch enqueued
         on a SIDE stream as soon as its candidates exist (``overlap=True``): the device scores round k's candidates
-        while the sampler's round k+1 (its kernels on the caller's stream, its ``np.linalg.eig`` on the host) runs.
+        while the sampler's round k+1 (its kernels on the caller's stream) runs.
         Replaces the strictly serial ``grasps = sample_grasps(...); collect_pc(...); for each grasp: test_network``
         of kinect2grasp.py:141-150,443-514.  Results are those of ``score(cloud, concatenate(chunks))`` bit for bit:
         a candidate's crop, keyed draw and forward depend on nothing but the candidate (and its global index).
@@ -327,7 +327,7 @@ def detect_grasps(scene_cloud, surface_normal, scorer, sampler=None, num_grasps=
         index = gpg.CloudIndex(cloud_d)               # ONE spatial index per scene, shared by the sampler and the crop
         if pipelined:
             # the sampler's rounds feed the scorer as they complete: scoring of round k (side stream) runs while the
-            # sampler's round k+1 is on the device and its eig on the host (VERDICT r5 missing #5)
+            # sampler's round k+1 is on the device (VERDICT r5 missing #5)
             rounds = sampler.iter_rounds(cloud_d, pfs, surface_normal, num_grasps, max_num_samples,
                                          sample_indices=sample_indices, seed=seed, scene_index=index)
             return scorer.score_chunks(cloud_d, on_priority_stream(rounds, dev), scene_index=index)
