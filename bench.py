@@ -920,6 +920,19 @@ def main():
             local_rank, backend = 0, "gloo"
             torch.cuda.set_device(0)
             dist.init_process_group("gloo")
+            # Eight processes on ONE device: their first train-mode HIP forward (the first launch out of the training
+            # translation units: the runtime loads those code objects then) would otherwise happen in all of them at the
+            # same instant, behind the replica broadcast — the one circumstance under which a rank is occasionally lost to
+            # HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION (HISTORY.md 9: 4-8 of 30 launches; 1 of 30 with the ranks taking turns
+            # here; never with one process per GPU).  Debug construct only.
+            import time as _t
+            _t.sleep(0.5 * rank)
+            _m = build_model(64, 2, torch.device("cuda", 0)).train()
+            with torch.no_grad():
+                _m(torch.randn(4, 3, 64, device="cuda:0"))
+            torch.cuda.synchronize()
+            del _m
+            dist.barrier()
         else:
             backend = "nccl"           # RCCL on ROCm
             torch.cuda.set_device(local_rank)
