@@ -251,6 +251,17 @@ def run(variant, argv=None):
     rank, world, local_rank = ddp.init_from_env("nccl" if (args.cuda and not one_gpu_debug) else "gloo")
     if one_gpu_debug:
         local_rank = 0
+        if args.cuda and world > 1:
+            # (debug construct only) the ranks take turns on their first train-mode HIP forward: eight processes loading the
+            # training kernels' code objects on ONE device at the same instant occasionally lose a rank (bench.py, HISTORY 9)
+            import torch.distributed as _dist
+            time.sleep(0.5 * rank)
+            _m = PointNetCls(num_points=64, input_chann=3, k=2).cuda().train()
+            with torch.no_grad():
+                _m(torch.randn(4, 3, 64, device="cuda"))
+            torch.cuda.synchronize()
+            del _m
+            _dist.barrier()
     if args.cuda:
         torch.cuda.manual_seed(1)
     if args.seed is None:
